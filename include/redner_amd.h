@@ -1,0 +1,203 @@
+/* redner_amd.h -- C ABI of the MI355X-native differentiable path tracer.
+ *
+ * This is the drop-in boundary for the one hot path of BachiLi/redner: everything the reference's
+ * pybind11 module `redner` (src/redner.cpp:20-272) exposes for rendering, expressed as plain C
+ * structs, raw pointers and sizes -- no torch / pybind types.  The Python module
+ * redner_amd/redner.py re-creates the reference's class surface (redner.Camera, redner.Shape,
+ * redner.Scene, redner.render, ...) on top of these entry points via ctypes, so the unmodified
+ * pyredner/render_pytorch.py runs against it.
+ *
+ * Pointer conventions are the reference's own (src/ptr.h:10-24: raw addresses, no ownership, no
+ * size, 0 = absent): `dev` pointers address GPU memory of device `gpu_index` (torch CUDA/HIP
+ * tensors' data_ptr()), `host` pointers address CPU memory and are read during the call that
+ * receives them.  All outputs are caller-owned and ACCUMULATED into (+=), never overwritten
+ * (src/primary_contribution.cpp:39-43, src/atomic.h:43-141).
+ *
+ * Error handling: the reference aborts (assert/exit(1), src/cuda_utils.h:12-16).  Here every
+ * entry point that can fail returns NULL / non-zero and writes a message retrievable with
+ * rdr_last_error(); the Python layer raises RuntimeError.  There is NO CPU fallback: creating a
+ * scene with use_gpu == 0, or without a usable gfx950 device, is an error.
+ */
+#ifndef REDNER_AMD_H
+#define REDNER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDR_MAX_MIP_LEVELS 8 /* src/texture.h:11 max_num_texels */
+
+/* enum values follow the declaration order of the reference's enums */
+enum rdr_camera_type { RDR_CAMERA_PERSPECTIVE = 0, RDR_CAMERA_ORTHOGRAPHIC = 1, RDR_CAMERA_FISHEYE = 2,
+                       RDR_CAMERA_PANORAMA = 3 };                 /* src/camera.h:12-17   */
+enum rdr_sampler_type { RDR_SAMPLER_INDEPENDENT = 0, RDR_SAMPLER_SOBOL = 1 }; /* src/pathtracer.h:11-14 */
+enum rdr_channel {                                                /* src/channels.h:6-23  */
+    RDR_CH_RADIANCE = 0, RDR_CH_ALPHA, RDR_CH_DEPTH, RDR_CH_POSITION, RDR_CH_GEOMETRY_NORMAL,
+    RDR_CH_SHADING_NORMAL, RDR_CH_UV, RDR_CH_BARYCENTRIC_COORDINATES, RDR_CH_DIFFUSE_REFLECTANCE,
+    RDR_CH_SPECULAR_REFLECTANCE, RDR_CH_ROUGHNESS, RDR_CH_GENERIC_TEXTURE, RDR_CH_VERTEX_COLOR,
+    RDR_CH_SHAPE_ID, RDR_CH_TRIANGLE_ID, RDR_CH_MATERIAL_ID
+};
+
+/* redner.Camera(...)  src/redner.cpp:34-50, src/camera.h:19-84.  All pointers HOST, read at
+ * scene creation.  cam_to_world != NULL selects the matrix parameterisation (use_look_at = 0). */
+typedef struct rdr_camera_desc {
+    int width, height;
+    const float *position, *look, *up;          /* 3 floats each, or NULL */
+    const float *cam_to_world, *world_to_cam;   /* 16 floats row-major, or NULL */
+    const float *intrinsic_mat_inv, *intrinsic_mat; /* 9 floats row-major */
+    const float *distortion_params;             /* 8 floats or NULL */
+    float clip_near;
+    int camera_type;                            /* rdr_camera_type */
+    int viewport_beg[2], viewport_end[2];       /* (x, y) */
+} rdr_camera_desc;
+
+/* redner.DCamera(...)  src/redner.cpp:52-60.  DEV pointers to fp32 gradient buffers (or NULL). */
+typedef struct rdr_dcamera_desc {
+    float *position, *look, *up, *cam_to_world, *world_to_cam, *intrinsic_mat_inv, *intrinsic_mat,
+          *distortion_params;
+} rdr_dcamera_desc;
+
+/* redner.Shape(...)  src/redner.cpp:84-104, src/shape.h:9-61.  DEV pointers. */
+typedef struct rdr_shape_desc {
+    const float *vertices;      /* [num_vertices, 3] */
+    const int32_t *indices;     /* [num_triangles, 3] */
+    const float *uvs;           /* [num_uv_vertices, 2] or NULL */
+    const float *normals;       /* [num_normal_vertices, 3] or NULL */
+    const int32_t *uv_indices;  /* or NULL */
+    const int32_t *normal_indices; /* or NULL */
+    const float *colors;        /* [num_vertices, 3] or NULL */
+    int num_vertices, num_uv_vertices, num_normal_vertices, num_triangles;
+    int material_id, light_id;
+} rdr_shape_desc;
+
+/* redner.DShape(vertices, uvs, normals, colors)  src/redner.cpp:106-110.  DEV fp32. */
+typedef struct rdr_dshape_desc { float *vertices, *uvs, *normals, *colors; } rdr_dshape_desc;
+
+/* redner.Texture1/3/N(...)  src/redner.cpp:112-131, src/texture.h:14-47.  DEV pointers.
+ * A constant texture has num_levels = 1 and width[0] = height[0] = 0. */
+typedef struct rdr_texture_desc {
+    const float *texels[RDR_MAX_MIP_LEVELS];
+    int width[RDR_MAX_MIP_LEVELS], height[RDR_MAX_MIP_LEVELS];
+    int channels;       /* 1, 3, or N for the generic texture */
+    int num_levels;     /* 0 = texture absent */
+    const float *uv_scale; /* 2 floats */
+} rdr_texture_desc;
+
+/* redner.Material(...)  src/redner.cpp:133-151 */
+typedef struct rdr_material_desc {
+    rdr_texture_desc diffuse_reflectance, specular_reflectance, roughness, generic_texture, normal_map;
+    int compute_specular_lighting, two_sided, use_vertex_color;
+} rdr_material_desc;
+
+/* redner.DMaterial(...)  src/redner.cpp:153-158: same shape, texel pointers are fp32 gradients */
+typedef struct rdr_dtexture_desc {
+    float *texels[RDR_MAX_MIP_LEVELS];
+    int num_levels;
+    float *uv_scale;
+} rdr_dtexture_desc;
+typedef struct rdr_dmaterial_desc {
+    rdr_dtexture_desc diffuse_reflectance, specular_reflectance, roughness, generic_texture, normal_map;
+} rdr_dmaterial_desc;
+
+/* redner.AreaLight(shape_id, intensity, two_sided, directly_visible)  src/redner.cpp:160-164.
+ * intensity is copied (the reference reads its HOST pointer in the constructor). */
+typedef struct rdr_area_light_desc {
+    int shape_id;
+    float intensity[3];
+    int two_sided, directly_visible;
+} rdr_area_light_desc;
+/* redner.DAreaLight(intensity)  src/redner.cpp:166-167.  DEV fp32[3]. */
+typedef struct rdr_darea_light_desc { float *intensity; } rdr_darea_light_desc;
+
+/* redner.EnvironmentMap(...)  src/redner.cpp:169-177.  values/cdfs DEV, matrices HOST. */
+typedef struct rdr_envmap_desc {
+    rdr_texture_desc values;
+    const float *env_to_world, *world_to_env;   /* 16 floats, HOST */
+    const float *sample_cdf_ys, *sample_cdf_xs; /* DEV */
+    float pdf_norm;
+    int directly_visible;
+} rdr_envmap_desc;
+typedef struct rdr_denvmap_desc { rdr_dtexture_desc values; float *world_to_env; } rdr_denvmap_desc;
+
+/* redner.RenderOptions(seed, num_samples, max_bounces, channels, sampler_type, sample_pixel_center)
+ * src/redner.cpp:207-216, src/pathtracer.h:16-23.
+ * Extension for multi-GPU sample sharding (no reference counterpart): this
+ * call renders Sobol' samples [sample_offset, sample_offset + num_samples) of a total_samples-spp
+ * estimate, i.e. with weight 1/total_samples.  total_samples == 0 means "num_samples". */
+typedef struct rdr_render_options {
+    uint64_t seed;
+    int num_samples, max_bounces;
+    const int *channels; int num_channels;   /* rdr_channel values */
+    int sampler_type;                        /* rdr_sampler_type */
+    int sample_pixel_center;
+    int sample_offset, total_samples;
+} rdr_render_options;
+
+/* redner.DScene(...)  src/redner.cpp:75-82 */
+typedef struct rdr_dscene_desc {
+    rdr_dcamera_desc camera;
+    const rdr_dshape_desc *shapes; int num_shapes;
+    const rdr_dmaterial_desc *materials; int num_materials;
+    const rdr_darea_light_desc *area_lights; int num_area_lights;
+    const rdr_denvmap_desc *envmap;   /* or NULL */
+} rdr_dscene_desc;
+
+typedef struct rdr_scene rdr_scene;
+
+/* redner.Scene(camera, shapes, materials, area_lights, envmap, use_gpu, gpu_index,
+ *              use_primary_edge_sampling, use_secondary_edge_sampling)
+ * src/redner.cpp:62-73, src/scene.cpp:63-307.  Copies the descriptors, keeps the data pointers
+ * (the caller keeps the tensors alive), builds the triangle hierarchy, the light CDFs and the
+ * edge-sampling structures.  Returns NULL on error. */
+rdr_scene *rdr_scene_create(const rdr_camera_desc *camera,
+                            const rdr_shape_desc *shapes, int num_shapes,
+                            const rdr_material_desc *materials, int num_materials,
+                            const rdr_area_light_desc *area_lights, int num_area_lights,
+                            const rdr_envmap_desc *envmap,
+                            int use_gpu, int gpu_index,
+                            int use_primary_edge_sampling, int use_secondary_edge_sampling);
+void rdr_scene_destroy(rdr_scene *scene);
+/* Scene.max_generic_texture_dimension  src/redner.cpp:73 */
+int rdr_scene_max_generic_texture_dimension(const rdr_scene *scene);
+
+/* redner.render(scene, options, rendered_image, d_rendered_image, d_scene, screen_gradient_image,
+ *               debug_image)   src/redner.cpp:257, src/pathtracer.cpp:177-958.
+ * Forward iff rendered_image != NULL ([H_vp, W_vp, C] fp32 DEV, accumulated); backward iff
+ * d_rendered_image != NULL (then d_scene must be given).  Synchronises the device before
+ * returning, like the reference (src/pathtracer.cpp:947-949).  Returns 0 on success. */
+int rdr_render(const rdr_scene *scene, const rdr_render_options *options,
+               float *rendered_image, const float *d_rendered_image,
+               const rdr_dscene_desc *d_scene,
+               float *screen_gradient_image, float *debug_image);
+
+/* redner.compute_num_channels(channels, max_generic_texture_dimension)  src/redner.cpp:201.
+ * Returns -1 for an unknown channel id. */
+int rdr_compute_num_channels(const int *channels, int num_channels, int max_generic_texture_dimension);
+
+/* Message of the last failure on the calling thread ("" if none). */
+const char *rdr_last_error(void);
+
+/* Measurement hooks (no reference counterpart; used by bench.py and the roofline report). */
+typedef struct rdr_trace_stats {
+    double closest_ms, any_ms;           /* accumulated device time of the two traversal kernels */
+    uint64_t closest_launches, any_launches;
+    uint64_t closest_rays, any_rays;
+    uint64_t nodes_visited, tris_tested; /* only counted when counting is enabled */
+} rdr_trace_stats;
+void rdr_trace_stats_enable(int timing, int counting);
+void rdr_trace_stats_reset(void);
+void rdr_trace_stats_get(rdr_trace_stats *out);
+
+/* Closest-hit / any-hit queries on a batch of rays (DEV pointers; 32-byte ray records
+ * {org.xyz, tmin, dir.xyz, tmax}, 8-byte hit records {shape, prim}).  This is the boundary the
+ * reference crosses into Embree/OptiX (src/scene.cpp:503-597, 629-690); exposed for the
+ * traversal parity tests and micro-benchmarks. */
+int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, int num_rays, int any_hit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REDNER_AMD_H */

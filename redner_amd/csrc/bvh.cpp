@@ -1,0 +1,132 @@
+// bvh.cpp -- host-side binned-SAH build of the triangle hierarchy described in bvh.h.
+// Runs once per Scene (the reference rebuilds its Embree/OptiX scene per Scene object too,
+// src/scene.cpp:128-154); GPU-side build/refit is SURVEY.md section 8f row 1.
+#include "bvh.h"
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+namespace rt {
+namespace {
+
+struct Prim { float lo[3], hi[3], c[3]; int shape, prim; float v[9]; };
+
+struct Box {
+    float lo[3], hi[3];
+    Box() { for (int k = 0; k < 3; ++k) { lo[k] = std::numeric_limits<float>::infinity(); hi[k] = -lo[k]; } }
+    void grow(const float *l, const float *h) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], l[k]); hi[k] = std::max(hi[k], h[k]); } }
+    void grow_pt(const float *p) { grow(p, p); }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0) return 0;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Builder {
+    std::vector<Prim> prims;
+    BvhHost out;
+    static constexpr int kBins = 16, kLeafMax = 4;
+
+    void set_bounds(int node, const Box &b) {
+        Node &n = out.nodes[node];
+        for (int k = 0; k < 3; ++k) { n.lo[k] = b.lo[k]; n.hi[k] = b.hi[k]; }
+        pad_box(n.lo, n.hi);
+    }
+
+    void make_leaf(int node, int first, int count) {
+        int slot0 = (int)out.ids.size() / 2;
+        for (int i = first; i < first + count; ++i) {
+            out.tris.insert(out.tris.end(), prims[i].v, prims[i].v + 9);
+            out.ids.push_back(prims[i].shape);
+            out.ids.push_back(prims[i].prim);
+        }
+        out.nodes[node].a = slot0;
+        out.nodes[node].b = count;
+    }
+
+    void build(int node, int first, int count, int depth) {
+        out.depth = std::max(out.depth, depth);
+        Box b, cb;
+        for (int i = first; i < first + count; ++i) { b.grow(prims[i].lo, prims[i].hi); cb.grow_pt(prims[i].c); }
+        set_bounds(node, b);
+        int best_axis = -1, best_bin = -1;
+        float best_cost = std::numeric_limits<float>::infinity();
+        if (count > 1) {
+            for (int axis = 0; axis < 3; ++axis) {
+                float ext = cb.hi[axis] - cb.lo[axis];
+                if (!(ext > 0)) continue;
+                Box bins[kBins]; int cnt[kBins] = {0};
+                float scale = kBins / ext;
+                for (int i = first; i < first + count; ++i) {
+                    int bi = std::min(kBins - 1, std::max(0, (int)((prims[i].c[axis] - cb.lo[axis]) * scale)));
+                    bins[bi].grow(prims[i].lo, prims[i].hi); cnt[bi]++;
+                }
+                float ra[kBins]; int rc[kBins];
+                Box acc; int c = 0;
+                for (int k = kBins - 1; k > 0; --k) { acc.grow(bins[k].lo, bins[k].hi); c += cnt[k]; ra[k] = acc.half_area(); rc[k] = c; }
+                Box l; int lc = 0;
+                for (int k = 0; k < kBins - 1; ++k) {
+                    l.grow(bins[k].lo, bins[k].hi); lc += cnt[k];
+                    if (lc == 0 || rc[k + 1] == 0) continue;
+                    float cost = l.half_area() * lc + ra[k + 1] * rc[k + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = k; }
+                }
+            }
+        }
+        float leaf_cost = b.half_area() * count;
+        bool split = best_axis >= 0 && (count > kLeafMax || best_cost + 1.0f * b.half_area() < leaf_cost);
+        int mid = first + count / 2;
+        if (split) {
+            float ext = cb.hi[best_axis] - cb.lo[best_axis];
+            float scale = kBins / ext;
+            float lo = cb.lo[best_axis];
+            auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p) {
+                int bi = std::min(kBins - 1, std::max(0, (int)((p.c[best_axis] - lo) * scale)));
+                return bi <= best_bin;
+            });
+            mid = (int)(it - prims.begin());
+            if (mid == first || mid == first + count) split = false;
+        }
+        if (!split) {
+            if (count <= kLeafMax) { make_leaf(node, first, count); return; }
+            // degenerate (coincident centroids): median split by index keeps the tree finite
+            mid = first + count / 2;
+        }
+        int left = (int)out.nodes.size();
+        out.nodes.push_back(Node{});
+        out.nodes.push_back(Node{});
+        out.nodes[node].a = left;
+        out.nodes[node].b = 0;
+        build(left, first, mid - first, depth + 1);
+        build(left + 1, mid, first + count - mid, depth + 1);
+    }
+};
+
+} // namespace
+
+BvhHost build_bvh(const std::vector<MeshView> &meshes) {
+    Builder bd;
+    for (size_t s = 0; s < meshes.size(); ++s) {
+        const MeshView &m = meshes[s];
+        for (int t = 0; t < m.num_triangles; ++t) {
+            Prim p; p.shape = (int)s; p.prim = t;
+            for (int k = 0; k < 3; ++k) {
+                int vi = m.indices[3 * t + k];
+                for (int a = 0; a < 3; ++a) p.v[3 * k + a] = m.vertices[3 * vi + a];
+            }
+            for (int a = 0; a < 3; ++a) {
+                p.lo[a] = std::min(p.v[a], std::min(p.v[3 + a], p.v[6 + a]));
+                p.hi[a] = std::max(p.v[a], std::max(p.v[3 + a], p.v[6 + a]));
+                p.c[a] = 0.5f * (p.lo[a] + p.hi[a]);
+            }
+            bd.prims.push_back(p);
+        }
+    }
+    if (bd.prims.empty()) return bd.out;
+    bd.out.nodes.push_back(Node{});
+    bd.build(0, 0, (int)bd.prims.size(), 0);
+    return bd.out;
+}
+
+} // namespace rt

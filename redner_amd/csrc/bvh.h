@@ -1,0 +1,109 @@
+// bvh.h -- the triangle hierarchy that replaces Embree / OptiX Prime
+// (reference call sites: src/scene.cpp:128-154 build, :503-597 intersect(), :629-690 occluded()).
+//
+// Layout (HBM, built once per Scene on the host, see bvh.cpp):
+//   nodes : 32-byte records {lo.xyz, a | hi.xyz, b}.  Inner node: a = index of its left child,
+//           the right child is a+1 (siblings are adjacent, so both children arrive in one 64-byte
+//           fetch); b = 0.  Leaf: a = first triangle slot, b = triangle count (1..4).
+//   tris  : 36-byte records, 9 fp32 (three corners), stored in leaf order.
+//   ids   : per triangle slot {shape id, triangle id} -- read only for accepted hits.
+// These are the 32 B / 36 B units of the traversal kernel's algorithmic-byte count
+// (SURVEY.md section 8d).  All boxes are padded with rt::pad_box so traversal is conservative with
+// respect to the shared hit predicate in raytri.h; the result equals a brute-force scan.
+#pragma once
+#include "raytri.h"
+#include <stdint.h>
+
+namespace rt {
+
+struct Node {
+    float lo[3]; int a;
+    float hi[3]; int b;
+};
+static_assert(sizeof(Node) == 32, "node must be 32 bytes");
+
+struct BvhD {              // device/host view
+    const Node *nodes;
+    const float *tris;     // 9 floats per slot
+    const int *ids;        // 2 ints per slot
+    int num_nodes, num_tris;
+};
+
+struct Counters { unsigned long long nodes, tris; };
+
+// Ray queue records exchanged between the shading stages and the traversal kernels (HBM, dense by
+// queue slot).  A dead slot has tmax < 0 and always reports a miss.
+struct alignas(16) RayRec { float ox, oy, oz, tmin, dx, dy, dz, tmax; };   // 32 B
+struct alignas(8) HitRec { int shape, prim; };                            // 8 B; shape < 0 = miss
+static_assert(sizeof(RayRec) == 32 && sizeof(HitRec) == 8, "queue record sizes");
+
+// One ray against the hierarchy.  ANY = stop at the first accepted hit (occlusion query).
+// `cnt` (optional) tallies node records loaded and triangle records tested.
+template <bool ANY>
+RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], float tnear, float tfar,
+                          Counters *cnt = nullptr) {
+    Hit best{tfar, -1, -1};
+    if (bvh.num_nodes == 0) return best;
+    const float inv[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};
+    int stack[64];
+    int sp = 0;
+    float tn;
+    unsigned long long nn = 1, nt = 0;
+    const Node &root = bvh.nodes[0];
+    if (!ray_box(o, inv, tnear, tfar, root.lo, root.hi, &tn)) { if (cnt) { cnt->nodes += nn; } return best; }
+    int cur = 0;
+    for (;;) {
+        const Node &n = bvh.nodes[cur];
+        if (n.b > 0) {
+            for (int k = 0; k < n.b; ++k) {
+                int slot = n.a + k;
+                const float *t = bvh.tris + 9 * slot;
+                float th;
+                ++nt;
+                if (ray_triangle(o, d, tnear, tfar, t, t + 3, t + 6, &th)) {
+                    int s = bvh.ids[2 * slot], p = bvh.ids[2 * slot + 1];
+                    if (ANY) { if (cnt) { cnt->nodes += nn; cnt->tris += nt; } return Hit{th, s, p}; }
+                    if (closer(th, s, p, best)) best = Hit{th, s, p};
+                }
+            }
+        } else {
+            const Node &l = bvh.nodes[n.a], &r = bvh.nodes[n.a + 1];
+            nn += 2;
+            // keep the window closed at best.t so equal-t candidates are still visited (tie-break)
+            float lim = best.shape < 0 ? tfar : best.t * 1.0000004f + 1e-30f;
+            float tl, tr;
+            bool hl = ray_box(o, inv, tnear, lim, l.lo, l.hi, &tl);
+            bool hr = ray_box(o, inv, tnear, lim, r.lo, r.hi, &tr);
+            if (hl && hr) {
+                int near = n.a, far = n.a + 1;
+                if (tr < tl) { near = n.a + 1; far = n.a; }
+                stack[sp++] = far;
+                cur = near;
+                continue;
+            } else if (hl) { cur = n.a; continue; }
+            else if (hr) { cur = n.a + 1; continue; }
+        }
+        // pop; entries whose box entry lies beyond the current best are re-tested lazily by their
+        // children's box tests (lim shrinks), which keeps the stack to one int per entry.
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    if (cnt) { cnt->nodes += nn; cnt->tris += nt; }
+    return best;
+}
+
+} // namespace rt
+
+#include <vector>
+namespace rt {
+// Host-side build product.
+struct BvhHost {
+    std::vector<Node> nodes;
+    std::vector<float> tris;
+    std::vector<int> ids;
+    int depth = 0;
+};
+struct MeshView { const float *vertices; const int *indices; int num_triangles; };
+// Binned-SAH top-down build over all triangles of all shapes (shape id = position in `meshes`).
+BvhHost build_bvh(const std::vector<MeshView> &meshes);
+}

@@ -1,0 +1,94 @@
+// capi.cpp -- extern "C" entry points declared in include/redner_amd.h.
+#include "../../include/redner_amd.h"
+#include "render.h"
+#include "scene.h"
+#include <cstring>
+#include <exception>
+#include <string>
+
+namespace {
+thread_local std::string g_last_error;
+void set_error(const char *what) { g_last_error = what ? what : "unknown error"; }
+}
+
+extern "C" {
+
+const char *rdr_last_error(void) { return g_last_error.c_str(); }
+
+rdr_scene *rdr_scene_create(const rdr_camera_desc *camera, const rdr_shape_desc *shapes, int num_shapes,
+                            const rdr_material_desc *materials, int num_materials,
+                            const rdr_area_light_desc *area_lights, int num_area_lights,
+                            const rdr_envmap_desc *envmap, int use_gpu, int gpu_index,
+                            int use_primary_edge_sampling, int use_secondary_edge_sampling) {
+    try {
+        g_last_error.clear();
+        return reinterpret_cast<rdr_scene *>(rdr::create_scene(camera, shapes, num_shapes, materials, num_materials,
+                                                               area_lights, num_area_lights, envmap, use_gpu, gpu_index,
+                                                               use_primary_edge_sampling, use_secondary_edge_sampling));
+    } catch (const std::exception &e) {
+        set_error(e.what());
+        return nullptr;
+    }
+}
+
+void rdr_scene_destroy(rdr_scene *scene) { delete reinterpret_cast<rdr::Scene *>(scene); }
+
+int rdr_scene_max_generic_texture_dimension(const rdr_scene *scene) {
+    return scene ? reinterpret_cast<const rdr::Scene *>(scene)->max_generic_texture_dimension : 0;
+}
+
+int rdr_render(const rdr_scene *scene, const rdr_render_options *options, float *rendered_image,
+               const float *d_rendered_image, const rdr_dscene_desc *d_scene, float *screen_gradient_image,
+               float *debug_image) {
+    try {
+        g_last_error.clear();
+        if (!scene || !options) throw std::runtime_error("rdr_render: scene and options are required");
+        const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
+        exec::select_device(1, s.gpu_index);
+        rdr::render(s, *options, rendered_image, d_rendered_image, d_scene, screen_gradient_image, debug_image);
+        return 0;
+    } catch (const std::exception &e) {
+        set_error(e.what());
+        return 1;
+    }
+}
+
+int rdr_compute_num_channels(const int *channels, int num_channels, int max_generic_texture_dimension) {
+    return rdr::compute_num_channels(channels, num_channels, max_generic_texture_dimension);
+}
+
+void rdr_trace_stats_enable(int timing, int counting) {
+    exec::trace_stats().timing = timing != 0;
+    exec::trace_stats().counting = counting != 0;
+}
+void rdr_trace_stats_reset(void) {
+    exec::TraceStats &s = exec::trace_stats();
+    bool t = s.timing, c = s.counting;
+    exec::trace_stats_collect();
+    s = exec::TraceStats();
+    s.timing = t; s.counting = c;
+}
+void rdr_trace_stats_get(rdr_trace_stats *out) {
+    exec::trace_stats_collect();
+    const exec::TraceStats &s = exec::trace_stats();
+    out->closest_ms = s.closest_ms; out->any_ms = s.any_ms;
+    out->closest_launches = s.closest_launches; out->any_launches = s.any_launches;
+    out->closest_rays = s.closest_rays; out->any_rays = s.any_rays;
+    out->nodes_visited = s.nodes; out->tris_tested = s.tris;
+}
+
+int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, int num_rays, int any_hit) {
+    try {
+        g_last_error.clear();
+        const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
+        exec::select_device(1, s.gpu_index);
+        exec::trace(s.bvh, reinterpret_cast<const rt::RayRec *>(rays), reinterpret_cast<rt::HitRec *>(hits), num_rays, any_hit != 0);
+        exec::sync();
+        return 0;
+    } catch (const std::exception &e) {
+        set_error(e.what());
+        return 1;
+    }
+}
+
+} // extern "C"

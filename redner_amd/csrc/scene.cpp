@@ -1,0 +1,229 @@
+// scene.cpp -- Scene construction (see scene.h).
+#include "scene.h"
+#include "surface.h"
+#include "sobol.h"
+#include <memory>
+#include "edges.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+extern "C" const uint64_t rdr_sobol_table[];
+extern "C" const float rdr_ltc_table[];
+
+namespace rdr {
+
+namespace {
+
+template <class T>
+T *to_device(Scene &s, const T *src, size_t count) {
+    T *p = (T *)exec::dmalloc(sizeof(T) * (count ? count : 1));
+    s.owned.push_back(p);
+    if (count) exec::upload(p, src, sizeof(T) * count);
+    return p;
+}
+
+template <class T>
+std::vector<T> from_device(const T *src, size_t count) {
+    std::vector<T> v(count);
+    if (src && count) exec::download(v.data(), src, sizeof(T) * count);
+    return v;
+}
+
+TexD convert_tex(const rdr_texture_desc &t) {
+    TexD r;
+    std::memset(&r, 0, sizeof(r));
+    r.num_levels = std::min(t.num_levels, (int)kMaxMip);
+    r.channels = t.channels;
+    r.uv_scale = t.uv_scale;
+    for (int i = 0; i < r.num_levels; ++i) { r.texels[i] = t.texels[i]; r.width[i] = t.width[i]; r.height[i] = t.height[i]; }
+    return r;
+}
+
+M4 m4_from(const float *p) { M4 m; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m.m[i][j] = p[4 * i + j]; return m; }
+M3 m3_from(const float *p) { M3 m; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m.m[i][j] = p[3 * i + j]; return m; }
+
+} // namespace
+
+Scene::~Scene() {
+    delete_edge_data(edges);
+    for (void *p : owned) exec::dfree(p);
+}
+
+int compute_num_channels(const int *channels, int n, int max_generic) {
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        switch (channels[i]) {
+            case RDR_CH_RADIANCE: case RDR_CH_POSITION: case RDR_CH_GEOMETRY_NORMAL: case RDR_CH_SHADING_NORMAL:
+            case RDR_CH_DIFFUSE_REFLECTANCE: case RDR_CH_SPECULAR_REFLECTANCE: case RDR_CH_VERTEX_COLOR:
+                total += 3; break;
+            case RDR_CH_UV: case RDR_CH_BARYCENTRIC_COORDINATES:
+                total += 2; break;
+            case RDR_CH_ALPHA: case RDR_CH_DEPTH: case RDR_CH_ROUGHNESS: case RDR_CH_SHAPE_ID:
+            case RDR_CH_TRIANGLE_ID: case RDR_CH_MATERIAL_ID:
+                total += 1; break;
+            case RDR_CH_GENERIC_TEXTURE:
+                total += max_generic; break;
+            default: return -1;
+        }
+    }
+    return total;
+}
+
+Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, int num_shapes,
+                    const rdr_material_desc *materials, int num_materials,
+                    const rdr_area_light_desc *area_lights, int num_area_lights,
+                    const rdr_envmap_desc *envmap, int use_gpu, int gpu_index,
+                    int primary_edges, int secondary_edges) {
+    exec::select_device(use_gpu, gpu_index);   // throws when no gfx950 device / use_gpu == 0
+    if (!cam) throw std::runtime_error("Scene: camera is required");
+    if (cam->camera_type != RDR_CAMERA_PERSPECTIVE)
+        throw std::runtime_error("Scene: only the perspective camera is implemented so far "
+                                 "(orthographic/fisheye/panorama: SURVEY.md section 8f row 3)");
+    if (cam->distortion_params)
+        throw std::runtime_error("Scene: lens distortion is not implemented yet (section 8f row 3)");
+    if (envmap)
+        throw std::runtime_error("Scene: environment maps are not implemented yet (section 8f row 3)");
+
+    std::unique_ptr<Scene> sp(new Scene());
+    Scene &s = *sp;
+    s.gpu_index = gpu_index;
+    s.use_primary_edges = primary_edges != 0;
+    s.use_secondary_edges = secondary_edges != 0;
+
+    // ---- camera (src/camera.h:22-65) ----
+    CameraD &c = s.d.cam;
+    std::memset(&c, 0, sizeof(c));
+    c.width = cam->width; c.height = cam->height;
+    c.clip_near = cam->clip_near; c.kind = cam->camera_type;
+    c.vp_x0 = cam->viewport_beg[0]; c.vp_y0 = cam->viewport_beg[1];
+    c.vp_x1 = cam->viewport_end[0]; c.vp_y1 = cam->viewport_end[1];
+    c.intrinsic_mat_inv = m3_from(cam->intrinsic_mat_inv);
+    c.intrinsic_mat = m3_from(cam->intrinsic_mat);
+    if (cam->cam_to_world) {
+        c.cam_to_world = m4_from(cam->cam_to_world);
+        c.world_to_cam = m4_from(cam->world_to_cam);
+        c.use_look_at = 0;
+    } else {
+        c.position = v3f(cam->position); c.look = v3f(cam->look); c.up = v3f(cam->up);
+        c.cam_to_world = look_at(c.position, c.look, c.up);
+        c.world_to_cam = inverse(c.cam_to_world);
+        c.use_look_at = 1;
+    }
+
+    // ---- shapes / materials / lights ----
+    s.shapes.resize(num_shapes);
+    s.h_vertices.resize(num_shapes); s.h_indices.resize(num_shapes);
+    s.h_uvs.resize(num_shapes); s.h_normals.resize(num_shapes);
+    s.h_uv_indices.resize(num_shapes); s.h_normal_indices.resize(num_shapes);
+    for (int i = 0; i < num_shapes; ++i) {
+        const rdr_shape_desc &in = shapes[i];
+        ShapeD &o = s.shapes[i];
+        o.vertices = in.vertices; o.indices = in.indices; o.uvs = in.uvs; o.normals = in.normals;
+        o.uv_indices = in.uv_indices; o.normal_indices = in.normal_indices; o.colors = in.colors;
+        o.num_vertices = in.num_vertices; o.num_uv_vertices = in.num_uv_vertices;
+        o.num_normal_vertices = in.num_normal_vertices; o.num_triangles = in.num_triangles;
+        o.material_id = in.material_id; o.light_id = in.light_id;
+        s.h_vertices[i] = from_device(in.vertices, (size_t)3 * in.num_vertices);
+        s.h_indices[i] = from_device(in.indices, (size_t)3 * in.num_triangles);
+        if (in.normals) s.h_normals[i] = from_device(in.normals, (size_t)3 * (in.num_normal_vertices > 0 ? in.num_normal_vertices : in.num_vertices));
+        if (in.uvs) s.h_uvs[i] = from_device(in.uvs, (size_t)2 * (in.num_uv_vertices > 0 ? in.num_uv_vertices : in.num_vertices));
+        if (in.uv_indices) s.h_uv_indices[i] = from_device(in.uv_indices, (size_t)3 * in.num_triangles);
+        if (in.normal_indices) s.h_normal_indices[i] = from_device(in.normal_indices, (size_t)3 * in.num_triangles);
+        for (int k = 0; k < 3 * in.num_triangles; ++k)
+            if (s.h_indices[i][k] < 0 || s.h_indices[i][k] >= in.num_vertices)
+                throw std::runtime_error("Scene: triangle index out of range in shape " + std::to_string(i));
+        if (in.material_id < 0 || in.material_id >= num_materials)
+            throw std::runtime_error("Scene: material_id out of range in shape " + std::to_string(i));
+    }
+    s.materials.resize(num_materials);
+    for (int i = 0; i < num_materials; ++i) {
+        const rdr_material_desc &in = materials[i];
+        MaterialD &o = s.materials[i];
+        o.diffuse = convert_tex(in.diffuse_reflectance); o.specular = convert_tex(in.specular_reflectance);
+        o.roughness = convert_tex(in.roughness); o.generic = convert_tex(in.generic_texture);
+        o.normal_map = convert_tex(in.normal_map);
+        o.diffuse.channels = 3; o.specular.channels = 3; o.roughness.channels = 1; o.normal_map.channels = 3;
+        o.compute_specular_lighting = in.compute_specular_lighting; o.two_sided = in.two_sided;
+        o.use_vertex_color = in.use_vertex_color;
+        if (o.generic.num_levels > 0)
+            s.max_generic_texture_dimension = std::max(s.max_generic_texture_dimension, o.generic.channels);
+    }
+    s.lights.resize(num_area_lights);
+    for (int i = 0; i < num_area_lights; ++i) {
+        const rdr_area_light_desc &in = area_lights[i];
+        if (in.shape_id < 0 || in.shape_id >= num_shapes) throw std::runtime_error("Scene: area light shape_id out of range");
+        LightD &o = s.lights[i];
+        o.shape_id = in.shape_id; o.two_sided = in.two_sided; o.directly_visible = in.directly_visible;
+        for (int k = 0; k < 3; ++k) o.intensity[k] = in.intensity[k];
+    }
+
+    // ---- light PMF / CDF, per-light area CDF (src/scene.cpp:38-61, 197-253) ----
+    int num_lights = num_area_lights;
+    s.light_pmf.assign(num_lights, 0); s.light_cdf.assign(num_lights, 0); s.light_areas.assign(num_area_lights, 0);
+    s.area_cdf_offset.assign(num_area_lights, 0);
+    {
+        int total_tris = 0;
+        for (int l = 0; l < num_area_lights; ++l) { s.area_cdf_offset[l] = total_tris; total_tris += s.shapes[s.lights[l].shape_id].num_triangles; }
+        s.area_cdf_pool.assign(total_tris, 0);
+        double total_importance = 0;
+        for (int l = 0; l < num_area_lights; ++l) {
+            int sid = s.lights[l].shape_id;
+            ShapeD hs = s.shapes[sid];     // host view of the same shape
+            hs.vertices = s.h_vertices[sid].data(); hs.indices = s.h_indices[sid].data();
+            double *cdf = s.area_cdf_pool.data() + s.area_cdf_offset[l];
+            double total = 0;
+            for (int t = 0; t < hs.num_triangles; ++t) { cdf[t] = tri_area(hs, t); total += cdf[t]; }
+            double run = 0;
+            for (int t = 0; t < hs.num_triangles; ++t) { double a = cdf[t]; cdf[t] = run; run += a; }
+            for (int t = 0; t < hs.num_triangles; ++t) cdf[t] = cdf[t] / total;
+            s.light_areas[l] = total;
+            const float *I = s.lights[l].intensity;
+            float lum = 0.212671f * I[0] + 0.715160f * I[1] + 0.072169f * I[2];   // fp32, as luminance<float>
+            s.light_pmf[l] = total * lum * double(M_PI);
+            total_importance += s.light_pmf[l];
+        }
+        if (num_lights > 0) {
+            if (!(total_importance > 0)) throw std::runtime_error("Scene: total light importance must be positive");
+            for (int l = 0; l < num_lights; ++l) s.light_pmf[l] /= total_importance;
+            s.light_cdf[0] = 0;
+            for (int l = 1; l < num_lights; ++l) s.light_cdf[l] = s.light_cdf[l - 1] + s.light_pmf[l - 1];
+        }
+    }
+
+    // ---- triangle hierarchy ----
+    {
+        std::vector<rt::MeshView> meshes(num_shapes);
+        for (int i = 0; i < num_shapes; ++i)
+            meshes[i] = rt::MeshView{s.h_vertices[i].data(), s.h_indices[i].data(), s.shapes[i].num_triangles};
+        s.bvh_host = rt::build_bvh(meshes);
+        s.bvh.num_nodes = (int)s.bvh_host.nodes.size();
+        s.bvh.num_tris = (int)s.bvh_host.ids.size() / 2;
+        s.bvh.nodes = to_device(s, s.bvh_host.nodes.data(), s.bvh_host.nodes.size());
+        s.bvh.tris = to_device(s, s.bvh_host.tris.data(), s.bvh_host.tris.size());
+        s.bvh.ids = to_device(s, s.bvh_host.ids.data(), s.bvh_host.ids.size());
+    }
+
+    // ---- device copies of the flat tables ----
+    s.d.shapes = to_device(s, s.shapes.data(), s.shapes.size());
+    s.d.materials = to_device(s, s.materials.data(), s.materials.size());
+    s.d.lights = to_device(s, s.lights.data(), s.lights.size());
+    s.d.envmap = nullptr;
+    s.d.num_shapes = num_shapes; s.d.num_materials = num_materials;
+    s.d.num_area_lights = num_area_lights; s.d.num_lights = num_lights;
+    s.d.light_pmf = to_device(s, s.light_pmf.data(), s.light_pmf.size());
+    s.d.light_cdf = to_device(s, s.light_cdf.data(), s.light_cdf.size());
+    s.d.light_areas = to_device(s, s.light_areas.data(), s.light_areas.size());
+    s.d.area_cdf_pool = to_device(s, s.area_cdf_pool.data(), s.area_cdf_pool.size());
+    s.d.area_cdf_offset = to_device(s, s.area_cdf_offset.data(), s.area_cdf_offset.size());
+    s.sobol_table = to_device(s, rdr_sobol_table, (size_t)kSobolTableWords);
+    s.ltc_table = to_device(s, rdr_ltc_table, (size_t)128 * 128 * 9);
+
+    // ---- edge sampling structures ----
+    if (s.use_primary_edges || s.use_secondary_edges) s.edges = build_edge_data(s);
+    return sp.release();
+}
+
+} // namespace rdr

@@ -1,0 +1,57 @@
+// scene.h -- host-side Scene object behind rdr_scene_create().
+//
+// Counterpart of the reference's Scene constructor (src/scene.cpp:63-307): copies the PODs, keeps
+// the caller's data pointers, and builds the acceleration/sampling structures once:
+//   * the triangle hierarchy of bvh.h (replaces the Embree / OptiX Prime scene),
+//   * light PMF/CDF and per-light area CDFs (src/scene.cpp:38-61, 197-253),
+//   * the edge list, its PMF/CDF and the two edge hierarchies (edges.h; src/edge.cpp:233-383,
+//     src/edge_tree.cpp:724-882).
+// Geometry is read back from HBM once for those builds (GPU-side build/refit is section 8f row 1).
+#pragma once
+#include "../../include/redner_amd.h"
+#include "bvh.h"
+#include "scene_data.h"
+#include <string>
+#include <vector>
+
+namespace rdr {
+
+struct EdgeData;   // edges.h
+
+struct Scene {
+    int gpu_index = 0;
+    bool use_primary_edges = false, use_secondary_edges = false;
+    int max_generic_texture_dimension = 0;
+
+    // host mirrors
+    std::vector<ShapeD> shapes;
+    std::vector<MaterialD> materials;
+    std::vector<LightD> lights;
+    std::vector<std::vector<float>> h_vertices, h_uvs, h_normals;
+    std::vector<std::vector<int>> h_indices, h_uv_indices, h_normal_indices;
+    std::vector<double> light_pmf, light_cdf, light_areas, area_cdf_pool;
+    std::vector<int> area_cdf_offset;
+    rt::BvhHost bvh_host;
+
+    // device view
+    SceneD d;
+    rt::BvhD bvh;
+    const uint64_t *sobol_table = nullptr;   // 1024 x 52 u64
+    const float *ltc_table = nullptr;        // 128 x 128 x 9 f32
+    EdgeData *edges = nullptr;
+
+    std::vector<void *> owned;   // device allocations released in the destructor
+    ~Scene();
+};
+
+Scene *create_scene(const rdr_camera_desc *camera,
+                    const rdr_shape_desc *shapes, int num_shapes,
+                    const rdr_material_desc *materials, int num_materials,
+                    const rdr_area_light_desc *area_lights, int num_area_lights,
+                    const rdr_envmap_desc *envmap,
+                    int use_gpu, int gpu_index, int primary_edges, int secondary_edges);
+
+// Channel layout (src/channels.cpp:54-113).  -1 on an unknown channel.
+int compute_num_channels(const int *channels, int n, int max_generic_texture_dimension);
+
+} // namespace rdr

@@ -1,0 +1,280 @@
+// stages_fwd.h -- forward wavefront stages (one lane = one live path).
+//
+// What the reference does in seven launches per bounce over a 280-byte-per-vertex AoS PathBuffer
+// (src/pathtracer.cpp:240-390: sample_primary_rays, intersect+intersect_shape, accumulate_primary_
+// contribs, sample_point_on_light, bsdf_sample, accumulate_path_contribs, ...) is regrouped here
+// around the two traversal launches of a bounce:
+//     GenPrimary -> [closest] -> ShadePrimary -> compact
+//     per bounce:  BounceSample -> [any-hit, closest] -> BounceContrib -> compact
+// Per path vertex only {ray, incoming ray differential, hit ids, throughput, min-roughness, one
+// occlusion bit} stay in HBM (SoA, 185 B/vertex instead of ~1.7 kB): shading points, light points
+// and every random number are *recomputed* from those where needed (the Sobol' stream is
+// stateless), trading fp64 flops, which MI355X has, for HBM bytes, which bound this path.
+//
+// Lanes are addressed like the reference so that sample-exact parity holds: state lives at the
+// lane's own id (pixel id for camera paths, edge-ray id for edge sub-paths), the live-lane list is
+// order-preserving, and lane `p` draws from Sobol' slot `p >> rng_shift` (shift 1 = the two rays of
+// an edge sample share their numbers, src/pathtracer.cpp:630-645 copy_interleave).
+#pragma once
+#include "bsdf.h"
+#include "bvh.h"
+#include "camera.h"
+#include "lights.h"
+#include "sobol.h"
+
+namespace rdr {
+
+// ---- per-vertex state, struct-of-arrays with stride n -------------------------------------------
+struct VSlice {
+    double *ray;      // 6 x n : org.xyz, dir.xyz of the ray arriving at this vertex
+    double *rdiff;    // 12 x n: differential carried by that ray (before transfer onto the surface)
+    int *shape, *tri; // hit ids of this vertex (shape < 0: no hit)
+    double *thr;      // 3 x n : path throughput arriving here
+    double *mrough;   // n     : running minimum roughness
+    unsigned char *occl;   // n: the NEE shadow ray cast from this vertex was blocked
+    int n;
+};
+
+RDR_FN V3 ld3(const double *b, int n, int i, int k) { return V3{b[(size_t)(k) * n + i], b[(size_t)(k + 1) * n + i], b[(size_t)(k + 2) * n + i]}; }
+RDR_FN void st3(double *b, int n, int i, int k, V3 v) { b[(size_t)(k) * n + i] = v.x; b[(size_t)(k + 1) * n + i] = v.y; b[(size_t)(k + 2) * n + i] = v.z; }
+
+RDR_FN Ray load_ray(const VSlice &v, int i) { return make_ray(ld3(v.ray, v.n, i, 0), ld3(v.ray, v.n, i, 3)); }
+RDR_FN void store_ray(const VSlice &v, int i, V3 o, V3 d) { st3(v.ray, v.n, i, 0, o); st3(v.ray, v.n, i, 3, d); }
+RDR_FN RayDiff load_rdiff(const VSlice &v, int i) {
+    return RayDiff{ld3(v.rdiff, v.n, i, 0), ld3(v.rdiff, v.n, i, 3), ld3(v.rdiff, v.n, i, 6), ld3(v.rdiff, v.n, i, 9)};
+}
+RDR_FN void store_rdiff(const VSlice &v, int i, const RayDiff &r) {
+    st3(v.rdiff, v.n, i, 0, r.org_dx); st3(v.rdiff, v.n, i, 3, r.org_dy);
+    st3(v.rdiff, v.n, i, 6, r.dir_dx); st3(v.rdiff, v.n, i, 9, r.dir_dy);
+}
+
+RDR_FN void put_ray(rt::RayRec *q, int slot, const Ray &r, bool dead) {
+    rt::RayRec rec;
+    rec.ox = (float)r.org.x; rec.oy = (float)r.org.y; rec.oz = (float)r.org.z; rec.tmin = (float)r.tmin;
+    rec.dx = (float)r.dir.x; rec.dy = (float)r.dir.y; rec.dz = (float)r.dir.z;
+    rec.tmax = dead ? -1.f : (float)r.tmax;
+    q[slot] = rec;
+}
+
+// Where a stage deposits radiance: the image (camera paths) and/or a per-lane scalar (edge paths).
+struct Sink {
+    float *image;          // [num_pixels * nd], may be null
+    double *edge_contrib;  // [lanes], may be null
+    int nd, radiance_dim;  // channel layout (src/channels.cpp)
+    double weight;         // 1 / spp
+};
+
+struct LightDraw { double light_sel, tri_sel; V2 uv; };
+RDR_FN LightDraw draw_light(const SobolD &rng, int slot, int dim) {
+    return LightDraw{rng.draw(slot, dim), rng.draw(slot, dim + 1), v2(rng.draw(slot, dim + 2), rng.draw(slot, dim + 3))};
+}
+
+// ---- stage: camera rays -------------------------------------------------------------------------
+struct GenPrimary {
+    SceneD sc; SobolD rng; int sample_center;
+    VSlice v0; rt::RayRec *q;
+    RDR_FN void operator()(int p) const {
+        V2 s = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
+        RayDiff rd;
+        Ray r = primary_ray_with_diff(sc.cam, pixel_to_screen(sc.cam, p, s), rd);
+        store_ray(v0, p, r.org, r.dir);
+        store_rdiff(v0, p, rd);
+        st3(v0.thr, v0.n, p, 0, v3(1));
+        v0.mrough[p] = 0;
+        put_ray(q, p, r, false);
+    }
+};
+
+// Emission seen directly along `ray` at a hit (src/primary_contribution.cpp:13-31).
+RDR_FN V3 direct_emission(const SceneD &sc, int shape, int tri, const Ray &ray, const RayDiff &rd) {
+    V3 e = v3(0);
+    if (shape < 0) return e;
+    const ShapeD &sh = sc.shapes[shape];
+    if (sh.light_id >= 0) {
+        const LightD &l = sc.lights[sh.light_id];
+        if (l.directly_visible) {
+            bool facing = true;
+            if (!l.two_sided) {
+                RayDiff tmp;
+                Surf sp = surf_at(sh, tri, ray, rd, tmp);
+                facing = dot(-ray.dir, sp.frame.n) > 0;
+            }
+            if (facing) e += v3f(l.intensity);
+        }
+    }
+    return e;
+}
+
+// ---- stage: first-hit contribution -------------------------------------------------------------
+// Lanes: `active[idx]` (null = identity).  Records the hit ids of vertex `v` from queue slot idx.
+struct ShadePrimary {
+    SceneD sc; const int *active; VSlice v; const rt::HitRec *hits; Sink sink;
+    RDR_FN void operator()(int idx) const {
+        int p = active ? active[idx] : idx;
+        rt::HitRec h = hits[idx];
+        v.shape[p] = h.shape; v.tri[p] = h.shape >= 0 ? h.prim : -1;
+        Ray ray = load_ray(v, p);
+        V3 e = direct_emission(sc, h.shape, h.prim, ray, load_rdiff(v, p));
+        V3 c = sink.weight * ld3(v.thr, v.n, p, 0) * e;
+        if (sink.image) {
+            float *px = sink.image + (size_t)sink.nd * p + sink.radiance_dim;
+            px[0] += float(c.x); px[1] += float(c.y); px[2] += float(c.z);
+        }
+        if (sink.edge_contrib) sink.edge_contrib[p] += sum(c);
+    }
+};
+
+// Everything a bounce needs at its shading vertex, rebuilt from the stored ids.
+struct VertexCtx {
+    Ray ray; RayDiff rd_in, rd_surf; Surf sp; V3 wi; double mrough;
+    const ShapeD *shape; const MaterialD *mat;
+};
+RDR_FN VertexCtx load_vertex(const SceneD &sc, const VSlice &v, int p) {
+    VertexCtx c;
+    c.ray = load_ray(v, p);
+    c.rd_in = load_rdiff(v, p);
+    c.shape = &sc.shapes[v.shape[p]];
+    c.mat = &sc.materials[c.shape->material_id];
+    c.sp = surf_at(*c.shape, v.tri[p], c.ray, c.rd_in, c.rd_surf);
+    c.wi = -c.ray.dir;
+    c.mrough = v.mrough[p];
+    return c;
+}
+
+// ---- stage: draw the NEE point and the BSDF direction, emit both rays ---------------------------
+struct BounceSample {
+    SceneD sc; SobolD rng; int dim, rng_shift;
+    const int *active; VSlice v, vn;
+    rt::RayRec *q_nee, *q_bsdf;
+    RDR_FN void operator()(int idx) const {
+        int p = active[idx];
+        int slot = p >> rng_shift;
+        VertexCtx c = load_vertex(sc, v, p);
+        // next-event estimation ray
+        LightDraw ld = draw_light(rng, slot, dim);
+        LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
+        if (pk.shape_id >= 0) {
+            Surf lp = sample_tri(sc.shapes[pk.shape_id], pk.tri_id, ld.uv);
+            put_ray(q_nee, idx, shadow_ray_to(c.sp.position, lp.position), false);
+        } else {
+            Ray dead = make_ray(c.sp.position, v3(0));
+            put_ray(q_nee, idx, dead, true);
+        }
+        // BSDF ray
+        V2 buv = v2(rng.draw(slot, dim + 4), rng.draw(slot, dim + 5));
+        double bw = rng.draw(slot, dim + 6);
+        RayDiff wo_rd = raydiff_zero();
+        double next_mr;
+        V3 dir = bsdf_sample_dir(*c.mat, c.sp, c.wi, buv, bw, c.mrough, c.rd_surf, wo_rd, next_mr);
+        store_ray(vn, p, c.sp.position, dir);
+        store_rdiff(vn, p, wo_rd);
+        vn.mrough[p] = next_mr;
+        Ray nr = make_ray(c.sp.position, dir);
+        put_ray(q_bsdf, idx, nr, len_sq(dir) <= 1e-3f);
+    }
+};
+
+// Result of evaluating one bounce (shared by the forward and the adjoint stage).
+struct BounceEval {
+    V3 nee, scatter;        // contributions before multiplying the throughput
+    V3 next_thr; bool next_thr_valid;
+};
+
+// NEE + BSDF-hit emission with power-2 MIS (src/path_contribution.cpp:24-118).
+RDR_FN BounceEval eval_bounce(const SceneD &sc, const VertexCtx &c, V3 thr,
+                              bool nee_visible, const LightPick &pk, const Surf &lp,
+                              int bshape, const Surf &bp) {
+    BounceEval r;
+    r.nee = r.scatter = r.next_thr = v3(0);
+    r.next_thr_valid = false;
+    V3 pos = c.sp.position;
+    if (nee_visible && pk.shape_id >= 0) {
+        const ShapeD &lsh = sc.shapes[pk.shape_id];
+        V3 dir = lp.position - pos;
+        double d2 = len_sq(dir);
+        V3 wo = dir / sqrt(d2);
+        if (d2 > 1e-20f && lsh.light_id >= 0) {
+            const LightD &l = sc.lights[lsh.light_id];
+            if (l.two_sided || dot(-wo, lp.frame.n) > 0) {
+                V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
+                double g = fabs(dot(wo, lp.geom_normal)) / d2;
+                double pdf_nee = sc.light_pmf[lsh.light_id] / sc.light_areas[lsh.light_id];
+                double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough) * g;
+                double mis = 1 / (1 + sq(pdf_b / pdf_nee));
+                r.nee = (mis * g / pdf_nee) * f * v3f(l.intensity);
+            }
+        }
+    }
+    if (bshape >= 0) {
+        const ShapeD &bsh = sc.shapes[bshape];
+        V3 dir = bp.position - pos;
+        double d2 = len_sq(dir);
+        V3 wo = dir / sqrt(d2);
+        double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough);
+        r.next_thr_valid = true;
+        if (d2 > 1e-20f && pdf_b > 1e-20f) {
+            V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
+            if (bsh.light_id >= 0) {
+                const LightD &l = sc.lights[bsh.light_id];
+                if (l.two_sided || dot(-wo, bp.frame.n) > 0) {
+                    double inv_area = 1 / sc.light_areas[bsh.light_id];
+                    double g = fabs(dot(wo, bp.geom_normal)) / d2;
+                    double pdf_nee = (sc.light_pmf[bsh.light_id] * inv_area) / g;
+                    double mis = 1 / (1 + sq(pdf_nee / pdf_b));
+                    r.scatter = (mis / pdf_b) * f * v3f(l.intensity);
+                }
+            }
+            r.next_thr = thr * (f / pdf_b);
+        } else {
+            r.next_thr = v3(0);
+        }
+    }
+    return r;
+}
+
+// ---- stage: gather both query results, accumulate the bounce, advance the throughput ------------
+struct BounceContrib {
+    SceneD sc; SobolD rng; int dim, rng_shift;
+    const int *active; VSlice v, vn;
+    const rt::HitRec *h_nee, *h_bsdf;
+    Sink sink;
+    RDR_FN void operator()(int idx) const {
+        int p = active[idx];
+        int slot = p >> rng_shift;
+        VertexCtx c = load_vertex(sc, v, p);
+        LightDraw ld = draw_light(rng, slot, dim);
+        LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
+        Surf lp = surf_zero();
+        if (pk.shape_id >= 0) lp = sample_tri(sc.shapes[pk.shape_id], pk.tri_id, ld.uv);
+        bool blocked = h_nee[idx].shape >= 0;
+        if (v.occl) v.occl[p] = blocked ? 1 : 0;
+        rt::HitRec hb = h_bsdf[idx];
+        vn.shape[p] = hb.shape; vn.tri[p] = hb.shape >= 0 ? hb.prim : -1;
+        Surf bp = surf_zero();
+        if (hb.shape >= 0) {
+            RayDiff tmp;
+            bp = surf_at(sc.shapes[hb.shape], hb.prim, load_ray(vn, p), load_rdiff(vn, p), tmp);
+        }
+        V3 thr = ld3(v.thr, v.n, p, 0);
+        BounceEval e = eval_bounce(sc, c, thr, !blocked, pk, lp, hb.shape, bp);
+        if (e.next_thr_valid) st3(vn.thr, vn.n, p, 0, e.next_thr);
+        V3 pc = thr * (e.nee + e.scatter);
+        if (sink.image) {
+            float *px = sink.image + (size_t)sink.nd * p + sink.radiance_dim;
+            px[0] += float(sink.weight * pc.x); px[1] += float(sink.weight * pc.y); px[2] += float(sink.weight * pc.z);
+        }
+        if (sink.edge_contrib) sink.edge_contrib[p] += sum(sink.weight * pc);
+    }
+};
+
+// Predicates for the order-preserving compaction of the live-lane list.
+struct KeepHit {       // lane survives iff its vertex recorded a hit (update_active_pixels)
+    const int *shape;
+    RDR_FN bool operator()(int p) const { return shape[p] >= 0; }
+};
+struct KeepNonZeroDir {   // init_active_pixels: drop rays with an all-zero direction
+    const double *ray; int n;
+    RDR_FN bool operator()(int p) const { return !all_zero(ld3(ray, n, p, 3)); }
+};
+
+} // namespace rdr

@@ -1,0 +1,63 @@
+// exec.h (host debugging harness) -- TEST INFRASTRUCTURE, not a product path.
+//
+// Single-threaded stand-in for redner_amd/csrc/hip/exec.h so that the *same* stage bodies and
+// host driver can be stepped through with gdb/ASan and compared against the oracle in a container
+// without a GPU.  It is compiled only into tests/hostsim/_build/, is never imported by
+// redner_amd, and the product raises if the HIP library or a GPU is missing.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdexcept>
+#include <string>
+
+#define RDR_FN inline
+#define RDR_HOSTSIM 1
+
+namespace rdr {
+inline void accum(double *p, double v) { *p += v; }
+}
+
+namespace exec {
+inline void *dmalloc(size_t bytes) { void *p = malloc(bytes ? bytes : 16); if (!p) throw std::bad_alloc(); return p; }
+inline void dfree(void *p) { free(p); }
+inline void zero(void *p, size_t bytes) { memset(p, 0, bytes); }
+inline void upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
+inline void download(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
+inline void sync() {}
+template <class F>
+inline void launch(int n, const F &f) { for (int i = 0; i < n; ++i) f(i); }
+} // namespace exec
+
+// ---- host stand-ins for the hand-written kernels (compact.hip / trace.hip) ----------------------
+#include "bvh.h"
+namespace exec {
+inline void select_device(int /*use_gpu*/, int /*gpu_index*/) {}
+template <class P>
+inline int compact(const int *in, int n, int *out, const P &pred) {
+    int c = 0;
+    for (int i = 0; i < n; ++i) { int p = in ? in[i] : i; if (pred(p)) out[c++] = p; }
+    return c;
+}
+struct TraceStats { double closest_ms = 0, any_ms = 0; uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes = 0, tris = 0; bool timing = false, counting = false; };
+inline TraceStats &trace_stats() { static TraceStats s; return s; }
+inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n, bool any) {
+    TraceStats &st = trace_stats();
+    rt::Counters cnt{0, 0};
+    for (int i = 0; i < n; ++i) {
+        const rt::RayRec &r = rays[i];
+        rt::Hit h{0.f, -1, -1};
+        if (!(r.tmax < 0.f)) {
+            float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+            h = any ? rt::traverse<true>(bvh, o, d, r.tmin, r.tmax, st.counting ? &cnt : nullptr)
+                    : rt::traverse<false>(bvh, o, d, r.tmin, r.tmax, st.counting ? &cnt : nullptr);
+        }
+        hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};
+    }
+    (any ? st.any_launches : st.closest_launches)++;
+    (any ? st.any_rays : st.closest_rays) += n;
+    st.nodes += cnt.nodes; st.tris += cnt.tris;
+}
+} // namespace exec
+namespace exec { inline void trace_stats_collect() {} }
