@@ -67,3 +67,117 @@ inline void launch(int n, const F &f) {
 }
 
 } // namespace exec
+
+// ---------------------------------------------------------------------------------------------
+// Order-preserving stream compaction of the live-lane list (replaces thrust::copy_if /
+// remove_if, src/active_pixels.cpp:17-49).  Three small kernels, wave64-native:
+//   count   : each 256-thread workgroup handles 1024 candidates; per-wave __ballot + popcount,
+//             4 wave totals combined through LDS -> one count per workgroup
+//   scan    : one workgroup turns the per-workgroup counts into exclusive offsets (+ total)
+//   scatter : recomputes the ballots; lane rank = mbcnt(ballot) + wave offset + workgroup offset
+// Stability (needed because Sobol' slots of the secondary-edge sampler are assigned by compacted
+// rank, src/pathtracer.cpp:504-505) follows from ranks being prefix sums in lane order.
+// ---------------------------------------------------------------------------------------------
+#include "../bvh.h"
+namespace exec {
+
+constexpr int kCompactItems = 4;                       // candidates per thread
+constexpr int kCompactTile = 256 * kCompactItems;      // per workgroup
+
+__device__ inline int lane_prefix(unsigned long long ballot) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ballot, 0));
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) compact_count(const int *in, int n, P pred, int *block_counts) {
+    __shared__ int wave_tot[4];
+    int base = blockIdx.x * kCompactTile;
+    int cnt = 0;
+    for (int it = 0; it < kCompactItems; ++it) {
+        int i = base + it * 256 + threadIdx.x;
+        bool keep = false;
+        if (i < n) { int p = in ? in[i] : i; keep = pred(p); }
+        unsigned long long b = __ballot(keep);
+        cnt += __popcll(b);
+    }
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+// exclusive scan of up to 256*16 workgroup counts by one workgroup
+static __global__ void __launch_bounds__(256) compact_scan(int *block_counts, int nblocks, int *total) {
+    __shared__ int part[256];
+    int per = (nblocks + 255) / 256;
+    int beg = threadIdx.x * per, end = min(beg + per, nblocks);
+    int s = 0;
+    for (int i = beg; i < end; ++i) s += block_counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { int t = part[i]; part[i] = run; run += t; }
+        *total = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = beg; i < end; ++i) { int t = block_counts[i]; block_counts[i] = run; run += t; }
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) compact_scatter(const int *in, int n, P pred, const int *block_offsets, int *out) {
+    __shared__ int wave_tot[kCompactItems][4];
+    int base = blockIdx.x * kCompactTile;
+    int wave = threadIdx.x >> 6;
+    int val[kCompactItems]; bool keep[kCompactItems]; int rank[kCompactItems];
+    for (int it = 0; it < kCompactItems; ++it) {
+        int i = base + it * 256 + threadIdx.x;
+        keep[it] = false; val[it] = 0;
+        if (i < n) { val[it] = in ? in[i] : i; keep[it] = pred(val[it]); }
+        unsigned long long b = __ballot(keep[it]);
+        rank[it] = lane_prefix(b);
+        if ((threadIdx.x & 63) == 0) wave_tot[it][wave] = __popcll(b);
+    }
+    __syncthreads();
+    int off = block_offsets[blockIdx.x];
+    for (int it = 0; it < kCompactItems; ++it) {
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += wave_tot[it][w];
+        if (keep[it]) out[off + before + rank[it]] = val[it];
+        off += wave_tot[it][0] + wave_tot[it][1] + wave_tot[it][2] + wave_tot[it][3];
+    }
+}
+
+struct CompactScratch { int *block_counts = nullptr; int *total = nullptr; int capacity = 0; };
+CompactScratch &compact_scratch(int nblocks);
+
+// `out` must not alias `in`: a workgroup may scatter into a tile that an earlier-numbered
+// workgroup has not read yet.
+template <class P>
+inline int compact(const int *in, int n, int *out, const P &pred) {
+    if (n <= 0) return 0;
+    int nblocks = (n + kCompactTile - 1) / kCompactTile;
+    if (nblocks > 256 * 4096) throw std::runtime_error("compact: input too large");
+    CompactScratch &sc = compact_scratch(nblocks);
+    hipStream_t st = ctx().stream;
+    hipLaunchKernelGGL(compact_count<P>, dim3(nblocks), dim3(256), 0, st, in, n, pred, sc.block_counts);
+    hipLaunchKernelGGL(compact_scan, dim3(1), dim3(256), 0, st, sc.block_counts, nblocks, sc.total);
+    hipLaunchKernelGGL(compact_scatter<P>, dim3(nblocks), dim3(256), 0, st, in, n, pred, sc.block_counts, out);
+    check(hipGetLastError(), "compact launch");
+    int total = 0;
+    download(&total, sc.total, sizeof(int));
+    return total;
+}
+
+// ---- traversal kernels (trace.hip) --------------------------------------------------------------
+struct TraceStats {
+    double closest_ms = 0, any_ms = 0;
+    uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes = 0, tris = 0;
+    bool timing = false, counting = false;
+};
+TraceStats &trace_stats();
+void trace_stats_collect();     // folds pending hipEvent pairs / device counters into trace_stats()
+void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n, bool any);
+void select_device(int use_gpu, int gpu_index);
+
+} // namespace exec
