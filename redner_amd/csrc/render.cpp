@@ -76,6 +76,121 @@ int run_bounce(const Scene &scene, const SobolD &rng, int dim, int rng_shift,
     return exec::compact(active, num_active, next_active, KeepHit{vn.shape});
 }
 
+// ---- gradient accumulators ------------------------------------------------------------------------
+// fp64 mirrors of every tensor in the caller's DScene; folded into the fp32 tensors by flush().
+struct GradStore {
+    Arena arena;
+    GScene g;
+    struct Pair { double *acc; float *out; size_t count; };
+    std::vector<Pair> pairs;
+    std::vector<GShape> h_shapes;
+    std::vector<GMaterial> h_materials;
+
+    double *mirror(float *out, size_t count) {
+        if (!out || count == 0) return nullptr;
+        double *acc = arena.get<double>(count);
+        exec::zero(acc, sizeof(double) * count);
+        pairs.push_back(Pair{acc, out, count});
+        return acc;
+    }
+    GTex mirror_tex(const TexD &t, const rdr_dtexture_desc &d) {
+        GTex g;
+        for (int i = 0; i < kMaxMip; ++i) g.texels[i] = nullptr;
+        g.uv_scale = nullptr;
+        if (t.num_levels == 0 || d.num_levels == 0) return g;
+        bool constant = t.width[0] <= 0 && t.height[0] <= 0;
+        for (int i = 0; i < t.num_levels && i < d.num_levels; ++i) {
+            size_t count = constant ? (size_t)t.channels : (size_t)t.width[i] * t.height[i] * t.channels;
+            g.texels[i] = mirror(d.texels[i], count);
+        }
+        g.uv_scale = mirror(d.uv_scale, 2);
+        return g;
+    }
+
+    GradStore(const Scene &scene, const rdr_dscene_desc &ds) {
+        if (ds.num_shapes != (int)scene.shapes.size() || ds.num_materials != (int)scene.materials.size() ||
+            ds.num_area_lights != (int)scene.lights.size())
+            throw std::runtime_error("render: DScene does not match the Scene (shape/material/light counts)");
+        h_shapes.resize(scene.shapes.size());
+        for (size_t i = 0; i < scene.shapes.size(); ++i) {
+            const ShapeD &sh = scene.shapes[i];
+            const rdr_dshape_desc &d = ds.shapes[i];
+            h_shapes[i].vertices = mirror(d.vertices, (size_t)3 * sh.num_vertices);
+            if (!h_shapes[i].vertices) throw std::runtime_error("render: DShape.vertices is required");
+            h_shapes[i].uvs = sh.uvs ? mirror(d.uvs, (size_t)2 * (sh.num_uv_vertices > 0 ? sh.num_uv_vertices : sh.num_vertices)) : nullptr;
+            h_shapes[i].normals = sh.normals ? mirror(d.normals, (size_t)3 * (sh.num_normal_vertices > 0 ? sh.num_normal_vertices : sh.num_vertices)) : nullptr;
+            h_shapes[i].colors = sh.colors ? mirror(d.colors, (size_t)3 * sh.num_vertices) : nullptr;
+        }
+        h_materials.resize(scene.materials.size());
+        for (size_t i = 0; i < scene.materials.size(); ++i) {
+            const MaterialD &m = scene.materials[i];
+            const rdr_dmaterial_desc &d = ds.materials[i];
+            h_materials[i].diffuse = mirror_tex(m.diffuse, d.diffuse_reflectance);
+            h_materials[i].specular = mirror_tex(m.specular, d.specular_reflectance);
+            h_materials[i].roughness = mirror_tex(m.roughness, d.roughness);
+            h_materials[i].generic = mirror_tex(m.generic, d.generic_texture);
+            h_materials[i].normal_map = mirror_tex(m.normal_map, d.normal_map);
+        }
+        g.shapes = arena.get<GShape>(h_shapes.size());
+        exec::upload(g.shapes, h_shapes.data(), sizeof(GShape) * h_shapes.size());
+        g.materials = arena.get<GMaterial>(h_materials.size());
+        exec::upload(g.materials, h_materials.data(), sizeof(GMaterial) * h_materials.size());
+        // light intensities: one contiguous fp64 block, scattered back per light
+        g.light_intensity = nullptr;
+        if (!scene.lights.empty()) {
+            g.light_intensity = arena.get<double>(3 * scene.lights.size());
+            exec::zero(g.light_intensity, sizeof(double) * 3 * scene.lights.size());
+            for (size_t l = 0; l < scene.lights.size(); ++l)
+                if (ds.area_lights[l].intensity) pairs.push_back(Pair{g.light_intensity + 3 * l, ds.area_lights[l].intensity, 3});
+        }
+        const rdr_dcamera_desc &dc = ds.camera;
+        g.cam.position = mirror(dc.position, 3); g.cam.look = mirror(dc.look, 3); g.cam.up = mirror(dc.up, 3);
+        g.cam.cam_to_world = mirror(dc.cam_to_world, 16); g.cam.world_to_cam = mirror(dc.world_to_cam, 16);
+        g.cam.intrinsic_mat_inv = mirror(dc.intrinsic_mat_inv, 9); g.cam.intrinsic_mat = mirror(dc.intrinsic_mat, 9);
+        g.envmap = nullptr;
+    }
+    void flush() {
+        for (const Pair &p : pairs) exec::launch((int)p.count, FlushGrad{p.acc, p.out});
+    }
+};
+
+// ---- backward sweep of one sample (src/pathtracer.cpp:392-944) ------------------------------------
+struct Backward {
+    const Scene &scene; const rdr_render_options &opt;
+    int P, B; const float *d_image; float *screen_grad; double weight; int nd, radiance_dim;
+    GradStore grads;
+    Arena arena;
+    AdjState adj;
+
+    Backward(const Scene &scene_, const rdr_render_options &opt_, const rdr_dscene_desc &ds, int P_, int B_,
+             const float *d_image_, float *screen_grad_, double weight_, int nd_, int radiance_dim_)
+        : scene(scene_), opt(opt_), P(P_), B(B_), d_image(d_image_), screen_grad(screen_grad_), weight(weight_),
+          nd(nd_), radiance_dim(radiance_dim_), grads(scene_, ds) {
+        adj.n = P;
+        adj.thr = arena.get<double>((size_t)3 * P);
+        adj.ray_dir = arena.get<double>((size_t)3 * P);
+        adj.point = arena.get<double>((size_t)kAdjPointDoubles * P);
+    }
+
+    void run_sample(int sample_id, std::vector<VSlice> &vs, int *active, std::vector<int> &num_active, const Queues &q) {
+        (void)q;
+        SobolD rng{scene.sobol_table, opt.seed, sample_id};
+        const bool has_lights = scene.d.num_lights > 0;
+        exec::zero(adj.thr, sizeof(double) * 3 * P);
+        exec::zero(adj.ray_dir, sizeof(double) * 3 * P);
+        exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * P);
+        const int dim0 = opt.sample_pixel_center ? 0 : 2;
+        for (int d = B - 1; d >= 0 && has_lights; --d) {
+            if (num_active[d] <= 0) continue;
+            exec::launch(num_active[d], AdjBounce{scene.d, grads.g, rng, dim0 + 7 * d, active + (size_t)d * P, vs[d], vs[d + 1],
+                                                  d_image, nd, radiance_dim, weight, adj});
+        }
+        exec::launch(P, AdjPrimary{scene.d, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
+                                   adj, screen_grad});
+    }
+    void flush() { grads.flush(); }
+};
+
 } // namespace
 
 void render(const Scene &scene, const rdr_render_options &opt, float *image, const float *d_image,

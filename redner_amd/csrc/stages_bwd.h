@@ -1,14 +1,251 @@
+// stages_bwd.h -- adjoint stages of the camera path (the "continuous" part of the gradient).
+//
+// Behavioural spec:
+//   AdjBounce   <- d_path_contribs_accumulator          src/path_contribution.cpp:156-626
+//   AdjPrimary  <- d_primary_contribs_accumulator (radiance)  src/primary_contribution.cpp:438-480
+//                  + d_primary_intersector               src/primary_intersection.cpp:5-130
+// Walking the path backwards, each vertex hands three adjoints to its predecessor: throughput,
+// incoming-ray direction and shading point (the reference's d_throughputs / d_rays / d_points;
+// its d_ray_differentials are identically zero because the BSDF-sampling adjoint is disabled,
+// src/path_contribution.cpp:458-474, so they are not materialised here).  One buffer set is
+// updated in place: lane p reads its successor's adjoints and overwrites them with its own.
+//
+// Like the reference this estimator deliberately ignores d(MIS), d(pdf_bsdf) and d(BSDF
+// sampling) (:369-376, :458-474) and drops the position gradient of diffuse inter-reflection
+// unless min_roughness > 0.01 (:447-455).
 #pragma once
 #include "stages_fwd.h"
-#include "scene.h"
-#include <stdexcept>
+
 namespace rdr {
 
-struct Backward {
-    Backward(const Scene &, const rdr_render_options &, const rdr_dscene_desc &, int, int, const float *, float *, double, int, int) {
-        throw std::runtime_error("backward pass not implemented yet");
-    }
-    template <class Q> void run_sample(int, std::vector<VSlice> &, int *, std::vector<int> &, const Q &) {}
-    void flush() {}
+constexpr int kAdjPointDoubles = 24;   // position 3, frame 9, dpdu 3, uv 2, du_dxy 2, dv_dxy 2, color 3
+
+struct AdjState {      // SoA, stride n, indexed by lane id
+    double *thr;       // 3 x n
+    double *ray_dir;   // 3 x n   (adjoint of the incoming ray's direction; the origin's is always 0)
+    double *point;     // 24 x n  (non-zero part of the shading point adjoint)
+    int n;
 };
+
+RDR_FN Surf load_adj_point(const AdjState &a, int p) {
+    Surf s = surf_zero();
+    s.position = ld3(a.point, a.n, p, 0);
+    s.frame.x = ld3(a.point, a.n, p, 3); s.frame.y = ld3(a.point, a.n, p, 6); s.frame.n = ld3(a.point, a.n, p, 9);
+    s.dpdu = ld3(a.point, a.n, p, 12);
+    s.uv = v2(a.point[(size_t)15 * a.n + p], a.point[(size_t)16 * a.n + p]);
+    s.du_dxy = v2(a.point[(size_t)17 * a.n + p], a.point[(size_t)18 * a.n + p]);
+    s.dv_dxy = v2(a.point[(size_t)19 * a.n + p], a.point[(size_t)20 * a.n + p]);
+    s.color = ld3(a.point, a.n, p, 21);
+    return s;
 }
+RDR_FN void store_adj_point(const AdjState &a, int p, const Surf &s) {
+    st3(a.point, a.n, p, 0, s.position);
+    st3(a.point, a.n, p, 3, s.frame.x); st3(a.point, a.n, p, 6, s.frame.y); st3(a.point, a.n, p, 9, s.frame.n);
+    st3(a.point, a.n, p, 12, s.dpdu);
+    a.point[(size_t)15 * a.n + p] = s.uv.x; a.point[(size_t)16 * a.n + p] = s.uv.y;
+    a.point[(size_t)17 * a.n + p] = s.du_dxy.x; a.point[(size_t)18 * a.n + p] = s.du_dxy.y;
+    a.point[(size_t)19 * a.n + p] = s.dv_dxy.x; a.point[(size_t)20 * a.n + p] = s.dv_dxy.y;
+    st3(a.point, a.n, p, 21, s.color);
+}
+
+RDR_FN V3 image_grad(const float *d_image, int nd, int radiance_dim, int pixel) {
+    const float *g = d_image + (size_t)nd * pixel + radiance_dim;
+    return V3{(double)g[0], (double)g[1], (double)g[2]};
+}
+
+// ---- adjoint of one bounce ----------------------------------------------------------------------
+struct AdjBounce {
+    SceneD sc; GScene g; SobolD rng; int dim;
+    const int *active; VSlice v, vn;
+    const float *d_image; int nd, radiance_dim; double weight;
+    AdjState adj;
+    RDR_FN void operator()(int idx) const {
+        int p = active[idx];
+        VertexCtx c = load_vertex(sc, v, p);
+        const GMaterial &gm = g.materials[c.shape->material_id];
+        V3 thr = ld3(v.thr, v.n, p, 0);
+        V3 pc_bar = weight * image_grad(d_image, nd, radiance_dim, p);   // adjoint of path_contrib
+        V3 thr_bar = v3(0), in_dir_bar = v3(0);
+        Surf sp_bar = surf_zero();
+        V3 pos = c.sp.position;
+
+        // ---- next-event estimation ----
+        if (!v.occl[p]) {
+            LightDraw ld = draw_light(rng, p, dim);
+            LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
+            if (pk.shape_id >= 0) {
+                const ShapeD &lsh = sc.shapes[pk.shape_id];
+                Surf lp = sample_tri(lsh, pk.tri_id, ld.uv);
+                V3 dir = lp.position - pos;
+                double d2 = len_sq(dir);
+                V3 wo = dir / sqrt(d2);
+                if (lsh.light_id >= 0) {
+                    const LightD &l = sc.lights[lsh.light_id];
+                    if (l.two_sided || dot(-wo, lp.frame.n) > 0) {
+                        V3 lv_bar[3] = {v3(0), v3(0), v3(0)};
+                        V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
+                        double cl = dot(wo, lp.geom_normal);
+                        double geo = fabs(cl) / d2;
+                        V3 Le = v3f(l.intensity);
+                        double pdf_nee = sc.light_pmf[lsh.light_id] * (1 / sc.light_areas[lsh.light_id]);
+                        double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough) * geo;
+                        double mis = 1 / (1 + sq(pdf_b / pdf_nee));
+                        V3 nee = (mis * geo / pdf_nee) * f * Le;
+                        V3 nee_bar = pc_bar * thr;
+                        thr_bar += pc_bar * nee;
+                        double w = mis / pdf_nee;
+                        double w_bar = geo * sum(nee_bar * f * Le);
+                        double pdfnee_bar = -w_bar * w / pdf_nee;
+                        double geo_bar = w * sum(nee_bar * f * Le);
+                        V3 f_bar = w * nee_bar * geo * Le;
+                        V3 Le_bar = w * nee_bar * geo * f;
+                        // pdf_nee depends on the sampled triangle's area
+                        double area_bar = -pdfnee_bar * pdf_nee / tri_area(lsh, pk.tri_id);
+                        adj_tri_area(lsh, pk.tri_id, area_bar, lv_bar);
+                        if (g.light_intensity) accum3(g.light_intensity + 3 * lsh.light_id, Le_bar);
+                        double cl_bar = cl > 0 ? geo_bar / d2 : -geo_bar / d2;
+                        double d2_bar = -geo_bar * geo / d2;
+                        V3 wo_bar = cl_bar * lp.geom_normal;
+                        Surf lp_bar = surf_zero();
+                        lp_bar.geom_normal = cl_bar * wo;
+                        V3 wi_bar = v3(0);
+                        adj_bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough, f_bar, gm, sp_bar, wi_bar, wo_bar);
+                        V3 dir_bar = wo_bar / sqrt(d2);
+                        double sd_bar = -sum(wo_bar * dir) / d2;
+                        d2_bar += (0.5f * sd_bar / sqrt(d2));
+                        dir_bar += adj_len_sq(dir, d2_bar);
+                        lp_bar.position += dir_bar;
+                        sp_bar.position -= dir_bar;
+                        in_dir_bar -= wi_bar;
+                        adj_sample_tri(lsh, pk.tri_id, ld.uv, lp_bar, lv_bar);
+                        TriVerts tv = load_tri(lsh, pk.tri_id);
+                        double *gv = g.shapes[pk.shape_id].vertices;
+                        accum3(gv + 3 * tv.i0, lv_bar[0]); accum3(gv + 3 * tv.i1, lv_bar[1]); accum3(gv + 3 * tv.i2, lv_bar[2]);
+                    }
+                }
+            }
+        }
+
+        // ---- BSDF-sampled continuation ----
+        int bshape = vn.shape[p];
+        if (bshape >= 0) {
+            const ShapeD &bsh = sc.shapes[bshape];
+            int btri = vn.tri[p];
+            RayDiff wo_rd = load_rdiff(vn, p);
+            RayDiff tmp;
+            Surf bp = surf_at(bsh, btri, load_ray(vn, p), wo_rd, tmp);
+            V3 next_thr_bar = ld3(adj.thr, adj.n, p, 0);
+            V3 next_dir_bar = ld3(adj.ray_dir, adj.n, p, 0);
+            Surf next_pt_bar = load_adj_point(adj, p);
+            V3 dir = bp.position - pos;
+            double d2 = len_sq(dir);
+            V3 wo = dir / sqrt(d2);
+            double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough);
+            if (pdf_b > 0) {
+                V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
+                V3 sb = f / pdf_b;
+                thr_bar += next_thr_bar * sb;
+                V3 sb_bar = next_thr_bar * thr;
+                V3 f_bar = sb_bar / pdf_b;
+                if (bsh.light_id >= 0) {
+                    const LightD &l = sc.lights[bsh.light_id];
+                    if (l.two_sided || dot(-wo, bp.frame.n) > 0) {
+                        double geo = fabs(dot(wo, bp.geom_normal)) / d2;
+                        V3 Le = v3f(l.intensity);
+                        double pdf_nee = (sc.light_pmf[bsh.light_id] * (1 / sc.light_areas[bsh.light_id])) / geo;
+                        double mis = 1 / (1 + sq(pdf_nee / pdf_b));
+                        V3 sc_contrib = (mis / pdf_b) * f * Le;
+                        V3 scb = pc_bar * thr;
+                        thr_bar += pc_bar * sc_contrib;
+                        double w = mis / pdf_b;
+                        f_bar += w * scb * Le;
+                        if (g.light_intensity) accum3(g.light_intensity + 3 * bsh.light_id, w * scb * f);
+                    }
+                }
+                V3 wi_bar = v3(0);
+                V3 wo_bar = next_dir_bar;
+                adj_bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough, f_bar, gm, sp_bar, wi_bar, wo_bar);
+                V3 dir_bar = wo_bar / sqrt(d2);
+                double sd_bar = -sum(wo_bar * dir) / d2;
+                double d2_bar = 0.5f * sd_bar / sqrt(d2);
+                dir_bar += adj_len_sq(dir, d2_bar);
+                Surf bp_bar = next_pt_bar;
+                bp_bar.position += dir_bar;
+                DRay r_bar = dray_zero();
+                RayDiff rd_bar = raydiff_zero();
+                TriGrad tg = trigrad_zero();
+                Ray br = make_ray(pos, wo);
+                adj_surf_at(bsh, btri, br, wo_rd, bp_bar, raydiff_zero(), r_bar, rd_bar, tg);
+                if (c.mrough > 0.01f) {
+                    sp_bar.position -= dir_bar;
+                    sp_bar.position += r_bar.org;
+                }
+                in_dir_bar -= wi_bar;
+                scatter_trigrad(bsh, g.shapes[bshape], btri, tg);
+            }
+        }
+        st3(adj.thr, adj.n, p, 0, thr_bar);
+        st3(adj.ray_dir, adj.n, p, 0, in_dir_bar);
+        store_adj_point(adj, p, sp_bar);
+    }
+};
+
+// ---- adjoint of the camera vertex ------------------------------------------------------------------
+struct AdjPrimary {
+    SceneD sc; GScene g; SobolD rng; int sample_center;
+    VSlice v0; const float *d_image; int nd, radiance_dim; double weight;
+    AdjState adj; float *screen_grad;
+    RDR_FN void operator()(int p) const {
+        int shape = v0.shape[p];
+        Ray ray = load_ray(v0, p);
+        RayDiff rd = load_rdiff(v0, p);
+        // radiance channel: only the light intensity receives a gradient here
+        if (shape >= 0) {
+            const ShapeD &sh = sc.shapes[shape];
+            if (sh.light_id >= 0 && g.light_intensity) {
+                RayDiff tmp;
+                Surf sp = surf_at(sh, v0.tri[p], ray, rd, tmp);
+                const LightD &l = sc.lights[sh.light_id];
+                if (dot(-ray.dir, sp.frame.n) > 0 && l.directly_visible) {
+                    V3 e_bar = weight * ld3(v0.thr, v0.n, p, 0) * image_grad(d_image, nd, radiance_dim, p);
+                    accum3(g.light_intensity + 3 * sh.light_id, e_bar);
+                }
+            }
+        }
+        if (shape < 0) return;    // a miss carries zero adjoints: nothing flows to the camera
+        DRay r_bar = dray_zero();
+        r_bar.dir = ld3(adj.ray_dir, adj.n, p, 0);
+        RayDiff prd_bar = raydiff_zero();
+        {
+            Surf pt_bar = load_adj_point(adj, p);
+            TriGrad tg = trigrad_zero();
+            adj_surf_at(sc.shapes[shape], v0.tri[p], ray, rd, pt_bar, raydiff_zero(), r_bar, prd_bar, tg);
+            scatter_trigrad(sc.shapes[shape], g.shapes[shape], v0.tri[p], tg);
+        }
+        V2 s = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
+        V2 screen = pixel_to_screen(sc.cam, p, s);
+        double delta = 1e-3;
+        double sx = 0.5 / sc.cam.width, sy = 0.5 / sc.cam.height;
+        DRay rx_bar{prd_bar.org_dx * sx / delta, prd_bar.dir_dx * sx / delta};
+        DRay ry_bar{prd_bar.org_dy * sy / delta, prd_bar.dir_dy * sy / delta};
+        r_bar.org += (prd_bar.org_dx * -sx + prd_bar.org_dy * -sy) / delta;
+        r_bar.dir += (prd_bar.dir_dx * -sx + prd_bar.dir_dy * -sy) / delta;
+        V2 scr_bar = v2(0, 0);
+        V2 *sb = screen_grad ? &scr_bar : nullptr;
+        adj_primary_ray(sc.cam, screen, r_bar, g.cam, sb);
+        adj_primary_ray(sc.cam, screen + v2(delta, 0), rx_bar, g.cam, sb);
+        adj_primary_ray(sc.cam, screen + v2(0, delta), ry_bar, g.cam, sb);
+        if (screen_grad) {
+            screen_grad[2 * p] += (float)scr_bar.x;
+            screen_grad[2 * p + 1] += (float)scr_bar.y;
+        }
+    }
+};
+
+// fp64 accumulator -> caller's fp32 gradient tensor (+=)
+struct FlushGrad {
+    const double *acc; float *out;
+    RDR_FN void operator()(int i) const { out[i] += (float)acc[i]; }
+};
+
+} // namespace rdr
