@@ -197,6 +197,10 @@ void rdr_trace_stats_get(rdr_trace_stats *out);
  * traversal parity tests and micro-benchmarks. */
 int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, int num_rays, int any_hit);
 
+/* Test hook: writes the edge list and both edge hierarchies (links, edge ids, weights, costs) as
+ * text, for the build-order parity test against the reference (tests/test_edge_build.py). */
+int rdr_debug_dump_edges(const rdr_scene *scene, const char *path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,6 +1,8 @@
 // capi.cpp -- extern "C" entry points declared in include/redner_amd.h.
 #include "../../include/redner_amd.h"
 #include "render.h"
+#include "edges.h"
+#include <cstdio>
 #include "scene.h"
 #include <cstring>
 #include <exception>
@@ -75,6 +77,34 @@ void rdr_trace_stats_get(rdr_trace_stats *out) {
     out->closest_launches = s.closest_launches; out->any_launches = s.any_launches;
     out->closest_rays = s.closest_rays; out->any_rays = s.any_rays;
     out->nodes_visited = s.nodes; out->tris_tested = s.tris;
+}
+
+int rdr_debug_dump_edges(const rdr_scene *scene, const char *path) {
+    const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    if (!s.edges) { fprintf(f, "edges 0\n"); fclose(f); return 0; }
+    const rdr::EdgeData &ed = *s.edges;
+    fprintf(f, "edges %d\n", (int)ed.edges.size());
+    for (const rdr::EdgeD &e : ed.edges) fprintf(f, "%d %d %d %d %d\n", e.shape_id, e.v0, e.v1, e.f0, e.f1);
+    if (!ed.cs_nodes.empty() || !ed.ncs_nodes.empty()) {
+        fprintf(f, "expand %.17g\n", ed.edge_bounds_expand);
+        for (int t = 0; t < 2; ++t) {
+            const std::vector<rdr::EdgeNode> &nodes = t == 0 ? ed.cs_nodes : ed.ncs_nodes;
+            int nl = t == 0 ? ed.cs_leaves : ed.ncs_leaves;
+            int nn = (int)nodes.size() - nl;
+            fprintf(f, "%s %d %d\n", t == 0 ? "cs" : "ncs", nl == 0 ? 0 : nn, nl);
+            for (size_t i = 0; i < nodes.size(); ++i) {
+                const rdr::EdgeNode &n = nodes[i];
+                fprintf(f, "%d %d %d %d %d %.17g %.17g", (int)i, n.parent, n.child0, n.child1, n.edge_id, n.wlen, n.cost);
+                fprintf(f, " %.17g %.17g %.17g %.17g %.17g %.17g", n.p_min.x, n.p_min.y, n.p_min.z, n.p_max.x, n.p_max.y, n.p_max.z);
+                if (t == 1) fprintf(f, " %.17g %.17g %.17g %.17g %.17g %.17g", n.d_min.x, n.d_min.y, n.d_min.z, n.d_max.x, n.d_max.y, n.d_max.z);
+                fprintf(f, "\n");
+            }
+        }
+    }
+    fclose(f);
+    return 0;
 }
 
 int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, int num_rays, int any_hit) {

@@ -1,0 +1,546 @@
+// edges.cpp -- host-side construction of the edge list, the primary-edge PMF/CDF and the two edge
+// hierarchies (see edges.h for the behavioural spec and why the build is order-exact).
+#include "edges.h"
+#include "camera.h"
+#include "scene.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+
+namespace rdr {
+
+namespace {
+
+// ---- the sequential merge sort the reference's CPU build runs (Thrust's sequential backend:
+// top-down split at n/2, insertion sort below 33 elements, merge taking from the right run only
+// when comp(right, left)).  Restated because two of the reference's comparators are not strict
+// weak orders (they return true on equality), which makes the outcome depend on the algorithm.
+template <class T, class Cmp>
+void insertion_sort_seq(T *first, T *last, Cmp comp) {
+    if (first == last) return;
+    for (T *i = first + 1; i != last; ++i) {
+        T tmp = *i;
+        if (comp(tmp, *first)) {
+            for (T *j = i; j != first; --j) *j = *(j - 1);
+            *first = tmp;
+        } else {
+            T *j = i, *k = i - 1;
+            while (comp(tmp, *k)) { *j = *k; j = k; --k; }
+            *j = tmp;
+        }
+    }
+}
+template <class T, class Cmp>
+void merge_sort_seq(T *first, T *last, Cmp comp) {
+    ptrdiff_t n = last - first;
+    if (n <= 32) { insertion_sort_seq(first, last, comp); return; }
+    T *mid = first + n / 2;
+    merge_sort_seq(first, mid, comp);
+    merge_sort_seq(mid, last, comp);
+    std::vector<T> a(first, mid), b(mid, last);
+    size_t i = 0, j = 0;
+    T *out = first;
+    while (i < a.size() && j < b.size()) {
+        if (comp(b[j], a[i])) *out++ = b[j++]; else *out++ = a[i++];
+    }
+    while (i < a.size()) *out++ = a[i++];
+    while (j < b.size()) *out++ = b[j++];
+}
+
+bool f3_less_eq(F3 a, F3 b) {      // "less_than" of src/edge.cpp:93-102: true on equality
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    if (a.z != b.z) return a.z < b.z;
+    return true;
+}
+
+struct SortedEnds { F3 lo, hi; };
+SortedEnds sorted_ends(const ShapeD &sh, const EdgeD &e) {
+    F3 a = f3_vertex(sh, e.v0), b = f3_vertex(sh, e.v1);
+    if (f3_less_eq(b, a)) std::swap(a, b);
+    return SortedEnds{a, b};
+}
+
+// Cohen-Sutherland clip of a screen-space segment against [0,1]^2 (src/line_clip.h:20-102).
+int out_code(V2 v) {
+    int c = 0;
+    if (v.x < 0.f) c |= 1; else if (v.x > 1.f) c |= 2;
+    if (v.y < 0.f) c |= 4; else if (v.y > 1.f) c |= 8;
+    return c;
+}
+bool clip_unit_square(V2 a, V2 b, V2 &ac, V2 &bc) {
+    int ca = out_code(a), cb = out_code(b);
+    ac = a; bc = b;
+    for (;;) {
+        if (!(ca | cb)) return true;
+        if (ca & cb) return false;
+        V2 v = v2(0, 0);
+        int co = ca ? ca : cb;
+        if (co & 8) { v.x = ac.x + (bc.x - ac.x) * (1.f - ac.y) / (bc.y - ac.y); v.y = 1.f; }
+        else if (co & 4) { v.x = ac.x + (bc.x - ac.x) * (0.f - ac.y) / (bc.y - ac.y); v.y = 0.f; }
+        else if (co & 2) { v.y = ac.y + (bc.y - ac.y) * (1.f - ac.x) / (bc.x - ac.x); v.x = 1.f; }
+        else if (co & 1) { v.y = ac.y + (bc.y - ac.y) * (0.f - ac.x) / (bc.x - ac.x); v.x = 0.f; }
+        if (co == ca) { ac = v; ca = out_code(ac); } else { bc = v; cb = out_code(bc); }
+    }
+}
+
+// ---- 6-D bounds of one edge (src/edge_tree.cpp:25-74) ----
+struct Box6 { V3 p_min, p_max, d_min, d_max; };
+Box6 empty_box6() {
+    double inf = std::numeric_limits<double>::infinity();
+    return Box6{v3(inf), v3(-inf), v3(inf), v3(-inf)};
+}
+V3 vmin(V3 a, V3 b) { return V3{std::min(a.x, b.x), std::min(a.y, b.y), std::min(a.z, b.z)}; }
+V3 vmax(V3 a, V3 b) { return V3{std::max(a.x, b.x), std::max(a.y, b.y), std::max(a.z, b.z)}; }
+Box6 merge6(const Box6 &a, const Box6 &b) {
+    return Box6{vmin(a.p_min, b.p_min), vmax(a.p_max, b.p_max), vmin(a.d_min, b.d_min), vmax(a.d_max, b.d_max)};
+}
+
+uint64_t expand3(uint64_t x) {          // two zero bits after each of 21 bits
+    x &= 0x1fffff;
+    x = (x | x << 32) & 0x1f00000000ffff;
+    x = (x | x << 16) & 0x1f0000ff0000ff;
+    x = (x | x << 8) & 0x100f00f00f00f00f;
+    x = (x | x << 4) & 0x10c30c30c30c30c3;
+    x = (x | x << 2) & 0x1249249249249249;
+    return x;
+}
+uint64_t expand6(uint64_t x) {          // five zero bits after each of 10 bits
+    uint64_t r = 0;
+    for (int i = 0; i < 10; ++i) r |= ((x >> i) & 1ull) << (6 * i);
+    return r;
+}
+double unit_coord(double v, double lo, double hi) {
+    if (hi - lo <= 0.f) return 0.5f;
+    return (v - lo) / (hi - lo);
+}
+
+int clz64(uint64_t x) { return x == 0 ? 64 : __builtin_clzll(x); }
+
+// ---- one hierarchy ------------------------------------------------------------------------------
+struct TreeBuilder {
+    bool is3d;
+    const ShapeD *shapes;
+    const std::vector<EdgeD> &edges;
+    const std::vector<Box6> &bounds;
+    std::vector<int> ids;               // edge ids of this tree, Morton-sorted
+    std::vector<uint64_t> codes;
+    std::vector<EdgeNode> nodes;        // [internal | leaves]
+    int n = 0, n_internal = 0;
+
+    TreeBuilder(bool is3d_, const ShapeD *shapes_, const std::vector<EdgeD> &edges_, const std::vector<Box6> &bounds_)
+        : is3d(is3d_), shapes(shapes_), edges(edges_), bounds(bounds_) {}
+
+    int leaf_ref(int i) const { return n_internal + i; }
+
+    double area(const EdgeNode &nd) const {
+        V3 dp = nd.p_max - nd.p_min;
+        if (is3d) return 2 * (dp.x * dp.y + dp.x * dp.z + dp.y * dp.z);
+        V3 dd = nd.d_max - nd.d_min;
+        return 2 * ((dp.x * dp.y + dp.x * dp.z + dp.y * dp.z) + (dd.x * dd.y + dd.x * dd.z + dd.y * dd.z));
+    }
+    void merge_children(EdgeNode &dst, const EdgeNode &a, const EdgeNode &b) const {
+        dst.p_min = vmin(a.p_min, b.p_min); dst.p_max = vmax(a.p_max, b.p_max);
+        if (!is3d) { dst.d_min = vmin(a.d_min, b.d_min); dst.d_max = vmax(a.d_max, b.d_max); }
+    }
+
+    int lcp(int i, int j) const {
+        if (i < 0 || i >= n || j < 0 || j >= n) return -1;
+        uint64_t a = codes[i], b = codes[j];
+        if (a == b) return clz64(a ^ b) + clz64((uint64_t)ids[i] ^ (uint64_t)ids[j]);
+        return clz64(a ^ b);
+    }
+
+    void build(const std::vector<int> &edge_ids) {
+        ids = edge_ids;
+        n = (int)ids.size();
+        if (n == 0) return;
+        // scene bounds of this subset
+        Box6 sb = empty_box6();
+        for (int id : ids) sb = merge6(sb, bounds[id]);
+        codes.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const Box6 &b = bounds[ids[i]];
+            V3 pc = 0.5f * (b.p_min + b.p_max);
+            if (is3d) {
+                double s = (1 << 21) - 1;
+                uint64_t x = (uint64_t)(unit_coord(pc.x, sb.p_min.x, sb.p_max.x) * s);
+                uint64_t y = (uint64_t)(unit_coord(pc.y, sb.p_min.y, sb.p_max.y) * s);
+                uint64_t z = (uint64_t)(unit_coord(pc.z, sb.p_min.z, sb.p_max.z) * s);
+                codes[i] = (expand3(x) << 2u) | (expand3(y) << 1u) | expand3(z);
+            } else {
+                V3 dc = 0.5f * (b.d_min + b.d_max);
+                uint64_t px = (uint64_t)(unit_coord(pc.x, sb.p_min.x, sb.p_max.x) * 1023);
+                uint64_t py = (uint64_t)(unit_coord(pc.y, sb.p_min.y, sb.p_max.y) * 1023);
+                uint64_t pz = (uint64_t)(unit_coord(pc.z, sb.p_min.z, sb.p_max.z) * 1023);
+                uint64_t dx = (uint64_t)(unit_coord(dc.x, sb.d_min.x, sb.d_max.x) * 1023);
+                uint64_t dy = (uint64_t)(unit_coord(dc.y, sb.d_min.y, sb.d_max.y) * 1023);
+                uint64_t dz = (uint64_t)(unit_coord(dc.z, sb.d_min.z, sb.d_max.z) * 1023);
+                codes[i] = (expand6(px) << 5u) | (expand6(py) << 4u) | (expand6(pz) << 3u) |
+                           (expand6(dx) << 2u) | (expand6(dy) << 1u) | expand6(dz);
+            }
+        }
+        // stable sort of (code, id) by code
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return codes[a] < codes[b]; });
+        std::vector<int> sid(n); std::vector<uint64_t> scode(n);
+        for (int i = 0; i < n; ++i) { sid[i] = ids[order[i]]; scode[i] = codes[order[i]]; }
+        ids.swap(sid); codes.swap(scode);
+
+        n_internal = std::max(n - 1, 1);
+        EdgeNode init;
+        double inf = std::numeric_limits<double>::infinity();
+        init.p_min = init.d_min = v3(inf); init.p_max = init.d_max = v3(-inf);
+        init.wlen = 0; init.cost = 0; init.parent = -1; init.child0 = init.child1 = -1; init.edge_id = -1;
+        nodes.assign(n_internal + n, init);
+
+        // Karras radix tree over the sorted codes (ties broken by edge id)
+        for (int idx = 0; idx < n - 1; ++idx) {
+            int d = (lcp(idx, idx + 1) - lcp(idx, idx - 1) >= 0) ? 1 : -1;
+            int dmin = lcp(idx, idx - d);
+            int lmax = 2;
+            while (lcp(idx, idx + lmax * d) > dmin) lmax *= 2;
+            int l = 0, divider = 2;
+            for (int t = lmax / divider; t >= 1;) {
+                if (lcp(idx, idx + (l + t) * d) > dmin) l += t;
+                if (t == 1) break;
+                divider *= 2;
+                t = lmax / divider;
+            }
+            int j = idx + l * d;
+            int dnode = lcp(idx, j);
+            int s = 0;
+            divider = 2;
+            for (int t = (l + (divider - 1)) / divider; t >= 1;) {
+                if (lcp(idx, idx + (s + t) * d) > dnode) s += t;
+                if (t == 1) break;
+                divider *= 2;
+                t = (l + (divider - 1)) / divider;
+            }
+            int gamma = idx + s * d + std::min(d, 0);
+            EdgeNode &nd = nodes[idx];
+            if (std::min(idx, j) == gamma) { nd.child0 = leaf_ref(gamma); nodes[leaf_ref(gamma)].parent = idx; }
+            else { nd.child0 = gamma; nodes[gamma].parent = idx; }
+            if (std::max(idx, j) == gamma + 1) { nd.child1 = leaf_ref(gamma + 1); nodes[leaf_ref(gamma + 1)].parent = idx; }
+            else { nd.child1 = gamma + 1; nodes[gamma + 1].parent = idx; }
+        }
+
+        // leaves + bottom-up bounds / weighted length
+        std::vector<int> counter(n_internal + n, 0);
+        for (int i = 0; i < n; ++i) {
+            EdgeNode &lf = nodes[leaf_ref(i)];
+            const Box6 &b = bounds[ids[i]];
+            lf.p_min = b.p_min; lf.p_max = b.p_max;
+            if (!is3d) { lf.d_min = b.d_min; lf.d_max = b.d_max; }
+            const EdgeD &e = edges[ids[i]];
+            lf.wlen = f3_distance(edge_v0f(shapes, e), edge_v1f(shapes, e)) * edge_exterior_dihedral(shapes, e);
+            lf.edge_id = ids[i];
+            int cur = lf.parent;
+            while (cur >= 0) {
+                if (++counter[cur] == 1) break;       // first arrival waits for the sibling
+                EdgeNode &nd = nodes[cur];
+                merge_children(nd, nodes[nd.child0], nodes[nd.child1]);
+                nd.wlen = nodes[nd.child0].wlen + nodes[nd.child1].wlen;
+                cur = nd.parent;
+            }
+        }
+        if (n == 1) { nodes[0] = nodes[leaf_ref(0)]; }     // single primitive: the root is a copy of the leaf
+
+        // treelet optimisation, bottom-up
+        std::fill(counter.begin(), counter.end(), 0);
+        for (int i = 0; i < n; ++i) {
+            EdgeNode &lf = nodes[leaf_ref(i)];
+            lf.cost = area(lf);
+            int cur = lf.parent;
+            while (cur >= 0) {
+                if (++counter[cur] == 1) break;
+                treelet_optimize(cur);
+                if (cur == 0) break;
+                cur = nodes[cur].parent;
+            }
+        }
+    }
+
+    // ---- Karras-style treelet restructuring with <= 7 leaves (src/edge_tree.cpp:464-711) ----
+    void refresh(int node) {
+        EdgeNode &nd = nodes[node];
+        merge_children(nd, nodes[nd.child0], nodes[nd.child1]);
+        nd.wlen = nodes[nd.child0].wlen + nodes[nd.child1].wlen;
+        nd.cost = area(nd) + nodes[nd.child0].cost + nodes[nd.child1].cost;
+    }
+
+    void propagate_cost(int root, const int *leaves, int nl) {
+        for (int i = 0; i < nl; ++i) {
+            int cur = leaves[i];
+            while (cur != root) {
+                EdgeNode &nd = nodes[cur];
+                if (nd.cost < 0) {
+                    if (nodes[nd.child0].cost >= 0 && nodes[nd.child1].cost >= 0) refresh(cur);
+                    else break;
+                }
+                cur = nodes[cur].parent;
+            }
+        }
+        refresh(root);
+    }
+
+    void restruct(int child_index, int root, const int *leaves, const int *inner, uint8_t partition,
+                  const uint8_t *optimal, int &index, int nl) {
+        struct Entry { uint8_t part, child; int parent; };
+        Entry stack[8];
+        int sp = 0;
+        stack[sp++] = Entry{partition, (uint8_t)child_index, root};
+        while (sp > 0) {
+            Entry e = stack[--sp];
+            if (__builtin_popcount(e.part) == 1) {
+                int leaf = leaves[__builtin_ffs(e.part) - 1];
+                if (e.child == 0) nodes[e.parent].child0 = leaf; else nodes[e.parent].child1 = leaf;
+                nodes[leaf].parent = e.parent;
+            } else {
+                int node = inner[index++];
+                nodes[node].cost = -1;
+                if (e.child == 0) nodes[e.parent].child0 = node; else nodes[e.parent].child1 = node;
+                nodes[node].parent = e.parent;
+                uint8_t left = optimal[e.part];
+                uint8_t right = (uint8_t)((~left) & e.part);
+                stack[sp++] = Entry{left, 0, node};
+                stack[sp++] = Entry{right, 1, node};
+            }
+        }
+        propagate_cost(root, leaves, nl);
+    }
+
+    void treelet_optimize(int root) {
+        if (nodes[root].edge_id != -1) return;
+        int leaves[7], inner[5];
+        int nl = 0, ni = 0;
+        leaves[nl++] = nodes[root].child0;
+        leaves[nl++] = nodes[root].child1;
+        int max_idx = 0;
+        while (nl < 7 && max_idx != -1) {
+            max_idx = -1;
+            double max_area = -1;
+            for (int i = 0; i < nl; ++i) {
+                if (nodes[leaves[i]].edge_id == -1) {
+                    double a = area(nodes[leaves[i]]);
+                    if (a > max_area) { max_area = a; max_idx = i; }
+                }
+            }
+            if (max_idx != -1) {
+                int tmp = leaves[max_idx];
+                inner[ni++] = tmp;
+                leaves[max_idx] = leaves[nl - 1];
+                leaves[nl - 1] = nodes[tmp].child0;
+                leaves[nl] = nodes[tmp].child1;
+                nl++;
+            }
+        }
+        // optimal partitioning of every subset (Karras & Aila 2013, Algorithm 2)
+        uint8_t optimal[128];
+        double a[128], c_opt[128];
+        int num_subsets = (1 << nl) - 1;
+        for (int s = 1; s <= num_subsets; ++s) {
+            EdgeNode acc = nodes[leaves[0]];
+            for (int i = 1; i < nl; ++i)
+                if ((s >> i) & 1) { EdgeNode t = acc; merge_children(acc, t, nodes[leaves[i]]); }
+            a[s] = area(acc);
+        }
+        for (int i = 0; i < nl; ++i) c_opt[1 << i] = nodes[leaves[i]].cost;
+        for (int k = 2; k <= nl; ++k) {
+            for (uint32_t s = 1; s <= (uint32_t)num_subsets; ++s) {
+                if (__builtin_popcount(s) != k) continue;
+                double c_s = std::numeric_limits<double>::infinity();
+                uint32_t p_s = 0;
+                uint32_t d = (s - 1u) & s;
+                uint32_t p = (-d) & s;
+                do {
+                    double c = c_opt[p] + c_opt[s ^ p];
+                    if (c < c_s) { c_s = c; p_s = p; }
+                    p = (p - d) & s;
+                } while (p != 0);
+                c_opt[s] = a[s] + c_s;
+                optimal[s] = (uint8_t)p_s;
+            }
+        }
+        uint8_t mask = (uint8_t)((1u << nl) - 1);
+        int index = 0;
+        uint8_t left = optimal[mask];
+        restruct(0, root, leaves, inner, left, optimal, index, nl);
+        uint8_t right = (uint8_t)((~left) & mask);
+        restruct(1, root, leaves, inner, right, optimal, index, nl);
+        refresh(root);
+    }
+};
+
+} // namespace
+
+void delete_edge_data(EdgeData *e) { delete e; }
+
+EdgeData *build_edge_data(Scene &scene) {
+    std::unique_ptr<EdgeData> ed(new EdgeData());
+    const int ns = (int)scene.shapes.size();
+    // host views of the shapes (same records, pointers into the host mirrors)
+    std::vector<ShapeD> hs(scene.shapes);
+    for (int i = 0; i < ns; ++i) {
+        hs[i].vertices = scene.h_vertices[i].data();
+        hs[i].indices = scene.h_indices[i].data();
+        hs[i].normals = scene.shapes[i].normals ? scene.h_normals[i].data() : nullptr;
+    }
+    const ShapeD *shapes = hs.data();
+
+    // ---- edge list (src/edge.cpp:233-297) ----
+    std::vector<EdgeD> &edges = ed->edges;
+    for (int sid = 0; sid < ns; ++sid) {
+        const ShapeD &sh = hs[sid];
+        std::vector<EdgeD> he(3 * (size_t)sh.num_triangles);
+        for (int t = 0; t < sh.num_triangles; ++t) {
+            int i0 = sh.indices[3 * t], i1 = sh.indices[3 * t + 1], i2 = sh.indices[3 * t + 2];
+            he[3 * t + 0] = EdgeD{sid, std::min(i0, i1), std::max(i0, i1), t, -1};
+            he[3 * t + 1] = EdgeD{sid, std::min(i1, i2), std::max(i1, i2), t, -1};
+            he[3 * t + 2] = EdgeD{sid, std::min(i2, i0), std::max(i2, i0), t, -1};
+        }
+        merge_sort_seq(he.data(), he.data() + he.size(), [](const EdgeD &a, const EdgeD &b) {
+            if (a.v0 == b.v0) return a.v1 < b.v1;
+            return a.v0 < b.v0;
+        });
+        // merge runs of identical (v0, v1): f1 of the run = f0 of its last member
+        std::vector<EdgeD> merged;
+        for (size_t i = 0; i < he.size();) {
+            EdgeD cur = he[i];
+            size_t j = i + 1;
+            while (j < he.size() && he[j].v0 == cur.v0 && he[j].v1 == cur.v1) { cur.f1 = he[j].f0; ++j; }
+            merged.push_back(cur);
+            i = j;
+        }
+        // sort by endpoint positions so duplicated (e.g. UV-seam) edges become neighbours
+        merge_sort_seq(merged.data(), merged.data() + merged.size(), [&](const EdgeD &a, const EdgeD &b) {
+            SortedEnds ea = sorted_ends(sh, a), eb = sorted_ends(sh, b);
+            if (f3_ne(ea.lo, eb.lo)) return f3_less_eq(ea.lo, eb.lo);
+            if (f3_ne(ea.hi, eb.hi)) return f3_less_eq(ea.hi, eb.hi);
+            return true;
+        });
+        const int ne = (int)merged.size();
+        std::vector<int> f1(ne);
+        for (int i = 0; i < ne; ++i) {
+            f1[i] = merged[i].f1;
+            if (f1[i] != -1) continue;
+            SortedEnds me = sorted_ends(sh, merged[i]);
+            if (i > 0) {
+                SortedEnds o = sorted_ends(sh, merged[i - 1]);
+                if (f3_eq(me.lo, o.lo) && f3_eq(me.hi, o.hi)) f1[i] = merged[i - 1].f0;
+            }
+            if (i < ne - 1) {
+                SortedEnds o = sorted_ends(sh, merged[i + 1]);
+                if (f3_eq(me.lo, o.lo) && f3_eq(me.hi, o.hi)) f1[i] = merged[i + 1].f0;
+            }
+        }
+        for (int i = 0; i < ne; ++i) { merged[i].f1 = f1[i]; edges.push_back(merged[i]); }
+    }
+    // drop edges between coplanar faces
+    {
+        std::vector<EdgeD> kept;
+        for (const EdgeD &e : edges) {
+            bool remove = false;
+            if (e.f0 != -1 && e.f1 != -1) {
+                V3 a = edge_v0(shapes, e), b = edge_v1(shapes, e);
+                V3 o0 = to_v3(edge_opp0f(shapes, e)), o1 = to_v3(edge_opp1f(shapes, e));
+                V3 n0 = normalize(cross(a - o0, b - o0)), n1 = normalize(cross(b - o1, a - o1));
+                remove = dot(n0, n1) >= (1 - 1e-6f);
+            }
+            if (!remove) kept.push_back(e);
+        }
+        edges.swap(kept);
+    }
+    const int ne = (int)edges.size();
+    const CameraD &cam = scene.d.cam;
+    V3 cam_org = xfm_point(cam.cam_to_world, v3(0));
+
+    // ---- primary edges: PMF = clipped screen-space length of camera silhouettes (:186-214, :299-334)
+    if (scene.use_primary_edges) {
+        ed->primary_pmf.assign(ne, 0); ed->primary_cdf.assign(ne, 0);
+        double total = 0;
+        for (int i = 0; i < ne; ++i) {
+            const EdgeD &e = edges[i];
+            V2 s0, s1, c0, c1;
+            double w = 0;
+            if (project_segment(cam, edge_v0(shapes, e), edge_v1(shapes, e), s0, s1))
+                if (clip_unit_square(s0, s1, c0, c1))
+                    if (edge_is_silhouette(shapes, cam_org, e)) w = len(c1 - c0);
+            ed->primary_pmf[i] = w;
+            total += w;
+        }
+        double run = 0;
+        for (int i = 0; i < ne; ++i) { ed->primary_pmf[i] = ed->primary_pmf[i] / total; }
+        for (int i = 0; i < ne; ++i) { ed->primary_cdf[i] = run; run += ed->primary_pmf[i]; }
+    }
+
+    // ---- secondary edges: the two hierarchies (src/edge_tree.cpp:724-882) ----
+    if (scene.use_secondary_edges && ne > 0) {
+        std::vector<int> cs_ids, ncs_ids;
+        for (int i = 0; i < ne; ++i) (edge_is_silhouette(shapes, cam_org, edges[i]) ? cs_ids : ncs_ids).push_back(i);
+        std::vector<Box6> bounds(ne);
+        for (int i = 0; i < ne; ++i) {
+            const EdgeD &e = edges[i];
+            F3 a = edge_v0f(shapes, e), b = edge_v1f(shapes, e);
+            Box6 bx;
+            bx.p_min = V3{(double)std::min(a.x, b.x), (double)std::min(a.y, b.y), (double)std::min(a.z, b.z)};
+            bx.p_max = V3{(double)std::max(a.x, b.x), (double)std::max(a.y, b.y), (double)std::max(a.z, b.z)};
+            V3 n0 = edge_n0(shapes, e);
+            V3 n1 = (e.f1 == -1) ? -n0 : edge_n1(shapes, e);
+            F3 mid = F3{0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
+            V3 p = to_v3(mid) - cam_org;
+            double p0d = dot(p, n0), p1d = dot(p, n1);
+            V3 h0 = V3{n0.x * p0d, n0.y * p0d, n0.z * p0d}, h1 = V3{n1.x * p1d, n1.y * p1d, n1.z * p1d};
+            bx.d_min = vmin(h0, h1); bx.d_max = vmax(h0, h1);
+            bounds[i] = bx;
+        }
+        // mean absolute deviation of the endpoints -> billboard half-width
+        std::vector<int> all_ids(cs_ids);
+        all_ids.insert(all_ids.end(), ncs_ids.begin(), ncs_ids.end());
+        V3 mean = v3(0);
+        for (int id : all_ids) {
+            F3 a = edge_v0f(shapes, edges[id]), b = edge_v1f(shapes, edges[id]);
+            mean += to_v3(F3{a.x + b.x, a.y + b.y, a.z + b.z});
+        }
+        mean = mean / (2. * double(ne));
+        V3 mad = v3(0);
+        for (int id : all_ids) {
+            F3 a = edge_v0f(shapes, edges[id]), b = edge_v1f(shapes, edges[id]);
+            V3 aa = V3{fabs(a.x - mean.x), fabs(a.y - mean.y), fabs(a.z - mean.z)};
+            V3 bb = V3{fabs(b.x - mean.x), fabs(b.y - mean.y), fabs(b.z - mean.z)};
+            mad += aa + bb;
+        }
+        mad = mad / double(ne);
+        ed->edge_bounds_expand = 0.01f * len(mad);
+
+        TreeBuilder cs(true, shapes, edges, bounds), ncs(false, shapes, edges, bounds);
+        cs.build(cs_ids);
+        ncs.build(ncs_ids);
+        ed->cs_nodes.swap(cs.nodes); ed->cs_leaves = cs.n;
+        ed->ncs_nodes.swap(ncs.nodes); ed->ncs_leaves = ncs.n;
+    }
+
+    // ---- device view ----
+    auto up = [&](const void *src, size_t bytes) -> void * {
+        void *p = exec::dmalloc(bytes);
+        scene.owned.push_back(p);
+        if (bytes) exec::upload(p, src, bytes);
+        return p;
+    };
+    EdgeSceneD &d = ed->d;
+    d.num_edges = ne;
+    d.edges = (const EdgeD *)up(edges.data(), sizeof(EdgeD) * edges.size());
+    d.primary_pmf = ed->primary_pmf.empty() ? nullptr : (const double *)up(ed->primary_pmf.data(), sizeof(double) * ne);
+    d.primary_cdf = ed->primary_cdf.empty() ? nullptr : (const double *)up(ed->primary_cdf.data(), sizeof(double) * ne);
+    d.cs_nodes = ed->cs_nodes.empty() ? nullptr : (const EdgeNode *)up(ed->cs_nodes.data(), sizeof(EdgeNode) * ed->cs_nodes.size());
+    d.ncs_nodes = ed->ncs_nodes.empty() ? nullptr : (const EdgeNode *)up(ed->ncs_nodes.data(), sizeof(EdgeNode) * ed->ncs_nodes.size());
+    d.edge_bounds_expand = ed->edge_bounds_expand;
+    d.cam_org = cam_org;
+    d.ltc = scene.ltc_table;
+    return ed.release();
+}
+
+} // namespace rdr

@@ -1,8 +1,146 @@
-// edges.h -- edge-sampling structures (placeholder until the edge estimator lands).
+// edges.h -- mesh edges and the two edge hierarchies used by the edge-sampling estimators.
+//
+// Behavioural spec: Edge + silhouette predicates src/edge.h:13-241; edge list construction,
+// primary PMF/CDF src/edge.cpp:43-334; EdgeTree (3-D hierarchy over camera-silhouette edges, 6-D
+// position x Hough-normal hierarchy over the rest) src/edge_tree.cpp:14-882, src/aabb.h.
+//
+// Layout: both hierarchies use one 128-byte node record (the 3-D tree leaves d_* unused) in a
+// single array [internal nodes | leaves]; links are array indices instead of pointers, so the
+// structure can be uploaded to HBM verbatim.  A node reference is an int: bit 30 selects the
+// tree (0 = camera-silhouette, 1 = the rest), the low bits index that tree's array.
+//
+// Which edge a sample lands on depends on the exact order of the edge list and on the exact
+// topology of the trees (Morton ties, treelet restructuring), so edges.cpp reproduces the
+// reference's build step by step, including the behaviour of the sequential sort it runs on CPU.
 #pragma once
+#include "surface.h"
+#include <vector>
+
 namespace rdr {
+
+struct EdgeD { int shape_id, v0, v1, f0, f1; };
+
+struct EdgeNode {
+    V3 p_min, p_max;     // spatial bounds
+    V3 d_min, d_max;     // Hough-space bounds (6-D tree only)
+    double wlen;         // sum of length * exterior dihedral angle below this node
+    double cost;         // SAH cost used by the treelet optimiser
+    int parent, child0, child1, edge_id;   // edge_id >= 0 marks a leaf
+};
+
+constexpr int kEdgeTreeBit = 1 << 30;
+
+struct EdgeSceneD {
+    const EdgeD *edges;
+    int num_edges;
+    const double *primary_pmf, *primary_cdf;
+    const EdgeNode *cs_nodes, *ncs_nodes;    // null when the tree is empty
+    double edge_bounds_expand;
+    V3 cam_org;
+    const float *ltc;                         // tabM, 128 x 128 x 9
+};
+
+RDR_FN const EdgeNode &edge_node(const EdgeSceneD &es, int ref) {
+    return (ref & kEdgeTreeBit) ? es.ncs_nodes[ref & (kEdgeTreeBit - 1)] : es.cs_nodes[ref];
+}
+RDR_FN bool edge_ref_is_3d(int ref) { return (ref & kEdgeTreeBit) == 0; }
+
+// ---- fp32 vertex helpers (comparisons and lengths are done in float, like the reference) --------
+struct F3 { float x, y, z; };
+RDR_FN F3 f3_vertex(const ShapeD &sh, int i) { return F3{sh.vertices[3 * i], sh.vertices[3 * i + 1], sh.vertices[3 * i + 2]}; }
+RDR_FN bool f3_ne(F3 a, F3 b) { return a.x != b.x || a.y != b.y || a.z != b.z; }
+RDR_FN bool f3_eq(F3 a, F3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+RDR_FN V3 to_v3(F3 a) { return V3{(double)a.x, (double)a.y, (double)a.z}; }
+RDR_FN float f3_distance(F3 a, F3 b) {
+    float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
+    return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+RDR_FN F3 edge_v0f(const ShapeD *shapes, const EdgeD &e) { return f3_vertex(shapes[e.shape_id], e.v0); }
+RDR_FN F3 edge_v1f(const ShapeD *shapes, const EdgeD &e) { return f3_vertex(shapes[e.shape_id], e.v1); }
+RDR_FN V3 edge_v0(const ShapeD *shapes, const EdgeD &e) { return to_v3(edge_v0f(shapes, e)); }
+RDR_FN V3 edge_v1(const ShapeD *shapes, const EdgeD &e) { return to_v3(edge_v1f(shapes, e)); }
+
+// third corner of face f0 (by index) / of face f1 (by position, because merged duplicates may
+// reference different vertex ids; src/edge.h:88-126)
+RDR_FN F3 edge_opp0f(const ShapeD *shapes, const EdgeD &e) {
+    const ShapeD &sh = shapes[e.shape_id];
+    for (int i = 0; i < 3; ++i) {
+        int vi = sh.indices[3 * e.f0 + i];
+        if (vi != e.v0 && vi != e.v1) return f3_vertex(sh, vi);
+    }
+    return edge_v0f(shapes, e);
+}
+RDR_FN F3 edge_opp1f(const ShapeD *shapes, const EdgeD &e) {
+    const ShapeD &sh = shapes[e.shape_id];
+    F3 a = edge_v0f(shapes, e), b = edge_v1f(shapes, e);
+    for (int i = 0; i < 3; ++i) {
+        F3 v = f3_vertex(sh, sh.indices[3 * e.f1 + i]);
+        if (f3_ne(v, a) && f3_ne(v, b)) return v;
+    }
+    return b;
+}
+
+RDR_FN V3 edge_n0(const ShapeD *shapes, const EdgeD &e) {
+    V3 a = edge_v0(shapes, e), b = edge_v1(shapes, e), o = to_v3(edge_opp0f(shapes, e));
+    V3 n = cross(a - o, b - o);
+    double l2 = len_sq(n);
+    if (l2 < 1e-20) return v3(0);
+    return n / sqrt(l2);
+}
+RDR_FN V3 edge_n1(const ShapeD *shapes, const EdgeD &e) {
+    V3 a = edge_v0(shapes, e), b = edge_v1(shapes, e), o = to_v3(edge_opp1f(shapes, e));
+    V3 n = cross(b - o, a - o);
+    double l2 = len_sq(n);
+    if (l2 < 1e-20) return v3(0);
+    return n / sqrt(l2);
+}
+
+// Is the edge a silhouette as seen from point p?  (src/edge.h:155-204)
+RDR_FN bool edge_is_silhouette(const ShapeD *shapes, V3 p, const EdgeD &e) {
+    V3 a = edge_v0(shapes, e), b = edge_v1(shapes, e);
+    if (e.f0 == -1 || e.f1 == -1) {
+        if (e.f0 != -1) {
+            V3 o = to_v3(edge_opp0f(shapes, e));
+            if (len_sq(cross(a - o, b - o)) < 1e-20) return false;
+        }
+        if (e.f1 != -1) {
+            V3 o = to_v3(edge_opp1f(shapes, e));
+            if (len_sq(cross(b - o, a - o)) < 1e-20) return false;
+        }
+        return true;
+    }
+    V3 o0 = to_v3(edge_opp0f(shapes, e)), o1 = to_v3(edge_opp1f(shapes, e));
+    V3 n0 = cross(a - o0, b - o0), n1 = cross(b - o1, a - o1);
+    double l0 = len_sq(n0), l1 = len_sq(n1);
+    if (l0 < 1e-20 || l1 < 1e-20) return false;
+    n0 = n0 / sqrt(l0); n1 = n1 / sqrt(l1);
+    if (!shapes[e.shape_id].normals) return !(dot(n0, n1) >= 1 - 1e-6f);
+    bool ff0 = dot(p - o0, n0) > 0.f, ff1 = dot(p - o1, n1) > 0.f;
+    return (ff0 && !ff1) || (!ff0 && ff1);
+}
+
+RDR_FN double edge_exterior_dihedral(const ShapeD *shapes, const EdgeD &e) {
+    double a = double(M_PI);
+    if (e.f1 != -1) {
+        double c = dot(edge_n0(shapes, e), edge_n1(shapes, e));
+        c = c < -1.0 ? -1.0 : (c > 1.0 ? 1.0 : c);
+        a = acos(c);
+    }
+    return a;
+}
+
+// ---- host-side container -------------------------------------------------------------------------
 struct Scene;
-struct EdgeData;
+struct EdgeData {
+    std::vector<EdgeD> edges;
+    std::vector<double> primary_pmf, primary_cdf;
+    std::vector<EdgeNode> cs_nodes, ncs_nodes;   // [internal | leaves]
+    int cs_leaves = 0, ncs_leaves = 0;
+    double edge_bounds_expand = 0;
+    EdgeSceneD d;            // device view
+};
 EdgeData *build_edge_data(Scene &scene);
 void delete_edge_data(EdgeData *e);
-}
+
+} // namespace rdr

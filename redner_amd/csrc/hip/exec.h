@@ -181,3 +181,8 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n,
 void select_device(int use_gpu, int gpu_index);
 
 } // namespace exec
+
+namespace rdr {
+__device__ inline void accum_f32(float *p, float v) { atomicAdd(p, v); }
+__host__ inline void accum_f32(float *p, float v) { *p += v; }
+}

@@ -170,23 +170,98 @@ struct Backward {
         adj.thr = arena.get<double>((size_t)3 * P);
         adj.ray_dir = arena.get<double>((size_t)3 * P);
         adj.point = arena.get<double>((size_t)kAdjPointDoubles * P);
+        const bool edges_on = scene.edges && scene.edges->d.num_edges > 0 &&
+                              (scene.use_primary_edges || scene.use_secondary_edges);
+        if (edges_on) {
+            const int L = 2 * P;                      // edge lanes: two rays per sample slot
+            ea = make_slice(arena, L, false);
+            eb = make_slice(arena, L, false);
+            for (int k = 0; k < 3; ++k) elist[k] = arena.get<int>(L);
+            edge_contrib = arena.get<double>(L);
+            edge_tmin = arena.get<double>(L);
+            hit_pos = arena.get<double>((size_t)3 * L);
+            prim_recs = arena.get<PrimaryEdgeRec>(P);
+            sec_recs = arena.get<SecondaryEdgeRec>(P);
+        }
+    }
+
+    VSlice ea, eb;                 // ping-pong vertex slices of the edge sub-paths (2P lanes each)
+    int *elist[3] = {nullptr, nullptr, nullptr};
+    double *edge_contrib = nullptr, *edge_tmin = nullptr, *hit_pos = nullptr;
+    PrimaryEdgeRec *prim_recs = nullptr;
+    SecondaryEdgeRec *sec_recs = nullptr;
+
+    // Path-trace the live edge lanes to the end, starting with `n_act` lanes listed in elist[1]
+    // whose current vertex is in `ea`.  Returns the number of Sobol' dimensions consumed.
+    int trace_edge_paths(const SobolD &rng_edge, int edim, int n_act, int first_depth, const Queues &q, const Sink &sink,
+                         bool need_lights) {
+        int used = 0;
+        const bool has_lights = scene.d.num_lights > 0;
+        int cur = 1;
+        for (int depth = first_depth, k = 0; depth < B && n_act > 0 && (!need_lights || has_lights); ++depth, ++k) {
+            const VSlice &m = (k % 2 == 0) ? ea : eb;
+            const VSlice &nx = (k % 2 == 0) ? eb : ea;
+            int nxt = (cur == 1) ? 2 : 1;
+            n_act = run_bounce(scene, rng_edge, edim + used, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt]);
+            cur = nxt;
+            used += 7;
+        }
+        return used;
     }
 
     void run_sample(int sample_id, std::vector<VSlice> &vs, int *active, std::vector<int> &num_active, const Queues &q) {
-        (void)q;
         SobolD rng{scene.sobol_table, opt.seed, sample_id};
+        SobolD rng_edge{scene.sobol_table, opt.seed + 131071U, sample_id};   // src/pathtracer.cpp:221-227
         const bool has_lights = scene.d.num_lights > 0;
+        const bool edges_on = prim_recs != nullptr;
+        Sink esink{nullptr, edge_contrib, nd, radiance_dim, weight};
+        int edim = 0;
         exec::zero(adj.thr, sizeof(double) * 3 * P);
         exec::zero(adj.ray_dir, sizeof(double) * 3 * P);
         exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * P);
         const int dim0 = opt.sample_pixel_center ? 0 : 2;
         for (int d = B - 1; d >= 0 && has_lights; --d) {
-            if (num_active[d] <= 0) continue;
-            exec::launch(num_active[d], AdjBounce{scene.d, grads.g, rng, dim0 + 7 * d, active + (size_t)d * P, vs[d], vs[d + 1],
-                                                  d_image, nd, radiance_dim, weight, adj});
+            const int nA = num_active[d];
+            if (nA <= 0) continue;
+            const int *act = active + (size_t)d * P;
+            exec::launch(nA, AdjBounce{scene.d, grads.g, rng, dim0 + 7 * d, act, vs[d], vs[d + 1],
+                                       d_image, nd, radiance_dim, weight, adj});
+            if (edges_on && scene.use_secondary_edges) {
+                // ---- secondary (shadow / inter-reflection) edges at this vertex, :500-706 ----
+                const EdgeSceneD &es = scene.edges->d;
+                const int lanes = 2 * nA;
+                exec::launch(nA, SampleSecondaryEdges{scene.d, es, rng, dim0 + 7 * d, rng_edge, edim, act, vs[d],
+                                                      d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});
+                edim += 4;
+                int n0 = exec::compact((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
+                exec::launch(n0, QueueRays{elist[0], ea, edge_tmin, q.bsdf});
+                exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
+                exec::launch(n0, RecordHits{elist[0], ea, q.h_bsdf});
+                exec::launch(nA, SecondaryEdgeWeights{scene.d, sec_recs, ea, hit_pos});
+                exec::zero(edge_contrib, sizeof(double) * lanes);
+                exec::launch(n0, ShadeRecorded{scene.d, elist[0], ea, esink});
+                int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
+                edim += trace_edge_paths(rng_edge, edim, n1, d + 1, q, esink, false);
+                exec::launch(nA, SecondaryEdgeDerivatives{scene.d, grads.g, act, sec_recs, hit_pos, ea.n, edge_contrib, adj});
+            }
         }
         exec::launch(P, AdjPrimary{scene.d, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
                                    adj, screen_grad});
+        if (edges_on && scene.use_primary_edges) {
+            // ---- primary (camera-visible silhouette) edges, :766-942 ----
+            const EdgeSceneD &es = scene.edges->d;
+            const int lanes = 2 * P;
+            exec::zero(edge_contrib, sizeof(double) * lanes);
+            exec::launch(P, SamplePrimaryEdges{scene.d, es, rng_edge, edim, d_image, nd, radiance_dim, prim_recs, ea});
+            edim += 2;
+            int n0 = exec::compact((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
+            exec::launch(n0, QueueRays{elist[0], ea, nullptr, q.bsdf});
+            exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
+            exec::launch(n0, ShadePrimary{scene.d, elist[0], ea, q.h_bsdf, esink});
+            int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
+            edim += trace_edge_paths(rng_edge, edim, n1, 0, q, esink, true);
+            exec::launch(P, PrimaryEdgeDerivatives{scene.d, grads.g, prim_recs, edge_contrib, screen_grad});
+        }
     }
     void flush() { grads.flush(); }
 };

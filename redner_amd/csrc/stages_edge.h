@@ -1,1 +1,682 @@
+// stages_edge.h -- the edge-sampling estimators (visibility gradients).
+//
+// Behavioural spec:
+//   SamplePrimaryEdges        <- primary_edge_sampler               src/edge.cpp:385-625
+//   PrimaryEdgeDerivatives    <- primary_edge_derivatives_computer  src/edge.cpp:700-783
+//   SampleSecondaryEdges      <- secondary_edge_sampler             src/edge.cpp:826-1773
+//        (ltc_bound :838-883, importance :885-928, leaf importance :942-1083, hierarchical pick
+//         sample_edge_h :1115-1237, NEE-billboard pick sample_edge_l :1239-1364)
+//   SecondaryEdgeWeights      <- secondary_edge_weights_updater     src/edge.cpp:1856-1981
+//   SecondaryEdgeDerivatives  <- secondary_edge_derivatives_accumulator  src/edge.cpp:2001-2053
+// Edge sub-paths live in lanes 2*slot (upper side) and 2*slot+1 (lower side) of a pair of
+// ping-pong vertex slices; both lanes of a slot draw the same random numbers.
 #pragma once
+#include "edges.h"
+#include "stages_bwd.h"
+
+namespace rdr {
+
+// ---- small 3x3 helpers (cofactor inverse in the reference's operation order, src/matrix.h:222-244)
+RDR_FN M3 m3_from_frame(const Frame &f) {
+    M3 r;
+    r.m[0][0] = f.x.x; r.m[0][1] = f.x.y; r.m[0][2] = f.x.z;
+    r.m[1][0] = f.y.x; r.m[1][1] = f.y.y; r.m[1][2] = f.y.z;
+    r.m[2][0] = f.n.x; r.m[2][1] = f.n.y; r.m[2][2] = f.n.z;
+    return r;
+}
+RDR_FN M3 m3_inverse(const M3 &a) {
+    const double (*m)[3] = a.m;
+    double det = m[0][0] * (m[1][1] * m[2][2] - m[2][1] * m[1][2]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                 m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    double id = 1 / det;
+    M3 r;
+    r.m[0][0] = (m[1][1] * m[2][2] - m[2][1] * m[1][2]) * id;
+    r.m[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id;
+    r.m[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id;
+    r.m[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * id;
+    r.m[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id;
+    r.m[1][2] = (m[1][0] * m[0][2] - m[0][0] * m[1][2]) * id;
+    r.m[2][0] = (m[1][0] * m[2][1] - m[2][0] * m[1][1]) * id;
+    r.m[2][1] = (m[2][0] * m[0][1] - m[0][0] * m[2][1]) * id;
+    r.m[2][2] = (m[0][0] * m[1][1] - m[1][0] * m[0][1]) * id;
+    return r;
+}
+RDR_FN M3 m3_mul(const M3 &a, const M3 &b) {
+    M3 r;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += a.m[i][k] * b.m[k][j];
+        r.m[i][j] = s;
+    }
+    return r;
+}
+RDR_FN V3 m3_apply(const M3 &a, V3 v) {     // sums start from 0.f, accumulate left to right
+    V3 r;
+    r.x = ((0.0 + a.m[0][0] * v.x) + a.m[0][1] * v.y) + a.m[0][2] * v.z;
+    r.y = ((0.0 + a.m[1][0] * v.x) + a.m[1][1] * v.y) + a.m[1][2] * v.z;
+    r.z = ((0.0 + a.m[2][0] * v.x) + a.m[2][1] * v.y) + a.m[2][2] * v.z;
+    return r;
+}
+
+struct PrimaryEdgeRec { EdgeD edge; V2 edge_pt; };
+struct SecondaryEdgeRec { EdgeD edge; V3 edge_pt, mwt, sp_pos; int use_nee_ray, diffuse_or_glossy; };
+
+// Emit queue records for the live lanes of an edge slice (optional per-lane tmin).
+struct QueueRays {
+    const int *active; VSlice v; const double *tmin; rt::RayRec *q;
+    RDR_FN void operator()(int idx) const {
+        int p = active[idx];
+        Ray r = load_ray(v, p);
+        if (tmin) r.tmin = tmin[p];
+        put_ray(q, idx, r, len_sq(r.dir) <= 1e-3f);
+    }
+};
+struct RecordHits {
+    const int *active; VSlice v; const rt::HitRec *hits;
+    RDR_FN void operator()(int idx) const {
+        int p = active[idx];
+        rt::HitRec h = hits[idx];
+        v.shape[p] = h.shape; v.tri[p] = h.shape >= 0 ? h.prim : -1;
+    }
+};
+// First-hit emission for lanes whose hit ids are already recorded.
+struct ShadeRecorded {
+    SceneD sc; const int *active; VSlice v; Sink sink;
+    RDR_FN void operator()(int idx) const {
+        int p = active[idx];
+        Ray ray = load_ray(v, p);
+        V3 e = direct_emission(sc, v.shape[p], v.tri[p], ray, load_rdiff(v, p));
+        V3 c = sink.weight * ld3(v.thr, v.n, p, 0) * e;
+        if (sink.edge_contrib) sink.edge_contrib[p] += sum(c);
+    }
+};
+struct FillDouble { double *p; double value; RDR_FN void operator()(int i) const { p[i] = value; } };
+
+// ===================================== primary edges ================================================
+struct SamplePrimaryEdges {
+    SceneD sc; EdgeSceneD es; SobolD rng; int dim;
+    const float *d_image; int nd, radiance_dim;
+    PrimaryEdgeRec *recs; VSlice v;       // lanes 2*slot, 2*slot+1
+    RDR_FN void operator()(int slot) const {
+        int l0 = 2 * slot, l1 = 2 * slot + 1;
+        PrimaryEdgeRec rec;
+        rec.edge = EdgeD{-1, 0, 0, 0, 0};
+        rec.edge_pt = v2(0, 0);
+        recs[slot] = rec;
+        for (int l = l0; l <= l1; ++l) {
+            st3(v.thr, v.n, l, 0, v3(0));
+            store_ray(v, l, v3(0), v3(0));
+            v.shape[l] = -1; v.tri[l] = -1;
+            v.mrough[l] = 0;
+        }
+        double edge_sel = rng.draw(slot, dim), t = rng.draw(slot, dim + 1);
+        int eid = iclamp(upper_bound_idx(es.primary_cdf, es.num_edges, edge_sel) - 1, 0, es.num_edges - 1);
+        const EdgeD &edge = es.edges[eid];
+        V3 a = edge_v0(sc.shapes, edge), b = edge_v1(sc.shapes, edge);
+        V2 a_ss, b_ss;
+        // both rays of a slot carry the differential of the sampled screen position; see DESIGN.md
+        // "edge-ray differentials" for how this differs from the reference's slot-indexed buffer
+        RayDiff rd;
+        if (!project_segment(sc.cam, a, b, a_ss, b_ss) || es.primary_pmf[eid] <= 0.f) {
+            store_rdiff(v, l0, raydiff_zero()); store_rdiff(v, l1, raydiff_zero());
+            return;
+        }
+        V2 pt = a_ss + t * (b_ss - a_ss);
+        if (!in_screen(sc.cam, pt)) {
+            store_rdiff(v, l0, raydiff_zero()); store_rdiff(v, l1, raydiff_zero());
+            return;
+        }
+        rec.edge = edge; rec.edge_pt = pt;
+        recs[slot] = rec;
+        V2 dn = normalize(a_ss - b_ss);
+        V2 hn = v2(dn.y, -dn.x);
+        double off = 1e-6f;
+        Ray up = primary_ray(sc.cam, pt + hn * off), lo = primary_ray(sc.cam, pt - hn * off);
+        store_ray(v, l0, up.org, up.dir);
+        store_ray(v, l1, lo.org, lo.dir);
+        int vw = sc.cam.vp_x1 - sc.cam.vp_x0, vh = sc.cam.vp_y1 - sc.cam.vp_y0;
+        int xi = iclamp(int(pt.x * sc.cam.width - sc.cam.vp_x0), 0, vw);
+        int yi = iclamp(int(pt.y * sc.cam.height - sc.cam.vp_y0), 0, vh);
+        V3 dc = image_grad(d_image, nd, radiance_dim, yi * vw + xi);
+        double pmf = es.primary_pmf[eid];
+        st3(v.thr, v.n, l0, 0, dc / pmf);
+        st3(v.thr, v.n, l1, 0, -dc / pmf);
+        primary_ray_with_diff(sc.cam, pt, rd);
+        store_rdiff(v, l0, rd); store_rdiff(v, l1, rd);
+    }
+};
+
+struct PrimaryEdgeDerivatives {
+    SceneD sc; GScene g; const PrimaryEdgeRec *recs; const double *edge_contrib; float *screen_grad;
+    RDR_FN void operator()(int slot) const {
+        const PrimaryEdgeRec &rec = recs[slot];
+        if (rec.edge.shape_id < 0) return;
+        double contrib = edge_contrib[2 * slot] + edge_contrib[2 * slot + 1];
+        V3 a = edge_v0(sc.shapes, rec.edge), b = edge_v1(sc.shapes, rec.edge);
+        V2 a_ss, b_ss;
+        if (!project_segment(sc.cam, a, b, a_ss, b_ss)) return;
+        V2 pt = rec.edge_pt;
+        // Eq. 8 of the paper: gradient of the edge equation w.r.t. its screen-space end points
+        V2 a_bar = v2(b_ss.y - pt.y, pt.x - b_ss.x);
+        V2 b_bar = v2(pt.y - a_ss.y, a_ss.x - pt.x);
+        V2 pt_bar = v2(a_ss.y - b_ss.y, b_ss.x - a_ss.x);
+        a_bar = a_bar * contrib; b_bar = b_bar * contrib; pt_bar = pt_bar * contrib;
+        V3 pa_bar = v3(0), pb_bar = v3(0);
+        adj_project_segment(sc.cam, a, b, a_bar, b_bar, g.cam, pa_bar, pb_bar);
+        double *gv = g.shapes[rec.edge.shape_id].vertices;
+        accum3(gv + 3 * rec.edge.v0, pa_bar);
+        accum3(gv + 3 * rec.edge.v1, pb_bar);
+        if (screen_grad) {
+            int vw = sc.cam.vp_x1 - sc.cam.vp_x0, vh = sc.cam.vp_y1 - sc.cam.vp_y0;
+            int xi = iclamp(int(pt.x * sc.cam.width - sc.cam.vp_x0), 0, vw);
+            int yi = iclamp(int(pt.y * sc.cam.height - sc.cam.vp_y0), 0, vh);
+            accum_f32(screen_grad + 2 * (yi * vw + xi), (float)pt_bar.x);
+            accum_f32(screen_grad + 2 * (yi * vw + xi) + 1, (float)pt_bar.y);
+        }
+    }
+};
+
+// ==================================== secondary edges ===============================================
+struct LtcCtx { V3 pos; M3 m, m_inv; };
+
+RDR_FN bool box_contains(V3 lo, V3 hi, V3 p) {
+    return p.x >= lo.x && p.x <= hi.x && p.y >= lo.y && p.y <= hi.y && p.z >= lo.z && p.z <= hi.z;
+}
+RDR_FN double min_abs_bound(double lo, double hi) {
+    if (lo <= 0.f && hi >= 0.f) return 0;
+    if (lo <= 0.f && hi <= 0.f) return hi;
+    return lo;
+}
+// Upper bound of the LTC-transformed clamped cosine over a box (src/edge.cpp:838-876).
+RDR_FN double ltc_bound(V3 lo, V3 hi, const LtcCtx &c) {
+    V3 dir = V3{0, 0, 1};
+    if (!box_contains(lo, hi, c.pos)) {
+        double inf = INFINITY;
+        V3 bl = v3(inf), bh = v3(-inf);
+        for (int i = 0; i < 8; ++i) {
+            V3 corner = V3{(i & 1) == 0 ? lo.x : hi.x, (i & 2) == 0 ? lo.y : hi.y, (i & 4) == 0 ? lo.z : hi.z};
+            V3 q = m3_apply(c.m_inv, corner - c.pos);
+            bl = V3{dmin(bl.x, q.x), dmin(bl.y, q.y), dmin(bl.z, q.z)};
+            bh = V3{dmax(bh.x, q.x), dmax(bh.y, q.y), dmax(bh.z, q.z)};
+        }
+        if (bh.z < 0) return 0;
+        dir.x = min_abs_bound(bl.x, bh.x);
+        dir.y = min_abs_bound(bl.y, bh.y);
+        dir.z = bh.z;
+        double dl = len(dir);
+        if (dl <= 0) dir = V3{0, 0, 1}; else dir = dir / dl;
+    }
+    V3 md = normalize(m3_apply(c.m, dir));
+    V3 ml = m3_apply(c.m_inv, md);
+    if (ml.z <= 0) return 0;
+    double nrm = sq(len_sq(ml));
+    return ml.z / nrm;
+}
+// Sphere/box overlap (Arvo), early-out form of src/aabb.h:158-174.
+RDR_FN bool sphere_box(V3 ctr, double radius, V3 lo, V3 hi) {
+    double dmin_ = 0, r2 = sq(radius);
+    for (int i = 0; i < 3; ++i) {
+        double ci = comp(ctr, i), li = comp(lo, i), hi_ = comp(hi, i);
+        if (ci < li) dmin_ += sq(ci - li);
+        else if (ci > hi_) dmin_ += sq(ci - hi_);
+        if (dmin_ <= r2) return true;
+    }
+    return false;
+}
+RDR_FN bool may_hold_silhouette(const EdgeSceneD &es, int ref, V3 p) {
+    if (edge_ref_is_3d(ref)) return true;
+    const EdgeNode &nd = edge_node(es, ref);
+    return sphere_box(0.5f * (p - es.cam_org), 0.5f * len(es.cam_org - p), nd.d_min, nd.d_max);
+}
+RDR_FN double node_importance(const EdgeSceneD &es, int ref, const LtcCtx &c) {
+    const EdgeNode &nd = edge_node(es, ref);
+    if (!edge_ref_is_3d(ref)) {
+        if (!sphere_box(0.5f * (c.pos - es.cam_org), 0.5f * len(es.cam_org - c.pos), nd.d_min, nd.d_max)) return 0;
+    }
+    double brdf = ltc_bound(nd.p_min, nd.p_max, c);
+    V3 ctr = 0.5f * (nd.p_min + nd.p_max);
+    return brdf * nd.wlen / dmax(len(c.pos - ctr), 1e-3);
+}
+
+// LTC line integral of an edge seen from the shading point (clipped to the tangent plane).
+struct LineSetup { bool ok; V3 wt, vo; double d, l0, l1; };
+RDR_FN double line_I(const LineSetup &s, double l) {
+    double d = s.d;
+    return (l / (d * (d * d + l * l)) + atan(l / d) / (d * d)) * s.vo.z + (l * l / (d * (d * d + l * l))) * s.wt.z;
+}
+RDR_FN LineSetup line_setup(V3 v0o, V3 v1o) {
+    LineSetup s;
+    s.ok = false;
+    if (v0o.z < 0.f) v0o = (v0o * v1o.z - v1o * v0o.z) / (v1o.z - v0o.z);
+    if (v1o.z < 0.f) v1o = (v0o * v1o.z - v1o * v0o.z) / (v1o.z - v0o.z);
+    V3 dirv = v1o - v0o;
+    s.wt = normalize(dirv);
+    s.l0 = dot(v0o, s.wt);
+    s.l1 = dot(v1o, s.wt);
+    s.vo = v0o - s.l0 * s.wt;
+    s.d = len(s.vo);
+    s.ok = true;
+    return s;
+}
+RDR_FN double edge_line_importance(const SceneD &sc, const EdgeD &e, const LtcCtx &c) {
+    V3 a = edge_v0(sc.shapes, e), b = edge_v1(sc.shapes, e);
+    if (len_sq(b - a) > 1e-10f) {
+        V3 ao = m3_apply(c.m_inv, a - c.pos), bo = m3_apply(c.m_inv, b - c.pos);
+        if (ao.z > 0.f || bo.z > 0.f) {
+            LineSetup s = line_setup(ao, bo);
+            return dmax(line_I(s, s.l1) - line_I(s, s.l0), 0.0);
+        }
+    }
+    return 0;
+}
+RDR_FN double leaf_importance_h(const SceneD &sc, const EdgeSceneD &es, int ref, const LtcCtx &c) {
+    const EdgeD &e = es.edges[edge_node(es, ref).edge_id];
+    if (!edge_is_silhouette(sc.shapes, c.pos, e)) return 0;
+    return edge_line_importance(sc, e, c);
+}
+// Leaf weight for the NEE-billboard mode: the edge must be a silhouette from both ends of the NEE
+// segment and the NEE ray must pass within `edge_bounds_expand` of it.
+RDR_FN double leaf_importance_l(const SceneD &sc, const EdgeSceneD &es, int ref, const LtcCtx &c,
+                                const Ray &nee, bool nee_valid) {
+    const EdgeD &e = es.edges[edge_node(es, ref).edge_id];
+    if (!edge_is_silhouette(sc.shapes, c.pos, e)) return 0;
+    if (nee_valid) {
+        if (!edge_is_silhouette(sc.shapes, nee.org + nee.tmax * nee.dir, e)) return 0;
+    } else {
+        if (!edge_is_silhouette(sc.shapes, nee.dir, e)) return 0;
+    }
+    V3 a = edge_v0(sc.shapes, e), b = edge_v1(sc.shapes, e);
+    V3 pn = nee.dir;
+    double t = -(dot(nee.org, pn) - dot(a, pn)) / dot(nee.dir, pn);
+    V3 ip = nee.org + nee.dir * t;
+    V3 ap = a - ip;
+    V3 ab = normalize(b - a);
+    V3 ept = ip + ap - (dot(ap, ab)) * ab;
+    if (len_sq(ip - ept) > sq(es.edge_bounds_expand)) return 0;
+    return edge_line_importance(sc, e, c);
+}
+
+// Slab test of the reference's edge-tree traversal (src/aabb.h:176-200), boxes grown by `expand`.
+RDR_FN bool ray_box_expand(V3 lo, V3 hi, const Ray &r, double expand) {
+    double t0 = r.tmin, t1 = r.tmax;
+    for (int i = 0; i < 3; ++i) {
+        double inv = 1 / comp(r.dir, i);
+        double tn = (comp(lo, i) - expand - comp(r.org, i)) * inv;
+        double tf = (comp(hi, i) + expand - comp(r.org, i)) * inv;
+        if (tn > tf) { double t = tn; tn = tf; tf = t; }
+        tf *= (1 + 1e-6f);
+        t0 = tn > t0 ? tn : t0;
+        t1 = tf < t1 ? tf : t1;
+        if (t0 > t1) return false;
+    }
+    return true;
+}
+
+constexpr int kEdgeStack = 128;
+constexpr int kHSamples = 16;
+
+struct HItem { int ref, num; double pmf; };
+
+// Stochastic top-down pick of one edge, splitting kHSamples "samples" by LTC-bounded importance
+// and keeping one leaf by reservoir sampling.  Returns the edge id or -1; weight = 1/pmf.
+RDR_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c,
+                                  double sample, double resample, double &weight) {
+    HItem stack[kEdgeStack];
+    int sp = 0;
+    int selected = -1;
+    double edge_w = 0, wsum = 0;
+    double imp_cs = es.cs_nodes ? 1.0 : 0.0, imp_ncs = es.ncs_nodes ? 1.0 : 0.0;
+    if (imp_cs <= 0 && imp_ncs <= 0) return -1;
+    double prob_cs = imp_cs / (imp_cs + imp_ncs), prob_ncs = 1 - prob_cs;
+    double exp_cs = kHSamples * prob_cs, exp_ncs = kHSamples * prob_ncs;
+    int n_cs = int(floor(exp_cs)), n_ncs = int(floor(exp_ncs));
+    if (n_cs + n_ncs < kHSamples) {
+        double prob = exp_cs - n_cs;
+        if (sample < prob) { n_cs++; sample /= prob; }
+        else { n_ncs++; sample = (sample - prob) / (1 - prob); }
+    }
+    if (n_cs > 0) stack[sp++] = HItem{0, n_cs, prob_cs};
+    if (n_ncs > 0) stack[sp++] = HItem{kEdgeTreeBit, n_ncs, prob_ncs};
+    while (sp > 0) {
+        HItem it = stack[--sp];
+        const EdgeNode &nd = edge_node(es, it.ref);
+        if (nd.edge_id != -1) {
+            double w = it.num * leaf_importance_h(sc, es, it.ref, c) / it.pmf;
+            if (w > 0) {
+                double prev = wsum;
+                wsum += w;
+                double nw = w / wsum;
+                if (resample <= nw || prev == 0) {
+                    selected = nd.edge_id;
+                    edge_w = w * it.pmf;
+                    resample /= nw;
+                } else {
+                    resample = (resample - nw) / (1 - nw);
+                }
+            }
+        } else {
+            int tree = it.ref & kEdgeTreeBit;
+            int c0 = nd.child0 | tree, c1 = nd.child1 | tree;
+            double i0, i1;
+            if (box_contains(nd.p_min, nd.p_max, c.pos)) { i0 = i1 = 1; }
+            else { i0 = node_importance(es, c0, c); i1 = node_importance(es, c1, c); }
+            if (i0 > 0 || i1 > 0) {
+                double p0 = i0 / (i0 + i1), p1 = 1 - p0;
+                double e0 = it.num * p0, e1 = it.num * p1;
+                int s0 = int(floor(e0)), s1 = int(floor(e1));
+                if (s0 + s1 < it.num) {
+                    double prob = e0 - s0;
+                    if (sample < prob) { s0++; sample /= prob; }
+                    else { s1++; sample = (sample - prob) / (1 - prob); }
+                }
+                if (s0 > 0 && sp < kEdgeStack) stack[sp++] = HItem{c0, s0, it.pmf * p0};
+                if (s1 > 0 && sp < kEdgeStack) stack[sp++] = HItem{c1, s1, it.pmf * p1};
+            }
+        }
+    }
+    if (edge_w <= 0 || wsum <= 0) return -1;
+    double pmf_h = edge_w * kHSamples / wsum;
+    weight = 1 / pmf_h;
+    return selected;
+}
+
+// NEE-billboard pick: gather every edge whose billboard the NEE ray crosses, keep one.
+RDR_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c, const Ray &nee, bool nee_valid,
+                         const Surf &nee_pt, int nee_shape, double resample, double &weight, V3 &edge_pt, V3 &mwt) {
+    int stack[kEdgeStack];
+    int sp = 0;
+    int selected = -1;
+    double edge_w = 0, wsum = 0;
+    if (es.cs_nodes) stack[sp++] = 0;
+    if (es.ncs_nodes) stack[sp++] = kEdgeTreeBit;
+    while (sp > 0) {
+        int ref = stack[--sp];
+        const EdgeNode &nd = edge_node(es, ref);
+        if (nd.edge_id != -1) {
+            double w = leaf_importance_l(sc, es, ref, c, nee, nee_valid);
+            if (w > 0) {
+                double prev = wsum;
+                wsum += w;
+                double nw = w / wsum;
+                if (resample <= nw || prev == 0) { selected = nd.edge_id; edge_w = w; resample /= nw; }
+                else resample = (resample - nw) / (1 - nw);
+            }
+        } else {
+            int tree = ref & kEdgeTreeBit;
+            int ch[2] = {nd.child0 | tree, nd.child1 | tree};
+            for (int k = 0; k < 2; ++k) {
+                const EdgeNode &cn = edge_node(es, ch[k]);
+                bool ok = may_hold_silhouette(es, ch[k], c.pos);
+                if (ok && nee_valid) ok = may_hold_silhouette(es, ch[k], nee_pt.position);
+                if (ok) ok = ray_box_expand(cn.p_min, cn.p_max, nee, es.edge_bounds_expand);
+                if (ok && sp < kEdgeStack) stack[sp++] = ch[k];
+            }
+        }
+    }
+    if (selected == -1) return -1;
+    double pmf = edge_w / wsum;
+    const EdgeD &e = es.edges[selected];
+    V3 a = edge_v0(sc.shapes, e), b = edge_v1(sc.shapes, e);
+    V3 pn = nee.dir;
+    double t = -(dot(nee.org, pn) - dot(a, pn)) / dot(nee.dir, pn);
+    if (t < nee.tmin || t > nee.tmax) return -1;
+    V3 ip = nee.org + nee.dir * t;
+    double jac = 0, pdf_nee = 0;
+    if (nee_valid) {
+        V3 ln = nee_pt.geom_normal, lpos = nee_pt.position;
+        double tau = dot(lpos - nee.org, ln) / dot(ip - nee.org, ln);
+        V3 omega = ip - nee.org;
+        jac = len(tau * ((b - a) - omega * (dot(b - a, ln) / dot(omega, ln))));
+        const ShapeD &lsh = sc.shapes[nee_shape];
+        pdf_nee = sc.light_pmf[lsh.light_id] / sc.light_areas[lsh.light_id];
+    }
+    if (pmf <= 0 || jac <= 0 || pdf_nee <= 0) return -1;
+    weight = 1 / (2 * es.edge_bounds_expand * pmf * jac * pdf_nee);
+    V3 ap = a - ip;
+    V3 ab = normalize(b - a);
+    edge_pt = ip + ap - (dot(ap, ab)) * ab - nee.org;
+    mwt = b - a;
+    return selected;
+}
+
+RDR_FN M3 ltc_matrix(const float *tab, const Surf &sp, V3 wi, double roughness) {
+    double ct = dot(wi, sp.frame.n);
+    double theta = acos(ct);
+    int rid = iclamp(int(roughness * (128 - 1)), 0, 128 - 1);
+    int tid = iclamp(int((theta / (M_PI / 2.f)) * (128 - 1)), 0, 128 - 1);
+    const float *p = tab + 9 * (rid + tid * 128);
+    M3 r;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i][j] = p[3 * i + j];
+    return r;
+}
+
+struct SampleSecondaryEdges {
+    SceneD sc; EdgeSceneD es;
+    SobolD rng_main; int dim_main;      // the forward sampler's light draw of this vertex
+    SobolD rng_edge; int dim_edge;      // edge sampler: 4 numbers per compacted slot
+    const int *active; VSlice v;        // main-path vertex
+    const float *d_image; int nd, radiance_dim;
+    SecondaryEdgeRec *recs; VSlice ev; double *edge_tmin;
+    RDR_FN void operator()(int idx) const {
+        int p = active[idx];
+        int l0 = 2 * idx, l1 = 2 * idx + 1;
+        VertexCtx c = load_vertex(sc, v, p);
+        SecondaryEdgeRec rec;
+        rec.edge = EdgeD{-1, 0, 0, 0, 0};
+        rec.edge_pt = rec.mwt = v3(0); rec.sp_pos = c.sp.position;
+        rec.use_nee_ray = 0; rec.diffuse_or_glossy = 0;
+        recs[idx] = rec;
+        for (int l = l0; l <= l1; ++l) {
+            st3(ev.thr, ev.n, l, 0, v3(0));
+            store_ray(ev, l, v3(0), v3(0));
+            ev.shape[l] = -1; ev.tri[l] = -1;
+            ev.mrough[l] = c.mrough;
+            edge_tmin[l] = 1e-3f;
+            store_rdiff(ev, l, raydiff_zero());
+        }
+        if (c.mrough > 1e-2f) return;
+
+        // NEE segment of this vertex (recomputed from the forward sampler's numbers)
+        LightDraw ld = draw_light(rng_main, p, dim_main);
+        LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
+        bool nee_valid = pk.shape_id >= 0;
+        Surf nee_pt = surf_zero();
+        Ray nee = make_ray(c.sp.position, v3(0));
+        if (nee_valid) {
+            nee_pt = sample_tri(sc.shapes[pk.shape_id], pk.tri_id, ld.uv);
+            nee = shadow_ray_to(c.sp.position, nee_pt.position);
+            nee.tmax = len(nee_pt.position - nee.org);
+        }
+        double edge_sel = rng_edge.draw(idx, dim_edge), resample_sel = rng_edge.draw(idx, dim_edge + 1);
+        double bsdf_comp = rng_edge.draw(idx, dim_edge + 2), t_sel = rng_edge.draw(idx, dim_edge + 3);
+
+        const MaterialD &mat = *c.mat;
+        V3 kd = tex3(mat.diffuse, c.sp), ks = tex3(mat.specular, c.sp);
+        double wd = luminance(kd), ws = luminance(ks), wsum = wd + ws;
+        if (wsum <= 0.f) return;
+        double pd = wd / wsum, ps = ws / wsum;
+        double m_pmf;
+        V3 n = c.sp.frame.n;
+        V3 wi = c.wi;
+        if (mat.two_sided && dot(wi, n) < 0.f) n = -n;
+        V3 fx = normalize(wi - n * dot(wi, n));
+        V3 fy = cross(n, fx);
+        if (dot(wi, n) > 1 - 1e-6f) onb(n, fx, fy);
+        Frame iso{fx, fy, n};
+        LtcCtx lc;
+        lc.pos = c.sp.position;
+        double roughness = dmax(tex1(mat.roughness, c.sp), c.mrough);
+        if (bsdf_comp <= pd) {
+            lc.m_inv = m3_from_frame(iso);
+            lc.m = m3_inverse(lc.m_inv);
+            m_pmf = pd;
+        } else {
+            lc.m_inv = m3_mul(m3_inverse(ltc_matrix(es.ltc, c.sp, wi, roughness)), m3_from_frame(iso));
+            lc.m = m3_inverse(lc.m_inv);
+            m_pmf = ps;
+        }
+        int eid = -1;
+        double ew = 0;
+        V3 sample_p = v3(0), mwt = v3(0);
+        bool use_nee = false;
+        double nee_pmf = 1;
+        bool dg = bsdf_comp <= pd || roughness > 0.1;
+        if (dg) {
+            use_nee = edge_sel < 0.5;
+            if (roughness > 0.1) nee_pmf = 0.5f;
+            else nee_pmf = use_nee ? pd * 0.5f : 1.f - pd * 0.5f;
+        }
+        if (!use_nee) {
+            if (dg) edge_sel = (edge_sel - 0.5) * 2;
+            eid = pick_edge_hierarchical(sc, es, lc, edge_sel, resample_sel, ew);
+            if (eid == -1 || ew <= 0) return;
+            const EdgeD &e = es.edges[eid];
+            if (!edge_is_silhouette(sc.shapes, lc.pos, e)) return;
+            V3 a = edge_v0(sc.shapes, e), b = edge_v1(sc.shapes, e);
+            V3 ao = m3_apply(lc.m_inv, a - lc.pos), bo = m3_apply(lc.m_inv, b - lc.pos);
+            if (ao.z <= 0.f && bo.z <= 0.f) return;
+            LineSetup s = line_setup(ao, bo);
+            double Il0 = line_I(s, s.l0), Il1 = line_I(s, s.l1);
+            double norm = Il1 - Il0;
+            double lb = s.l0, ub = s.l1;
+            if (lb > ub) { double tt = lb; lb = ub; ub = tt; }
+            double l = 0.5f * (lb + ub);
+            for (int it = 0; it < 20; ++it) {
+                if (!(l >= lb && l <= ub)) l = 0.5f * (lb + ub);
+                double value = (line_I(s, l) - Il0) / norm - t_sel;
+                if (fabs(value) < 1e-5f || it == 19) break;
+                if (value > 0.f) ub = l; else lb = l;
+                double dsq = s.d * s.d + l * l;
+                double deriv = 2.f * s.d * (s.vo + l * s.wt).z / (norm * dsq * dsq);
+                l -= value / deriv;
+            }
+            double dsq = s.d * s.d + l * l;
+            double lpdf = 2.f * s.d * (s.vo + l * s.wt).z / (norm * dsq * dsq);
+            if (lpdf <= 0.f) return;
+            sample_p = m3_apply(lc.m, s.vo + l * s.wt);
+            ew /= (m_pmf * lpdf);
+            mwt = m3_apply(lc.m, s.wt);
+        } else {
+            eid = pick_edge_nee(sc, es, lc, nee, nee_valid, nee_pt, pk.shape_id, resample_sel, ew, sample_p, mwt);
+            if (eid == -1 || ew <= 0) return;
+        }
+        const EdgeD &e = es.edges[eid];
+        V3 a = edge_v0(sc.shapes, e), b = edge_v1(sc.shapes, e);
+        V3 hn = normalize(cross(a - lc.pos, b - lc.pos));
+        double off = 1e-5f / len(sample_p);
+        V3 sdir = normalize(sample_p);
+        V3 up = normalize(sdir + off * hn), lo = normalize(sdir - off * hn);
+        V3 f = bsdf_eval(mat, c.sp, wi, sdir, c.mrough);
+        if (sum(f) < 1e-6f) return;
+        V3 dc = image_grad(d_image, nd, radiance_dim, p);
+        rec.edge = e; rec.edge_pt = sample_p; rec.mwt = mwt;
+        rec.use_nee_ray = use_nee ? 1 : 0; rec.diffuse_or_glossy = dg ? 1 : 0;
+        recs[idx] = rec;
+        store_ray(ev, l0, lc.pos, up);
+        store_ray(ev, l1, lc.pos, lo);
+        edge_tmin[l0] = edge_tmin[l1] = 1e-3f * len(sample_p);
+        RayDiff brd;
+        brd.org_dx = c.rd_surf.org_dx; brd.org_dy = c.rd_surf.org_dy;
+        if (bsdf_comp <= pd) {
+            brd.dir_dx = V3{0.03f, 0.03f, 0.03f};
+            brd.dir_dy = V3{0.03f, 0.03f, 0.03f};
+        } else {
+            V3 h = normalize(wi + sdir);
+            double hz = dot(h, c.sp.frame.n);
+            V3 dmdx = c.sp.dn_dx * hz, dmdy = c.sp.dn_dy * hz;
+            V3 ddx = c.rd_surf.dir_dx, ddy = c.rd_surf.dir_dy;
+            V3 ddn_dx = ddx * h - wi * dmdx, ddn_dy = ddy * h - wi * dmdy;   // per-component, as in the reference
+            brd.dir_dx = ddx - 2 * (-dot(wi, h) * c.sp.dn_dx + ddn_dx * h);
+            brd.dir_dy = ddy - 2 * (-dot(wi, h) * c.sp.dn_dy + ddn_dy * h);
+        }
+        store_rdiff(ev, l0, brd); store_rdiff(ev, l1, brd);
+        V3 nt = ld3(v.thr, v.n, p, 0) * f * dc * ew / nee_pmf;
+        st3(ev.thr, ev.n, l0, 0, nt);
+        st3(ev.thr, ev.n, l1, 0, -nt);
+    }
+};
+
+// Jacobian of the ray/plane intersection w.r.t. the line parameter (src/edge.cpp:1828-1853).
+RDR_FN V3 isect_jacobian(V3 org, V3 dir, V3 p, V3 n, V3 l) {
+    double dn = dot(dir, n);
+    if (fabs(dn) < 1e-10f) return v3(0);
+    double d = -dot(p, n);
+    double t = -(dot(org, n) + d) / dn;
+    if (t <= 0) return v3(0);
+    return t * (l - dir * (dot(l, n) / dot(dir, n)));
+}
+
+struct SecondaryEdgeWeights {
+    SceneD sc; const SecondaryEdgeRec *recs; VSlice ev; double *hit_pos;   // hit_pos: 3 x n, stride ev.n
+    RDR_FN void scale_lane(const SecondaryEdgeRec &rec, int l) const {
+        if (ev.shape[l] < 0) return;
+        RayDiff tmp;
+        Surf hp = surf_at(sc.shapes[ev.shape[l]], ev.tri[l], load_ray(ev, l), load_rdiff(ev, l), tmp);
+        st3(hit_pos, ev.n, l, 0, hp.position);
+        V3 dir = hp.position - rec.sp_pos;
+        double d2 = len_sq(dir);
+        if (d2 < 1e-8f) { st3(ev.thr, ev.n, l, 0, v3(0)); return; }
+        V3 nd = dir / sqrt(d2);
+        double geo = fabs(dot(hp.geom_normal, nd)) / d2;
+        V3 jac = isect_jacobian(rec.sp_pos, rec.edge_pt, hp.position, hp.geom_normal, rec.mwt);
+        V3 a = edge_v0(sc.shapes, rec.edge), b = edge_v1(sc.shapes, rec.edge);
+        V3 hn = normalize(cross(a - rec.sp_pos, b - rec.sp_pos));
+        double line_j = len(jac) / len(cross(hp.geom_normal, hn));
+        double dirac_j = len(cross(a - rec.sp_pos, b - rec.sp_pos));
+        double w = line_j / dirac_j;
+        st3(ev.thr, ev.n, l, 0, ld3(ev.thr, ev.n, l, 0) * (geo * w));
+    }
+    RDR_FN void operator()(int idx) const {
+        const SecondaryEdgeRec &rec = recs[idx];
+        if (rec.edge.shape_id < 0) return;
+        int l0 = 2 * idx, l1 = 2 * idx + 1;
+        int light0 = ev.shape[l0] >= 0 ? sc.shapes[ev.shape[l0]].light_id : -1;
+        int light1 = ev.shape[l1] >= 0 ? sc.shapes[ev.shape[l1]].light_id : -1;
+        bool hit_light = light0 != -1 || light1 != -1;
+        if (rec.use_nee_ray) {
+            if (hit_light) {
+                st3(ev.thr, ev.n, l0, 0, ld3(ev.thr, ev.n, l0, 0) * 0.5f);
+                st3(ev.thr, ev.n, l1, 0, ld3(ev.thr, ev.n, l1, 0) * 0.5f);
+            } else {
+                st3(ev.thr, ev.n, l0, 0, v3(0));
+                st3(ev.thr, ev.n, l1, 0, v3(0));
+            }
+        } else if (hit_light && rec.diffuse_or_glossy) {
+            st3(ev.thr, ev.n, l0, 0, ld3(ev.thr, ev.n, l0, 0) * 0.5f);
+            st3(ev.thr, ev.n, l1, 0, ld3(ev.thr, ev.n, l1, 0) * 0.5f);
+        }
+        scale_lane(rec, l0);
+        scale_lane(rec, l1);
+    }
+};
+
+struct SecondaryEdgeDerivatives {
+    SceneD sc; GScene g; const int *active; const SecondaryEdgeRec *recs;
+    const double *hit_pos; int n_lanes; const double *edge_contrib; AdjState adj;
+    RDR_FN void operator()(int idx) const {
+        const SecondaryEdgeRec &rec = recs[idx];
+        if (rec.edge.shape_id < 0) return;
+        int p = active[idx];
+        V3 a = edge_v0(sc.shapes, rec.edge), b = edge_v1(sc.shapes, rec.edge);
+        V3 dp = v3(0), da = v3(0), db = v3(0);
+        for (int k = 0; k < 2; ++k) {
+            double contrib = edge_contrib[2 * idx + k];
+            if (contrib == 0) continue;
+            V3 x = ld3(hit_pos, n_lanes, 2 * idx + k, 0);
+            V3 pos = rec.sp_pos;
+            V3 d0 = a - pos, d1 = b - pos;
+            dp += (cross(d1, d0) + cross(x - pos, d1) + cross(d0, x - pos)) * contrib;   // Eq. 16 (errata)
+            da += cross(d1, x - pos) * contrib;
+            db += cross(x - pos, d0) * contrib;
+        }
+        // position adjoint of the shading point (slots 0..2 of the adjoint point record)
+        adj.point[(size_t)0 * adj.n + p] += dp.x;
+        adj.point[(size_t)1 * adj.n + p] += dp.y;
+        adj.point[(size_t)2 * adj.n + p] += dp.z;
+        double *gv = g.shapes[rec.edge.shape_id].vertices;
+        accum3(gv + 3 * rec.edge.v0, da);
+        accum3(gv + 3 * rec.edge.v1, db);
+    }
+};
+
+} // namespace rdr

@@ -29,7 +29,9 @@ RDR_FN V2 operator-(V2 a) { return V2{-a.x, -a.y}; }
 RDR_FN V2 operator*(V2 a, double s) { return V2{a.x * s, a.y * s}; }
 RDR_FN V2 operator*(double s, V2 a) { return V2{s * a.x, s * a.y}; }
 RDR_FN V2 operator*(V2 a, V2 b) { return V2{a.x * b.x, a.y * b.y}; }
-RDR_FN V2 operator/(V2 a, double s) { return V2{a.x / s, a.y / s}; }
+// vector / scalar multiplies by the reciprocal, like the reference (src/vector.h:287-299): the
+// 1-ulp difference from a true division decides ties in the edge-hierarchy build.
+RDR_FN V2 operator/(V2 a, double s) { double inv = 1.f / s; return V2{a.x * inv, a.y * inv}; }
 RDR_FN V2 &operator+=(V2 &a, V2 b) { a.x += b.x; a.y += b.y; return a; }
 RDR_FN V2 &operator-=(V2 &a, V2 b) { a.x -= b.x; a.y -= b.y; return a; }
 RDR_FN double dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
@@ -44,7 +46,7 @@ RDR_FN V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 RDR_FN V3 operator*(V3 a, double s) { return V3{a.x * s, a.y * s, a.z * s}; }
 RDR_FN V3 operator*(double s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
 RDR_FN V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
-RDR_FN V3 operator/(V3 a, double s) { return V3{a.x / s, a.y / s, a.z / s}; }
+RDR_FN V3 operator/(V3 a, double s) { double inv = 1.f / s; return V3{a.x * inv, a.y * inv, a.z * inv}; }
 RDR_FN V3 operator/(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
 RDR_FN V3 operator+(V3 a, double s) { return V3{a.x + s, a.y + s, a.z + s}; }
 RDR_FN V3 operator-(V3 a, double s) { return V3{a.x - s, a.y - s, a.z - s}; }

@@ -61,3 +61,4 @@ inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits,
 }
 } // namespace exec
 namespace exec { inline void trace_stats_collect() {} }
+namespace rdr { inline void accum_f32(float *p, float v) { *p += v; } }
