@@ -85,6 +85,12 @@ def render_case(backend, builder, res, spp, mb, device=torch.device('cpu'), grad
     import scenes
     from redner_amd.render_pytorch import RenderFunction
     sc = getattr(scenes, builder)(device, resolution=(res, res))
+    for l in sc.area_lights:
+        l.intensity.requires_grad_(True)
+    for m in sc.materials:
+        m.diffuse_reflectance.mipmap[0].requires_grad_(True)
+    if sc.camera.position is not None:
+        sc.camera.position.requires_grad_(True)
     args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=backend.SamplerType.sobol, device=device,
                                           backend=backend)
     img = RenderFunction.apply(1, *args)
@@ -98,6 +104,12 @@ def render_case(backend, builder, res, spp, mb, device=torch.device('cpu'), grad
     for i, sh in enumerate(sc.shapes):
         if sh.vertices.grad is not None:
             out['grad_shape%d_vertices' % i] = sh.vertices.grad.cpu().numpy()
+    for i, l in enumerate(sc.area_lights):
+        out['grad_light%d_intensity' % i] = l.intensity.grad.cpu().numpy()
+    for i, m in enumerate(sc.materials):
+        out['grad_mat%d_diffuse' % i] = m.diffuse_reflectance.mipmap[0].grad.cpu().numpy()
+    if sc.camera.position is not None:
+        out['grad_cam_position'] = sc.camera.position.grad.cpu().numpy()
     return out
 
 
