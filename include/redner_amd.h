@@ -185,7 +185,9 @@ typedef struct rdr_trace_stats {
     double closest_ms, any_ms;           /* accumulated device time of the two traversal kernels */
     uint64_t closest_launches, any_launches;
     uint64_t closest_rays, any_rays;
-    uint64_t nodes_visited, tris_tested; /* only counted when counting is enabled */
+    /* 32-byte node records loaded / 36-byte triangle records tested, per query kind; only
+     * counted when counting is enabled (instrumented kernel variant) */
+    uint64_t closest_nodes, closest_tris, any_nodes, any_tris;
 } rdr_trace_stats;
 void rdr_trace_stats_enable(int timing, int counting);
 void rdr_trace_stats_reset(void);

@@ -102,7 +102,8 @@ class TraceStats(C.Structure):
     _fields_ = [('closest_ms', C.c_double), ('any_ms', C.c_double),
                 ('closest_launches', C.c_uint64), ('any_launches', C.c_uint64),
                 ('closest_rays', C.c_uint64), ('any_rays', C.c_uint64),
-                ('nodes_visited', C.c_uint64), ('tris_tested', C.c_uint64)]
+                ('closest_nodes', C.c_uint64), ('closest_tris', C.c_uint64),
+                ('any_nodes', C.c_uint64), ('any_tris', C.c_uint64)]
 
 
 EXPORTS = ('rdr_scene_create', 'rdr_scene_destroy', 'rdr_scene_max_generic_texture_dimension',

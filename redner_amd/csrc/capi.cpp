@@ -76,7 +76,8 @@ void rdr_trace_stats_get(rdr_trace_stats *out) {
     out->closest_ms = s.closest_ms; out->any_ms = s.any_ms;
     out->closest_launches = s.closest_launches; out->any_launches = s.any_launches;
     out->closest_rays = s.closest_rays; out->any_rays = s.any_rays;
-    out->nodes_visited = s.nodes; out->tris_tested = s.tris;
+    out->closest_nodes = s.nodes[0]; out->closest_tris = s.tris[0];
+    out->any_nodes = s.nodes[1]; out->any_tris = s.tris[1];
 }
 
 int rdr_debug_dump_edges(const rdr_scene *scene, const char *path) {

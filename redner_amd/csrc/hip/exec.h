@@ -20,7 +20,40 @@
 #define RDR_FN __host__ __device__ inline
 
 namespace rdr {
-__device__ inline void accum(double *p, double v) { unsafeAtomicAdd(p, v); }
+// Gradient scatter.  Many lanes of a wave usually add to the SAME address (all pixels of a wall
+// hit the same 4 vertices / the same constant albedo; every pixel adds to the camera), which would
+// serialise 64 fp64 atomics on one L2 line.  So: if every active lane of the wave targets one
+// address, the wave sums its values first (xor-butterfly when all 64 lanes are active, otherwise a
+// scalar loop over the active lanes in lane order) and issues ONE atomic; mixed addresses fall
+// back to one hardware fp64 atomic per lane.
+static __device__ unsigned long long g_replica_stride = 0;   // doubles between replicas (0 = none)
+static __device__ unsigned g_replica_mask = 0;               // replicas - 1 (power of two)
+
+__device__ inline void accum(double *p, double v) {
+    p += (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & g_replica_mask) * g_replica_stride;
+    const unsigned long long act = __ballot(1);
+    const unsigned long long addr = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
+    const bool same = addr == (((unsigned long long)hi << 32) | lo);
+    if (__ballot(same) != act || __popcll(act) == 1) { unsafeAtomicAdd(p, v); return; }
+    double s;
+    if (act == ~0ull) {
+        s = v;
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    } else {
+        s = 0;
+        const int vlo = __double2loint(v), vhi = __double2hiint(v);
+        unsigned long long m = act;
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            s += __hiloint2double(__builtin_amdgcn_readlane(vhi, l), __builtin_amdgcn_readlane(vlo, l));
+        }
+    }
+    const int first = __ffsll((long long)act) - 1;
+    if ((int)(threadIdx.x & 63) == first) unsafeAtomicAdd(p, s);
+}
 __host__ inline void accum(double *p, double v) { *p += v; }   // host instantiation is never executed
 }
 
@@ -51,6 +84,21 @@ inline void download(void *dst, const void *src, size_t bytes) {
     check(hipStreamSynchronize(ctx().stream), "download sync");
 }
 inline void sync() { check(hipStreamSynchronize(ctx().stream), "sync"); }
+
+// Replicated gradient accumulators (see GradStore in render.cpp): up to 256 replicas, as many as
+// fit in 256 MiB.  Must be called from the translation unit that instantiates the stage kernels.
+inline int choose_replicas(size_t replica_bytes) {
+    int r = 256;
+    while (r > 1 && replica_bytes * (size_t)r > ((size_t)256 << 20)) r >>= 1;
+    return r;
+}
+inline void set_replicas(size_t stride_doubles, int replicas) {
+    unsigned long long st = stride_doubles;
+    unsigned mask = (unsigned)(replicas - 1);
+    check(hipMemcpyToSymbolAsync(HIP_SYMBOL(rdr::g_replica_stride), &st, sizeof(st), 0, hipMemcpyHostToDevice, ctx().stream), "set_replicas");
+    check(hipMemcpyToSymbolAsync(HIP_SYMBOL(rdr::g_replica_mask), &mask, sizeof(mask), 0, hipMemcpyHostToDevice, ctx().stream), "set_replicas");
+    check(hipStreamSynchronize(ctx().stream), "set_replicas sync");
+}
 
 template <class F>
 __global__ void __launch_bounds__(256) stage_kernel(F f, int n) {
@@ -172,7 +220,7 @@ inline int compact(const int *in, int n, int *out, const P &pred) {
 // ---- traversal kernels (trace.hip) --------------------------------------------------------------
 struct TraceStats {
     double closest_ms = 0, any_ms = 0;
-    uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes = 0, tris = 0;
+    uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes[2] = {0, 0}, tris[2] = {0, 0};
     bool timing = false, counting = false;
 };
 TraceStats &trace_stats();

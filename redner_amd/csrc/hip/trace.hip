@@ -91,9 +91,9 @@ void trace_stats_collect() {
         g_pending.clear();
     }
     if (g_counters) {
-        unsigned long long c[2] = {0, 0};
+        unsigned long long c[4] = {0, 0, 0, 0};
         download(c, g_counters, sizeof(c));
-        st.nodes += c[0]; st.tris += c[1];
+        st.nodes[0] += c[0]; st.tris[0] += c[1]; st.nodes[1] += c[2]; st.tris[1] += c[3];
         zero(g_counters, sizeof(c));
         sync();
     }
@@ -110,8 +110,8 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n,
         check(hipEventRecord(p.a, s), "hipEventRecord");
     }
     if (st.counting) {
-        if (!g_counters) { g_counters = (unsigned long long *)dmalloc(16); zero(g_counters, 16); }
-        if (any) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, g_counters);
+        if (!g_counters) { g_counters = (unsigned long long *)dmalloc(32); zero(g_counters, 32); }
+        if (any) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, g_counters + 2);
         else hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, g_counters);
     } else {
         if (any) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, (unsigned long long *)nullptr);

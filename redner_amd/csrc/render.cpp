@@ -86,12 +86,27 @@ struct GradStore {
     std::vector<GShape> h_shapes;
     std::vector<GMaterial> h_materials;
 
+    // All accumulators live in ONE block of `stride` doubles that is replicated `replicas` times
+    // (replica r at base + r * stride); rdr::accum() picks the replica from the wave id, which
+    // spreads the atomics on hot addresses (camera, lights, constant albedos, wall corners) over
+    // many cache lines / memory channels.  flush() sums the replicas in fixed order.
+    double *block = nullptr;
+    size_t stride = 0, cursor = 0;
+    int replicas = 1;
+    bool counting = true;
+
     double *mirror(float *out, size_t count) {
         if (!out || count == 0) return nullptr;
-        double *acc = arena.get<double>(count);
-        exec::zero(acc, sizeof(double) * count);
-        pairs.push_back(Pair{acc, out, count});
-        return acc;
+        size_t at = cursor;
+        cursor += (count + 3) & ~(size_t)3;
+        if (counting) return reinterpret_cast<double *>(8);       // placeholder, replaced in pass 2
+        pairs.push_back(Pair{block + at, out, count});
+        return block + at;
+    }
+    double *reserve(size_t count) {
+        size_t at = cursor;
+        cursor += (count + 3) & ~(size_t)3;
+        return counting ? reinterpret_cast<double *>(8) : block + at;
     }
     GTex mirror_tex(const TexD &t, const rdr_dtexture_desc &d) {
         GTex g;
@@ -108,6 +123,17 @@ struct GradStore {
     }
 
     GradStore(const Scene &scene, const rdr_dscene_desc &ds) {
+        counting = true; cursor = 0;
+        layout(scene, ds);                                   // pass 1: size of one replica
+        stride = (cursor + 31) & ~(size_t)31;
+        replicas = exec::choose_replicas(stride * sizeof(double));
+        block = arena.get<double>(stride * replicas);
+        exec::zero(block, sizeof(double) * stride * replicas);
+        exec::set_replicas(stride, replicas);
+        counting = false; cursor = 0; pairs.clear();
+        layout(scene, ds);                                   // pass 2: real pointers
+    }
+    void layout(const Scene &scene, const rdr_dscene_desc &ds) {
         if (ds.num_shapes != (int)scene.shapes.size() || ds.num_materials != (int)scene.materials.size() ||
             ds.num_area_lights != (int)scene.lights.size())
             throw std::runtime_error("render: DScene does not match the Scene (shape/material/light counts)");
@@ -131,17 +157,19 @@ struct GradStore {
             h_materials[i].generic = mirror_tex(m.generic, d.generic_texture);
             h_materials[i].normal_map = mirror_tex(m.normal_map, d.normal_map);
         }
-        g.shapes = arena.get<GShape>(h_shapes.size());
-        exec::upload(g.shapes, h_shapes.data(), sizeof(GShape) * h_shapes.size());
-        g.materials = arena.get<GMaterial>(h_materials.size());
-        exec::upload(g.materials, h_materials.data(), sizeof(GMaterial) * h_materials.size());
+        if (!counting) {
+            g.shapes = arena.get<GShape>(h_shapes.size());
+            exec::upload(g.shapes, h_shapes.data(), sizeof(GShape) * h_shapes.size());
+            g.materials = arena.get<GMaterial>(h_materials.size());
+            exec::upload(g.materials, h_materials.data(), sizeof(GMaterial) * h_materials.size());
+        }
         // light intensities: one contiguous fp64 block, scattered back per light
         g.light_intensity = nullptr;
         if (!scene.lights.empty()) {
-            g.light_intensity = arena.get<double>(3 * scene.lights.size());
-            exec::zero(g.light_intensity, sizeof(double) * 3 * scene.lights.size());
-            for (size_t l = 0; l < scene.lights.size(); ++l)
-                if (ds.area_lights[l].intensity) pairs.push_back(Pair{g.light_intensity + 3 * l, ds.area_lights[l].intensity, 3});
+            g.light_intensity = reserve(3 * scene.lights.size());
+            if (!counting)
+                for (size_t l = 0; l < scene.lights.size(); ++l)
+                    if (ds.area_lights[l].intensity) pairs.push_back(Pair{g.light_intensity + 3 * l, ds.area_lights[l].intensity, 3});
         }
         const rdr_dcamera_desc &dc = ds.camera;
         g.cam.position = mirror(dc.position, 3); g.cam.look = mirror(dc.look, 3); g.cam.up = mirror(dc.up, 3);
@@ -150,7 +178,8 @@ struct GradStore {
         g.envmap = nullptr;
     }
     void flush() {
-        for (const Pair &p : pairs) exec::launch((int)p.count, FlushGrad{p.acc, p.out});
+        for (const Pair &p : pairs) exec::launch((int)p.count, FlushGrad{p.acc, p.out, stride, replicas});
+        exec::set_replicas(0, 1);
     }
 };
 

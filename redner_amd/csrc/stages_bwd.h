@@ -244,8 +244,12 @@ struct AdjPrimary {
 
 // fp64 accumulator -> caller's fp32 gradient tensor (+=)
 struct FlushGrad {
-    const double *acc; float *out;
-    RDR_FN void operator()(int i) const { out[i] += (float)acc[i]; }
+    const double *acc; float *out; size_t stride; int replicas;
+    RDR_FN void operator()(int i) const {
+        double s = 0;
+        for (int r = 0; r < replicas; ++r) s += acc[(size_t)r * stride + i];
+        out[i] += (float)s;
+    }
 };
 
 } // namespace rdr

@@ -241,8 +241,8 @@ class RenderFunction(torch.autograd.Function):
         u.options = rd.RenderOptions(seed[0], meta['num_samples'][0], meta['max_bounces'], meta['channels'],
                                      meta['sampler_type'], meta['sample_pixel_center'])
         if 'sample_offset' in meta:             # multi-GPU sample sharding (redner_amd extension)
-            u.options.sample_offset = meta['sample_offset']
-            u.options.total_samples = meta['total_samples']
+            u.options.sample_offset = meta['sample_offset'][0]
+            u.options.total_samples = meta['total_samples'][0]
         return u
 
     @staticmethod
@@ -308,6 +308,9 @@ class RenderFunction(torch.autograd.Function):
         d_scene = rd.DScene(d_camera, d_shapes, d_materials, d_lights, None, device.type == 'cuda', index)
         u.options.seed = ctx.seed[1]
         u.options.num_samples = meta['num_samples'][1]
+        if 'sample_offset' in meta:
+            u.options.sample_offset = meta['sample_offset'][1]
+            u.options.total_samples = meta['total_samples'][1]
         rd.render(u.scene, u.options, rd.float_ptr(0), rd.float_ptr(grad_img.data_ptr()), d_scene,
                   rd.float_ptr(0), rd.float_ptr(0))
         out = []

@@ -40,7 +40,7 @@ inline int compact(const int *in, int n, int *out, const P &pred) {
     for (int i = 0; i < n; ++i) { int p = in ? in[i] : i; if (pred(p)) out[c++] = p; }
     return c;
 }
-struct TraceStats { double closest_ms = 0, any_ms = 0; uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes = 0, tris = 0; bool timing = false, counting = false; };
+struct TraceStats { double closest_ms = 0, any_ms = 0; uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes[2] = {0, 0}, tris[2] = {0, 0}; bool timing = false, counting = false; };
 inline TraceStats &trace_stats() { static TraceStats s; return s; }
 inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n, bool any) {
     TraceStats &st = trace_stats();
@@ -57,8 +57,12 @@ inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits,
     }
     (any ? st.any_launches : st.closest_launches)++;
     (any ? st.any_rays : st.closest_rays) += n;
-    st.nodes += cnt.nodes; st.tris += cnt.tris;
+    st.nodes[any ? 1 : 0] += cnt.nodes; st.tris[any ? 1 : 0] += cnt.tris;
 }
 } // namespace exec
-namespace exec { inline void trace_stats_collect() {} }
+namespace exec {
+inline void trace_stats_collect() {}
+inline int choose_replicas(size_t) { return 1; }
+inline void set_replicas(size_t, int) {}
+}
 namespace rdr { inline void accum_f32(float *p, float v) { *p += v; } }
