@@ -8,14 +8,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _cached = None
 
 
+def _oracle_lib():
+    return [p for p in glob.glob(os.path.join(ROOT, 'oracle', '_ref', 'redner*.so')) if 'redner_dbg' not in p]
+
+
 def oracle_available():
-    return len(glob.glob(os.path.join(ROOT, 'oracle', '_ref', 'redner*.so'))) > 0
+    return len(_oracle_lib()) > 0
 
 
 def load_oracle():
     global _cached
     if _cached is None:
-        path = glob.glob(os.path.join(ROOT, 'oracle', '_ref', 'redner*.so'))[0]
+        path = _oracle_lib()[0]
         spec = importlib.util.spec_from_file_location('redner', path)
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
