@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <stdexcept>
 
 namespace rt {
 namespace {
@@ -126,6 +127,7 @@ BvhHost build_bvh(const std::vector<MeshView> &meshes) {
     if (bd.prims.empty()) return bd.out;
     bd.out.nodes.push_back(Node{});
     bd.build(0, 0, (int)bd.prims.size(), 0);
+    if (bd.out.depth + 2 > kTraverseStack) throw std::runtime_error("triangle hierarchy deeper than the traversal stack");
     return bd.out;
 }
 

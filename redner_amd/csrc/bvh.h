@@ -39,13 +39,15 @@ static_assert(sizeof(RayRec) == 32 && sizeof(HitRec) == 8, "queue record sizes")
 
 // One ray against the hierarchy.  ANY = stop at the first accepted hit (occlusion query).
 // `cnt` (optional) tallies node records loaded and triangle records tested.
+// `stack` holds kTraverseStack ints spaced `stride` apart (a private array on the host, a column of
+// an LDS tile on the GPU); the builder rejects hierarchies deeper than that.
+constexpr int kTraverseStack = 40;
 template <bool ANY>
 RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], float tnear, float tfar,
-                          Counters *cnt = nullptr) {
+                          int *stack, int stride, Counters *cnt = nullptr) {
     Hit best{tfar, -1, -1};
     if (bvh.num_nodes == 0) return best;
     const float inv[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};
-    int stack[64];
     int sp = 0;
     float tn;
     unsigned long long nn = 1, nt = 0;
@@ -77,7 +79,7 @@ RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], f
             if (hl && hr) {
                 int near = n.a, far = n.a + 1;
                 if (tr < tl) { near = n.a + 1; far = n.a; }
-                stack[sp++] = far;
+                stack[sp * stride] = far; ++sp;
                 cur = near;
                 continue;
             } else if (hl) { cur = n.a; continue; }
@@ -86,7 +88,8 @@ RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], f
         // pop; entries whose box entry lies beyond the current best are re-tested lazily by their
         // children's box tests (lim shrinks), which keeps the stack to one int per entry.
         if (sp == 0) break;
-        cur = stack[--sp];
+        --sp;
+        cur = stack[sp * stride];
     }
     if (cnt) { cnt->nodes += nn; cnt->tris += nt; }
     return best;

@@ -521,6 +521,20 @@ EdgeData *build_edge_data(Scene &scene) {
         ncs.build(ncs_ids);
         ed->cs_nodes.swap(cs.nodes); ed->cs_leaves = cs.n;
         ed->ncs_nodes.swap(ncs.nodes); ed->ncs_leaves = ncs.n;
+        // the NEE-mode traversal keeps one pending sibling per level in a fixed 64-entry stack
+        for (const std::vector<EdgeNode> *tree : {&ed->cs_nodes, &ed->ncs_nodes}) {
+            if (tree->empty()) continue;
+            std::vector<std::pair<int, int>> todo{{0, 1}};
+            int max_depth = 0;
+            while (!todo.empty()) {
+                auto [node, depth] = todo.back();
+                todo.pop_back();
+                max_depth = std::max(max_depth, depth);
+                const EdgeNode &nd = (*tree)[node];
+                if (nd.edge_id == -1 && nd.child0 >= 0) { todo.push_back({nd.child0, depth + 1}); todo.push_back({nd.child1, depth + 1}); }
+            }
+            if (max_depth + 2 > 64) throw std::runtime_error("edge hierarchy deeper than the traversal stack (64)");
+        }
     }
 
     // ---- device view ----

@@ -18,6 +18,12 @@
 #include <string>
 
 #define RDR_FN __host__ __device__ inline
+// Per-lane traversal stacks live in LDS (one column per thread of the 256-thread workgroup, entry k
+// of lane t at [k * 256 + t]: conflict-free), not in scratch: large scratch frames make the HSA
+// runtime re-allocate scratch per dispatch (tens of ms, see profiles/r1_notes.md).
+#define RDR_DEV_FN __device__ inline
+#define RDR_STACK_DECL(T, name, N) __shared__ T name##_lds[(N) * 256]; T *name = name##_lds + threadIdx.x
+#define RDR_STACK_AT(name, k) name[(k) * 256]
 
 namespace rdr {
 // Gradient scatter.  Many lanes of a wave usually add to the SAME address (all pixels of a wall
@@ -196,7 +202,10 @@ __global__ void __launch_bounds__(256) compact_scatter(const int *in, int n, P p
     }
 }
 
-struct CompactScratch { int *block_counts = nullptr; int *total = nullptr; int capacity = 0; };
+// `total` lives in pinned, device-mapped host memory: the scan kernel stores the count straight into
+// it, so reading it back costs one stream synchronisation and no copy launch (a pageable 4-byte
+// hipMemcpy measured ~195 us per call in the rocprofv3 trace, profiles/r1_notes.md).
+struct CompactScratch { int *block_counts = nullptr; int *total = nullptr; volatile int *total_host = nullptr; int capacity = 0; };
 CompactScratch &compact_scratch(int nblocks);
 
 // `out` must not alias `in`: a workgroup may scatter into a tile that an earlier-numbered
@@ -212,9 +221,8 @@ inline int compact(const int *in, int n, int *out, const P &pred) {
     hipLaunchKernelGGL(compact_scan, dim3(1), dim3(256), 0, st, sc.block_counts, nblocks, sc.total);
     hipLaunchKernelGGL(compact_scatter<P>, dim3(nblocks), dim3(256), 0, st, in, n, pred, sc.block_counts, out);
     check(hipGetLastError(), "compact launch");
-    int total = 0;
-    download(&total, sc.total, sizeof(int));
-    return total;
+    check(hipStreamSynchronize(st), "compact sync");
+    return *sc.total_host;
 }
 
 // ---- traversal kernels (trace.hip) --------------------------------------------------------------

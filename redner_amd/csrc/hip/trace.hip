@@ -33,7 +33,13 @@ CompactScratch &compact_scratch(int nblocks) {
     CompactScratch &s = per_device[dev & 15];
     if (s.capacity < nblocks) {
         if (s.block_counts) (void)hipFree(s.block_counts);
-        if (!s.total) s.total = (int *)dmalloc(sizeof(int));
+        if (!s.total) {
+            void *h = nullptr, *d = nullptr;
+            check(hipHostMalloc(&h, 64, hipHostMallocMapped), "hipHostMalloc");
+            check(hipHostGetDevicePointer(&d, h, 0), "hipHostGetDevicePointer");
+            s.total_host = (volatile int *)h;
+            s.total = (int *)d;
+        }
         s.capacity = nblocks + 1024;
         s.block_counts = (int *)dmalloc(sizeof(int) * s.capacity);
     }
@@ -44,6 +50,8 @@ template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays,
                                                     rt::HitRec *__restrict__ hits, int n,
                                                     unsigned long long *counters) {
+    __shared__ int stack_tile[rt::kTraverseStack * 256];     // 40 KiB: per-lane stack columns
+    int *stack = stack_tile + threadIdx.x;
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     rt::RayRec r = rays[i];
@@ -52,11 +60,11 @@ __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayR
         float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
         if (COUNT) {
             rt::Counters c{0, 0};
-            h = rt::traverse<ANY>(bvh, o, d, r.tmin, r.tmax, &c);
+            h = rt::traverse<ANY>(bvh, o, d, r.tmin, r.tmax, stack, 256, &c);
             atomicAdd(&counters[0], c.nodes);
             atomicAdd(&counters[1], c.tris);
         } else {
-            h = rt::traverse<ANY>(bvh, o, d, r.tmin, r.tmax, nullptr);
+            h = rt::traverse<ANY>(bvh, o, d, r.tmin, r.tmax, stack, 256, nullptr);
         }
     }
     hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};

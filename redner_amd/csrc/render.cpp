@@ -211,6 +211,8 @@ struct Backward {
             hit_pos = arena.get<double>((size_t)3 * L);
             prim_recs = arena.get<PrimaryEdgeRec>(P);
             sec_recs = arena.get<SecondaryEdgeRec>(P);
+            sec_picks = arena.get<SecPick>(P);
+            sec_mode = arena.get<unsigned char>(P);
         }
     }
 
@@ -219,6 +221,8 @@ struct Backward {
     double *edge_contrib = nullptr, *edge_tmin = nullptr, *hit_pos = nullptr;
     PrimaryEdgeRec *prim_recs = nullptr;
     SecondaryEdgeRec *sec_recs = nullptr;
+    SecPick *sec_picks = nullptr;
+    unsigned char *sec_mode = nullptr;
 
     // Path-trace the live edge lanes to the end, starting with `n_act` lanes listed in elist[1]
     // whose current vertex is in `ea`.  Returns the number of Sobol' dimensions consumed.
@@ -253,14 +257,20 @@ struct Backward {
             const int nA = num_active[d];
             if (nA <= 0) continue;
             const int *act = active + (size_t)d * P;
-            exec::launch(nA, AdjBounce{scene.d, grads.g, rng, dim0 + 7 * d, act, vs[d], vs[d + 1],
-                                       d_image, nd, radiance_dim, weight, adj});
+            AdjBounceArgs ba{scene.d, grads.g, rng, dim0 + 7 * d, act, vs[d], vs[d + 1], d_image, nd, radiance_dim, weight, adj};
+            exec::launch(nA, AdjBounceScatter{ba});
+            exec::launch(nA, AdjBounceNee{ba});
             if (edges_on && scene.use_secondary_edges) {
                 // ---- secondary (shadow / inter-reflection) edges at this vertex, :500-706 ----
                 const EdgeSceneD &es = scene.edges->d;
                 const int lanes = 2 * nA;
-                exec::launch(nA, SampleSecondaryEdges{scene.d, es, rng, dim0 + 7 * d, rng_edge, edim, act, vs[d],
-                                                      d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});
+                SecEdgeArgs sa{scene.d, es, rng, dim0 + 7 * d, rng_edge, edim, act, vs[d]};
+                exec::launch(nA, SecEdgeSetup{sa, sec_mode, sec_recs, sec_picks, ea, edge_tmin});
+                int nH = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 1});
+                exec::launch(nH, SecEdgePickH{sa, elist[0], sec_picks});
+                int nN = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 2});
+                exec::launch(nN, SecEdgePickN{sa, elist[0], sec_picks});
+                exec::launch(nA, SecEdgeFinish{sa, sec_mode, sec_picks, d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});
                 edim += 4;
                 int n0 = exec::compact((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
                 exec::launch(n0, QueueRays{elist[0], ea, edge_tmin, q.bsdf});

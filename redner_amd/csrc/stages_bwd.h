@@ -53,80 +53,31 @@ RDR_FN V3 image_grad(const float *d_image, int nd, int radiance_dim, int pixel) 
     return V3{(double)g[0], (double)g[1], (double)g[2]};
 }
 
-// ---- adjoint of one bounce ----------------------------------------------------------------------
-struct AdjBounce {
+// ---- adjoint of one bounce -------------------------------------------------------------------------
+// Two stages per vertex so that each fits the register file without scratch:
+//   AdjBounceScatter : the BSDF-sampled continuation.  Consumes the successor's adjoints and
+//                      OVERWRITES the lane's adjoint record with this vertex's (partial) adjoints.
+//   AdjBounceNee     : next-event estimation; ADDS its share to the record.
+// (The reference does both in one functor, src/path_contribution.cpp:156-626; the sums are the same.)
+struct AdjBounceArgs {
     SceneD sc; GScene g; SobolD rng; int dim;
     const int *active; VSlice v, vn;
     const float *d_image; int nd, radiance_dim; double weight;
     AdjState adj;
+};
+
+struct AdjBounceScatter {
+    AdjBounceArgs a;
     RDR_FN void operator()(int idx) const {
-        int p = active[idx];
+        const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v, &vn = a.vn; const AdjState &adj = a.adj;
+        int p = a.active[idx];
         VertexCtx c = load_vertex(sc, v, p);
         const GMaterial &gm = g.materials[c.shape->material_id];
         V3 thr = ld3(v.thr, v.n, p, 0);
-        V3 pc_bar = weight * image_grad(d_image, nd, radiance_dim, p);   // adjoint of path_contrib
+        V3 pc_bar = a.weight * image_grad(a.d_image, a.nd, a.radiance_dim, p);   // adjoint of path_contrib
         V3 thr_bar = v3(0), in_dir_bar = v3(0);
         Surf sp_bar = surf_zero();
         V3 pos = c.sp.position;
-
-        // ---- next-event estimation ----
-        if (!v.occl[p]) {
-            LightDraw ld = draw_light(rng, p, dim);
-            LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
-            if (pk.shape_id >= 0) {
-                const ShapeD &lsh = sc.shapes[pk.shape_id];
-                Surf lp = sample_tri(lsh, pk.tri_id, ld.uv);
-                V3 dir = lp.position - pos;
-                double d2 = len_sq(dir);
-                V3 wo = dir / sqrt(d2);
-                if (lsh.light_id >= 0) {
-                    const LightD &l = sc.lights[lsh.light_id];
-                    if (l.two_sided || dot(-wo, lp.frame.n) > 0) {
-                        V3 lv_bar[3] = {v3(0), v3(0), v3(0)};
-                        V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
-                        double cl = dot(wo, lp.geom_normal);
-                        double geo = fabs(cl) / d2;
-                        V3 Le = v3f(l.intensity);
-                        double pdf_nee = sc.light_pmf[lsh.light_id] * (1 / sc.light_areas[lsh.light_id]);
-                        double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough) * geo;
-                        double mis = 1 / (1 + sq(pdf_b / pdf_nee));
-                        V3 nee = (mis * geo / pdf_nee) * f * Le;
-                        V3 nee_bar = pc_bar * thr;
-                        thr_bar += pc_bar * nee;
-                        double w = mis / pdf_nee;
-                        double w_bar = geo * sum(nee_bar * f * Le);
-                        double pdfnee_bar = -w_bar * w / pdf_nee;
-                        double geo_bar = w * sum(nee_bar * f * Le);
-                        V3 f_bar = w * nee_bar * geo * Le;
-                        V3 Le_bar = w * nee_bar * geo * f;
-                        // pdf_nee depends on the sampled triangle's area
-                        double area_bar = -pdfnee_bar * pdf_nee / tri_area(lsh, pk.tri_id);
-                        adj_tri_area(lsh, pk.tri_id, area_bar, lv_bar);
-                        if (g.light_intensity) accum3(g.light_intensity + 3 * lsh.light_id, Le_bar);
-                        double cl_bar = cl > 0 ? geo_bar / d2 : -geo_bar / d2;
-                        double d2_bar = -geo_bar * geo / d2;
-                        V3 wo_bar = cl_bar * lp.geom_normal;
-                        Surf lp_bar = surf_zero();
-                        lp_bar.geom_normal = cl_bar * wo;
-                        V3 wi_bar = v3(0);
-                        adj_bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough, f_bar, gm, sp_bar, wi_bar, wo_bar);
-                        V3 dir_bar = wo_bar / sqrt(d2);
-                        double sd_bar = -sum(wo_bar * dir) / d2;
-                        d2_bar += (0.5f * sd_bar / sqrt(d2));
-                        dir_bar += adj_len_sq(dir, d2_bar);
-                        lp_bar.position += dir_bar;
-                        sp_bar.position -= dir_bar;
-                        in_dir_bar -= wi_bar;
-                        adj_sample_tri(lsh, pk.tri_id, ld.uv, lp_bar, lv_bar);
-                        TriVerts tv = load_tri(lsh, pk.tri_id);
-                        double *gv = g.shapes[pk.shape_id].vertices;
-                        accum3(gv + 3 * tv.i0, lv_bar[0]); accum3(gv + 3 * tv.i1, lv_bar[1]); accum3(gv + 3 * tv.i2, lv_bar[2]);
-                    }
-                }
-            }
-        }
-
-        // ---- BSDF-sampled continuation ----
         int bshape = vn.shape[p];
         if (bshape >= 0) {
             const ShapeD &bsh = sc.shapes[bshape];
@@ -187,6 +138,81 @@ struct AdjBounce {
         st3(adj.thr, adj.n, p, 0, thr_bar);
         st3(adj.ray_dir, adj.n, p, 0, in_dir_bar);
         store_adj_point(adj, p, sp_bar);
+    }
+};
+
+struct AdjBounceNee {
+    AdjBounceArgs a;
+    RDR_FN void operator()(int idx) const {
+        const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v; const AdjState &adj = a.adj;
+        int p = a.active[idx];
+        if (v.occl[p]) return;
+        LightDraw ld = draw_light(a.rng, p, a.dim);
+        LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
+        if (pk.shape_id < 0) return;
+        const ShapeD &lsh = sc.shapes[pk.shape_id];
+        if (lsh.light_id < 0) return;
+        VertexCtx c = load_vertex(sc, v, p);
+        V3 pos = c.sp.position;
+        Surf lp = sample_tri(lsh, pk.tri_id, ld.uv);
+        V3 dir = lp.position - pos;
+        double d2 = len_sq(dir);
+        V3 wo = dir / sqrt(d2);
+        const LightD &l = sc.lights[lsh.light_id];
+        if (!(l.two_sided || dot(-wo, lp.frame.n) > 0)) return;
+        const GMaterial &gm = g.materials[c.shape->material_id];
+        V3 thr = ld3(v.thr, v.n, p, 0);
+        V3 pc_bar = a.weight * image_grad(a.d_image, a.nd, a.radiance_dim, p);
+        V3 thr_bar = v3(0), in_dir_bar = v3(0);
+        Surf sp_bar = surf_zero();
+        V3 lv_bar[3] = {v3(0), v3(0), v3(0)};
+        V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
+        double cl = dot(wo, lp.geom_normal);
+        double geo = fabs(cl) / d2;
+        V3 Le = v3f(l.intensity);
+        double pdf_nee = sc.light_pmf[lsh.light_id] * (1 / sc.light_areas[lsh.light_id]);
+        double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough) * geo;
+        double mis = 1 / (1 + sq(pdf_b / pdf_nee));
+        V3 nee = (mis * geo / pdf_nee) * f * Le;
+        V3 nee_bar = pc_bar * thr;
+        thr_bar += pc_bar * nee;
+        double w = mis / pdf_nee;
+        double w_bar = geo * sum(nee_bar * f * Le);
+        double pdfnee_bar = -w_bar * w / pdf_nee;
+        double geo_bar = w * sum(nee_bar * f * Le);
+        V3 f_bar = w * nee_bar * geo * Le;
+        V3 Le_bar = w * nee_bar * geo * f;
+        // pdf_nee depends on the sampled triangle's area
+        double area_bar = -pdfnee_bar * pdf_nee / tri_area(lsh, pk.tri_id);
+        adj_tri_area(lsh, pk.tri_id, area_bar, lv_bar);
+        if (g.light_intensity) accum3(g.light_intensity + 3 * lsh.light_id, Le_bar);
+        double cl_bar = cl > 0 ? geo_bar / d2 : -geo_bar / d2;
+        double d2_bar = -geo_bar * geo / d2;
+        V3 wo_bar = cl_bar * lp.geom_normal;
+        Surf lp_bar = surf_zero();
+        lp_bar.geom_normal = cl_bar * wo;
+        V3 wi_bar = v3(0);
+        adj_bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough, f_bar, gm, sp_bar, wi_bar, wo_bar);
+        V3 dir_bar = wo_bar / sqrt(d2);
+        double sd_bar = -sum(wo_bar * dir) / d2;
+        d2_bar += (0.5f * sd_bar / sqrt(d2));
+        dir_bar += adj_len_sq(dir, d2_bar);
+        lp_bar.position += dir_bar;
+        sp_bar.position -= dir_bar;
+        in_dir_bar -= wi_bar;
+        adj_sample_tri(lsh, pk.tri_id, ld.uv, lp_bar, lv_bar);
+        TriVerts tv = load_tri(lsh, pk.tri_id);
+        double *gv = g.shapes[pk.shape_id].vertices;
+        accum3(gv + 3 * tv.i0, lv_bar[0]); accum3(gv + 3 * tv.i1, lv_bar[1]); accum3(gv + 3 * tv.i2, lv_bar[2]);
+        // add to the record written by AdjBounceScatter
+        st3(adj.thr, adj.n, p, 0, ld3(adj.thr, adj.n, p, 0) + thr_bar);
+        st3(adj.ray_dir, adj.n, p, 0, ld3(adj.ray_dir, adj.n, p, 0) + in_dir_bar);
+        Surf cur = load_adj_point(adj, p);
+        cur.position += sp_bar.position;
+        cur.frame.x += sp_bar.frame.x; cur.frame.y += sp_bar.frame.y; cur.frame.n += sp_bar.frame.n;
+        cur.dpdu += sp_bar.dpdu; cur.uv += sp_bar.uv; cur.du_dxy += sp_bar.du_dxy; cur.dv_dxy += sp_bar.dv_dxy;
+        cur.color += sp_bar.color;
+        store_adj_point(adj, p, cur);
     }
 };
 

@@ -312,16 +312,19 @@ RDR_FN bool ray_box_expand(V3 lo, V3 hi, const Ray &r, double expand) {
     return true;
 }
 
-constexpr int kEdgeStack = 128;
 constexpr int kHSamples = 16;
+// hierarchical pick: every stack entry carries >= 1 of the 16 samples, so <= 16 entries are live
+constexpr int kHStack = 20;
+// NEE pick: depth-first with both children pushed: <= tree depth + 1 entries (checked at scene build)
+constexpr int kNStack = 64;
 
 struct HItem { int ref, num; double pmf; };
 
 // Stochastic top-down pick of one edge, splitting kHSamples "samples" by LTC-bounded importance
 // and keeping one leaf by reservoir sampling.  Returns the edge id or -1; weight = 1/pmf.
-RDR_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c,
-                                  double sample, double resample, double &weight) {
-    HItem stack[kEdgeStack];
+RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c,
+                                      double sample, double resample, double &weight) {
+    RDR_STACK_DECL(HItem, stack, kHStack);
     int sp = 0;
     int selected = -1;
     double edge_w = 0, wsum = 0;
@@ -335,10 +338,11 @@ RDR_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, const 
         if (sample < prob) { n_cs++; sample /= prob; }
         else { n_ncs++; sample = (sample - prob) / (1 - prob); }
     }
-    if (n_cs > 0) stack[sp++] = HItem{0, n_cs, prob_cs};
-    if (n_ncs > 0) stack[sp++] = HItem{kEdgeTreeBit, n_ncs, prob_ncs};
+    if (n_cs > 0) { RDR_STACK_AT(stack, sp) = HItem{0, n_cs, prob_cs}; sp++; }
+    if (n_ncs > 0) { RDR_STACK_AT(stack, sp) = HItem{kEdgeTreeBit, n_ncs, prob_ncs}; sp++; }
     while (sp > 0) {
-        HItem it = stack[--sp];
+        --sp;
+        HItem it = RDR_STACK_AT(stack, sp);
         const EdgeNode &nd = edge_node(es, it.ref);
         if (nd.edge_id != -1) {
             double w = it.num * leaf_importance_h(sc, es, it.ref, c) / it.pmf;
@@ -369,8 +373,8 @@ RDR_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, const 
                     if (sample < prob) { s0++; sample /= prob; }
                     else { s1++; sample = (sample - prob) / (1 - prob); }
                 }
-                if (s0 > 0 && sp < kEdgeStack) stack[sp++] = HItem{c0, s0, it.pmf * p0};
-                if (s1 > 0 && sp < kEdgeStack) stack[sp++] = HItem{c1, s1, it.pmf * p1};
+                if (s0 > 0 && sp < kHStack) { RDR_STACK_AT(stack, sp) = HItem{c0, s0, it.pmf * p0}; sp++; }
+                if (s1 > 0 && sp < kHStack) { RDR_STACK_AT(stack, sp) = HItem{c1, s1, it.pmf * p1}; sp++; }
             }
         }
     }
@@ -381,16 +385,17 @@ RDR_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, const 
 }
 
 // NEE-billboard pick: gather every edge whose billboard the NEE ray crosses, keep one.
-RDR_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c, const Ray &nee, bool nee_valid,
-                         const Surf &nee_pt, int nee_shape, double resample, double &weight, V3 &edge_pt, V3 &mwt) {
-    int stack[kEdgeStack];
+RDR_DEV_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c, const Ray &nee, bool nee_valid,
+                             const Surf &nee_pt, int nee_shape, double resample, double &weight, V3 &edge_pt, V3 &mwt) {
+    RDR_STACK_DECL(int, stack, kNStack);
     int sp = 0;
     int selected = -1;
     double edge_w = 0, wsum = 0;
-    if (es.cs_nodes) stack[sp++] = 0;
-    if (es.ncs_nodes) stack[sp++] = kEdgeTreeBit;
+    if (es.cs_nodes) { RDR_STACK_AT(stack, sp) = 0; sp++; }
+    if (es.ncs_nodes) { RDR_STACK_AT(stack, sp) = kEdgeTreeBit; sp++; }
     while (sp > 0) {
-        int ref = stack[--sp];
+        --sp;
+        int ref = RDR_STACK_AT(stack, sp);
         const EdgeNode &nd = edge_node(es, ref);
         if (nd.edge_id != -1) {
             double w = leaf_importance_l(sc, es, ref, c, nee, nee_valid);
@@ -409,7 +414,7 @@ RDR_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c
                 bool ok = may_hold_silhouette(es, ch[k], c.pos);
                 if (ok && nee_valid) ok = may_hold_silhouette(es, ch[k], nee_pt.position);
                 if (ok) ok = ray_box_expand(cn.p_min, cn.p_max, nee, es.edge_bounds_expand);
-                if (ok && sp < kEdgeStack) stack[sp++] = ch[k];
+                if (ok && sp < kNStack) { RDR_STACK_AT(stack, sp) = ch[k]; sp++; }
             }
         }
     }
@@ -450,134 +455,203 @@ RDR_FN M3 ltc_matrix(const float *tab, const Surf &sp, V3 wi, double roughness) 
     return r;
 }
 
-struct SampleSecondaryEdges {
+// The secondary-edge sampler is cut into four stages so that lanes running the two very different
+// edge-selection procedures (stochastic hierarchy descent vs. NEE-billboard gathering) do not share
+// wavefronts: SecEdgeSetup decides the mode per slot, the slots are compacted per mode, SecEdgePickH /
+// SecEdgePickN traverse the edge hierarchies, SecEdgeFinish places the point on the edge and emits
+// the two rays.  Every stage rebuilds the small per-slot context (sec_prepare) from the stored path
+// vertex instead of passing ~400 bytes per slot through HBM.
+struct SecPick { int eid; double ew; V3 sample_p, mwt; };
+
+struct SecPre {
+    bool live;                 // false: slot produces no edge sample
+    VertexCtx c;
+    LtcCtx lc;
+    double pd, ps, m_pmf, roughness, nee_pmf, edge_sel, resample_sel, bsdf_comp, t_sel;
+    bool dg, use_nee, nee_valid;
+    Ray nee; Surf nee_pt; int nee_shape;
+};
+
+RDR_FN SecPre sec_prepare(const SceneD &sc, const EdgeSceneD &es, const SobolD &rng_main, int dim_main,
+                          const SobolD &rng_edge, int dim_edge, const VSlice &v, int p, int idx) {
+    SecPre s;
+    s.live = false;
+    s.c = load_vertex(sc, v, p);
+    if (s.c.mrough > 1e-2f) return s;
+    // NEE segment of this vertex (recomputed from the forward sampler's numbers)
+    LightDraw ld = draw_light(rng_main, p, dim_main);
+    LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
+    s.nee_valid = pk.shape_id >= 0;
+    s.nee_shape = pk.shape_id;
+    s.nee_pt = surf_zero();
+    s.nee = make_ray(s.c.sp.position, v3(0));
+    if (s.nee_valid) {
+        s.nee_pt = sample_tri(sc.shapes[pk.shape_id], pk.tri_id, ld.uv);
+        s.nee = shadow_ray_to(s.c.sp.position, s.nee_pt.position);
+        s.nee.tmax = len(s.nee_pt.position - s.nee.org);
+    }
+    s.edge_sel = rng_edge.draw(idx, dim_edge); s.resample_sel = rng_edge.draw(idx, dim_edge + 1);
+    s.bsdf_comp = rng_edge.draw(idx, dim_edge + 2); s.t_sel = rng_edge.draw(idx, dim_edge + 3);
+    const MaterialD &mat = *s.c.mat;
+    V3 kd = tex3(mat.diffuse, s.c.sp), ks = tex3(mat.specular, s.c.sp);
+    double wd = luminance(kd), ws = luminance(ks), wsum = wd + ws;
+    if (wsum <= 0.f) return s;
+    s.pd = wd / wsum; s.ps = ws / wsum;
+    V3 n = s.c.sp.frame.n;
+    V3 wi = s.c.wi;
+    if (mat.two_sided && dot(wi, n) < 0.f) n = -n;
+    V3 fx = normalize(wi - n * dot(wi, n));
+    V3 fy = cross(n, fx);
+    if (dot(wi, n) > 1 - 1e-6f) onb(n, fx, fy);
+    Frame iso{fx, fy, n};
+    s.lc.pos = s.c.sp.position;
+    s.roughness = dmax(tex1(mat.roughness, s.c.sp), s.c.mrough);
+    if (s.bsdf_comp <= s.pd) {
+        s.lc.m_inv = m3_from_frame(iso);
+        s.lc.m = m3_inverse(s.lc.m_inv);
+        s.m_pmf = s.pd;
+    } else {
+        s.lc.m_inv = m3_mul(m3_inverse(ltc_matrix(es.ltc, s.c.sp, wi, s.roughness)), m3_from_frame(iso));
+        s.lc.m = m3_inverse(s.lc.m_inv);
+        s.m_pmf = s.ps;
+    }
+    s.use_nee = false;
+    s.nee_pmf = 1;
+    s.dg = s.bsdf_comp <= s.pd || s.roughness > 0.1;
+    if (s.dg) {
+        s.use_nee = s.edge_sel < 0.5;
+        if (s.roughness > 0.1) s.nee_pmf = 0.5f;
+        else s.nee_pmf = s.use_nee ? s.pd * 0.5f : 1.f - s.pd * 0.5f;
+    }
+    if (!s.use_nee && s.dg) s.edge_sel = (s.edge_sel - 0.5) * 2;
+    s.live = true;
+    return s;
+}
+
+struct SecEdgeArgs {          // what every stage of the sampler needs
     SceneD sc; EdgeSceneD es;
     SobolD rng_main; int dim_main;      // the forward sampler's light draw of this vertex
     SobolD rng_edge; int dim_edge;      // edge sampler: 4 numbers per compacted slot
     const int *active; VSlice v;        // main-path vertex
-    const float *d_image; int nd, radiance_dim;
-    SecondaryEdgeRec *recs; VSlice ev; double *edge_tmin;
+};
+
+// mode[slot]: 0 = no sample, 1 = hierarchical pick, 2 = NEE-billboard pick.  Also resets the slot's outputs.
+struct SecEdgeSetup {
+    SecEdgeArgs a; unsigned char *mode; SecondaryEdgeRec *recs; SecPick *picks; VSlice ev; double *edge_tmin;
     RDR_FN void operator()(int idx) const {
-        int p = active[idx];
+        int p = a.active[idx];
         int l0 = 2 * idx, l1 = 2 * idx + 1;
-        VertexCtx c = load_vertex(sc, v, p);
+        SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, p, idx);
         SecondaryEdgeRec rec;
         rec.edge = EdgeD{-1, 0, 0, 0, 0};
-        rec.edge_pt = rec.mwt = v3(0); rec.sp_pos = c.sp.position;
+        rec.edge_pt = rec.mwt = v3(0); rec.sp_pos = s.c.sp.position;
         rec.use_nee_ray = 0; rec.diffuse_or_glossy = 0;
         recs[idx] = rec;
+        picks[idx] = SecPick{-1, 0.0, v3(0), v3(0)};
         for (int l = l0; l <= l1; ++l) {
             st3(ev.thr, ev.n, l, 0, v3(0));
             store_ray(ev, l, v3(0), v3(0));
             ev.shape[l] = -1; ev.tri[l] = -1;
-            ev.mrough[l] = c.mrough;
+            ev.mrough[l] = s.c.mrough;
             edge_tmin[l] = 1e-3f;
             store_rdiff(ev, l, raydiff_zero());
         }
-        if (c.mrough > 1e-2f) return;
+        mode[idx] = !s.live ? 0 : (s.use_nee ? 2 : 1);
+    }
+};
+struct KeepMode {
+    const unsigned char *mode; unsigned char want;
+    RDR_FN bool operator()(int idx) const { return mode[idx] == want; }
+};
 
-        // NEE segment of this vertex (recomputed from the forward sampler's numbers)
-        LightDraw ld = draw_light(rng_main, p, dim_main);
-        LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
-        bool nee_valid = pk.shape_id >= 0;
-        Surf nee_pt = surf_zero();
-        Ray nee = make_ray(c.sp.position, v3(0));
-        if (nee_valid) {
-            nee_pt = sample_tri(sc.shapes[pk.shape_id], pk.tri_id, ld.uv);
-            nee = shadow_ray_to(c.sp.position, nee_pt.position);
-            nee.tmax = len(nee_pt.position - nee.org);
-        }
-        double edge_sel = rng_edge.draw(idx, dim_edge), resample_sel = rng_edge.draw(idx, dim_edge + 1);
-        double bsdf_comp = rng_edge.draw(idx, dim_edge + 2), t_sel = rng_edge.draw(idx, dim_edge + 3);
-
-        const MaterialD &mat = *c.mat;
-        V3 kd = tex3(mat.diffuse, c.sp), ks = tex3(mat.specular, c.sp);
-        double wd = luminance(kd), ws = luminance(ks), wsum = wd + ws;
-        if (wsum <= 0.f) return;
-        double pd = wd / wsum, ps = ws / wsum;
-        double m_pmf;
-        V3 n = c.sp.frame.n;
-        V3 wi = c.wi;
-        if (mat.two_sided && dot(wi, n) < 0.f) n = -n;
-        V3 fx = normalize(wi - n * dot(wi, n));
-        V3 fy = cross(n, fx);
-        if (dot(wi, n) > 1 - 1e-6f) onb(n, fx, fy);
-        Frame iso{fx, fy, n};
-        LtcCtx lc;
-        lc.pos = c.sp.position;
-        double roughness = dmax(tex1(mat.roughness, c.sp), c.mrough);
-        if (bsdf_comp <= pd) {
-            lc.m_inv = m3_from_frame(iso);
-            lc.m = m3_inverse(lc.m_inv);
-            m_pmf = pd;
-        } else {
-            lc.m_inv = m3_mul(m3_inverse(ltc_matrix(es.ltc, c.sp, wi, roughness)), m3_from_frame(iso));
-            lc.m = m3_inverse(lc.m_inv);
-            m_pmf = ps;
-        }
-        int eid = -1;
+struct SecEdgePickH {
+    SecEdgeArgs a; const int *slots; SecPick *picks;
+    RDR_FN void operator()(int i) const {
+        int idx = slots[i];
+        SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
+        double ew = 0;
+        int eid = pick_edge_hierarchical(a.sc, a.es, s.lc, s.edge_sel, s.resample_sel, ew);
+        picks[idx] = SecPick{eid, ew, v3(0), v3(0)};
+    }
+};
+struct SecEdgePickN {
+    SecEdgeArgs a; const int *slots; SecPick *picks;
+    RDR_FN void operator()(int i) const {
+        int idx = slots[i];
+        SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
         double ew = 0;
         V3 sample_p = v3(0), mwt = v3(0);
-        bool use_nee = false;
-        double nee_pmf = 1;
-        bool dg = bsdf_comp <= pd || roughness > 0.1;
-        if (dg) {
-            use_nee = edge_sel < 0.5;
-            if (roughness > 0.1) nee_pmf = 0.5f;
-            else nee_pmf = use_nee ? pd * 0.5f : 1.f - pd * 0.5f;
-        }
-        if (!use_nee) {
-            if (dg) edge_sel = (edge_sel - 0.5) * 2;
-            eid = pick_edge_hierarchical(sc, es, lc, edge_sel, resample_sel, ew);
-            if (eid == -1 || ew <= 0) return;
+        int eid = pick_edge_nee(a.sc, a.es, s.lc, s.nee, s.nee_valid, s.nee_pt, s.nee_shape, s.resample_sel, ew, sample_p, mwt);
+        picks[idx] = SecPick{eid, ew, sample_p, mwt};
+    }
+};
+
+struct SecEdgeFinish {
+    SecEdgeArgs a; const unsigned char *mode; const SecPick *picks;
+    const float *d_image; int nd, radiance_dim;
+    SecondaryEdgeRec *recs; VSlice ev; double *edge_tmin;
+    RDR_FN void operator()(int idx) const {
+        if (mode[idx] == 0) return;
+        SecPick pkd = picks[idx];
+        int eid = pkd.eid;
+        double ew = pkd.ew;
+        if (eid == -1 || ew <= 0) return;
+        int p = a.active[idx];
+        int l0 = 2 * idx, l1 = 2 * idx + 1;
+        const SceneD &sc = a.sc;
+        const EdgeSceneD &es = a.es;
+        SecPre s = sec_prepare(sc, es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, p, idx);
+        const VertexCtx &c = s.c;
+        const LtcCtx &lc = s.lc;
+        V3 sample_p = pkd.sample_p, mwt = pkd.mwt;
+        if (!s.use_nee) {
             const EdgeD &e = es.edges[eid];
             if (!edge_is_silhouette(sc.shapes, lc.pos, e)) return;
-            V3 a = edge_v0(sc.shapes, e), b = edge_v1(sc.shapes, e);
-            V3 ao = m3_apply(lc.m_inv, a - lc.pos), bo = m3_apply(lc.m_inv, b - lc.pos);
+            V3 ea = edge_v0(sc.shapes, e), eb = edge_v1(sc.shapes, e);
+            V3 ao = m3_apply(lc.m_inv, ea - lc.pos), bo = m3_apply(lc.m_inv, eb - lc.pos);
             if (ao.z <= 0.f && bo.z <= 0.f) return;
-            LineSetup s = line_setup(ao, bo);
-            double Il0 = line_I(s, s.l0), Il1 = line_I(s, s.l1);
+            LineSetup ls = line_setup(ao, bo);
+            double Il0 = line_I(ls, ls.l0), Il1 = line_I(ls, ls.l1);
             double norm = Il1 - Il0;
-            double lb = s.l0, ub = s.l1;
+            double lb = ls.l0, ub = ls.l1;
             if (lb > ub) { double tt = lb; lb = ub; ub = tt; }
             double l = 0.5f * (lb + ub);
             for (int it = 0; it < 20; ++it) {
                 if (!(l >= lb && l <= ub)) l = 0.5f * (lb + ub);
-                double value = (line_I(s, l) - Il0) / norm - t_sel;
+                double value = (line_I(ls, l) - Il0) / norm - s.t_sel;
                 if (fabs(value) < 1e-5f || it == 19) break;
                 if (value > 0.f) ub = l; else lb = l;
-                double dsq = s.d * s.d + l * l;
-                double deriv = 2.f * s.d * (s.vo + l * s.wt).z / (norm * dsq * dsq);
+                double dsq = ls.d * ls.d + l * l;
+                double deriv = 2.f * ls.d * (ls.vo + l * ls.wt).z / (norm * dsq * dsq);
                 l -= value / deriv;
             }
-            double dsq = s.d * s.d + l * l;
-            double lpdf = 2.f * s.d * (s.vo + l * s.wt).z / (norm * dsq * dsq);
+            double dsq = ls.d * ls.d + l * l;
+            double lpdf = 2.f * ls.d * (ls.vo + l * ls.wt).z / (norm * dsq * dsq);
             if (lpdf <= 0.f) return;
-            sample_p = m3_apply(lc.m, s.vo + l * s.wt);
-            ew /= (m_pmf * lpdf);
-            mwt = m3_apply(lc.m, s.wt);
-        } else {
-            eid = pick_edge_nee(sc, es, lc, nee, nee_valid, nee_pt, pk.shape_id, resample_sel, ew, sample_p, mwt);
-            if (eid == -1 || ew <= 0) return;
+            sample_p = m3_apply(lc.m, ls.vo + l * ls.wt);
+            ew /= (s.m_pmf * lpdf);
+            mwt = m3_apply(lc.m, ls.wt);
         }
         const EdgeD &e = es.edges[eid];
-        V3 a = edge_v0(sc.shapes, e), b = edge_v1(sc.shapes, e);
-        V3 hn = normalize(cross(a - lc.pos, b - lc.pos));
+        V3 ea = edge_v0(sc.shapes, e), eb = edge_v1(sc.shapes, e);
+        V3 hn = normalize(cross(ea - lc.pos, eb - lc.pos));
         double off = 1e-5f / len(sample_p);
         V3 sdir = normalize(sample_p);
         V3 up = normalize(sdir + off * hn), lo = normalize(sdir - off * hn);
-        V3 f = bsdf_eval(mat, c.sp, wi, sdir, c.mrough);
+        V3 wi = c.wi;
+        V3 f = bsdf_eval(*c.mat, c.sp, wi, sdir, c.mrough);
         if (sum(f) < 1e-6f) return;
         V3 dc = image_grad(d_image, nd, radiance_dim, p);
+        SecondaryEdgeRec rec = recs[idx];
         rec.edge = e; rec.edge_pt = sample_p; rec.mwt = mwt;
-        rec.use_nee_ray = use_nee ? 1 : 0; rec.diffuse_or_glossy = dg ? 1 : 0;
+        rec.use_nee_ray = s.use_nee ? 1 : 0; rec.diffuse_or_glossy = s.dg ? 1 : 0;
         recs[idx] = rec;
         store_ray(ev, l0, lc.pos, up);
         store_ray(ev, l1, lc.pos, lo);
         edge_tmin[l0] = edge_tmin[l1] = 1e-3f * len(sample_p);
         RayDiff brd;
         brd.org_dx = c.rd_surf.org_dx; brd.org_dy = c.rd_surf.org_dy;
-        if (bsdf_comp <= pd) {
+        if (s.bsdf_comp <= s.pd) {
             brd.dir_dx = V3{0.03f, 0.03f, 0.03f};
             brd.dir_dy = V3{0.03f, 0.03f, 0.03f};
         } else {
@@ -590,7 +664,7 @@ struct SampleSecondaryEdges {
             brd.dir_dy = ddy - 2 * (-dot(wi, h) * c.sp.dn_dy + ddn_dy * h);
         }
         store_rdiff(ev, l0, brd); store_rdiff(ev, l1, brd);
-        V3 nt = ld3(v.thr, v.n, p, 0) * f * dc * ew / nee_pmf;
+        V3 nt = ld3(a.v.thr, a.v.n, p, 0) * f * dc * ew / s.nee_pmf;
         st3(ev.thr, ev.n, l0, 0, nt);
         st3(ev.thr, ev.n, l1, 0, -nt);
     }

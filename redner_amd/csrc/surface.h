@@ -390,7 +390,8 @@ RDR_FN void scatter_trigrad(const ShapeD &sh, const GShape &gs, int tri, const T
     int vi[3] = {tv.i0, tv.i1, tv.i2};
     int ui[3] = {at.ui0, at.ui1, at.ui2};
     int ni[3] = {at.ni0, at.ni1, at.ni2};
-    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {       // must unroll: dynamic indexing would push the TriGrad into scratch
         accum3(gs.vertices + 3 * vi[k], g.p[k]);
         if (sh.uvs && gs.uvs) { accum(gs.uvs + 2 * ui[k], g.uv[k].x); accum(gs.uvs + 2 * ui[k] + 1, g.uv[k].y); }
         if (sh.normals && gs.normals) accum3(gs.normals + 3 * ni[k], g.n[k]);

@@ -13,6 +13,9 @@
 #include <string>
 
 #define RDR_FN inline
+#define RDR_DEV_FN inline
+#define RDR_STACK_DECL(T, name, N) T name[N]
+#define RDR_STACK_AT(name, k) name[k]
 #define RDR_HOSTSIM 1
 
 namespace rdr {
@@ -50,8 +53,9 @@ inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits,
         rt::Hit h{0.f, -1, -1};
         if (!(r.tmax < 0.f)) {
             float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
-            h = any ? rt::traverse<true>(bvh, o, d, r.tmin, r.tmax, st.counting ? &cnt : nullptr)
-                    : rt::traverse<false>(bvh, o, d, r.tmin, r.tmax, st.counting ? &cnt : nullptr);
+            int stack[rt::kTraverseStack];
+            h = any ? rt::traverse<true>(bvh, o, d, r.tmin, r.tmax, stack, 1, st.counting ? &cnt : nullptr)
+                    : rt::traverse<false>(bvh, o, d, r.tmin, r.tmax, stack, 1, st.counting ? &cnt : nullptr);
         }
         hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};
     }
