@@ -196,6 +196,7 @@ RDR_FN double smith_g1(V3 v, V3 n, double roughness) {
 }
 
 RDR_FN V3 bsdf_eval(const MaterialD &m, const Surf &sp, V3 wi, V3 wo, double min_rough) {
+    RDR_CONTRACT_FAST
     ShadeCtx c = shade_ctx(m, sp);
     double gwi = dot(c.gn, wi), gwo = dot(c.gn, wo);
     double swi = fabs(dot(c.fr.n, wi)), swo = fabs(dot(c.fr.n, wo));
@@ -225,6 +226,7 @@ RDR_FN V3 bsdf_eval(const MaterialD &m, const Surf &sp, V3 wi, V3 wo, double min
 
 RDR_FN void adj_bsdf_eval(const MaterialD &m, const Surf &sp, V3 wi, V3 wo, double min_rough, V3 f_bar,
                           const GMaterial &gm, Surf &sp_bar, V3 &wi_bar, V3 &wo_bar) {
+    RDR_CONTRACT_FAST
     ShadeCtx c = shade_ctx(m, sp);
     V3 n = c.fr.n;
     V3 n_bar = v3(0);
@@ -336,6 +338,7 @@ RDR_FN LobePmf lobe_pmf(const MaterialD &m, const Surf &sp) {
 }
 
 RDR_FN double bsdf_pdf(const MaterialD &m, const Surf &sp, V3 wi, V3 wo, double min_rough) {
+    RDR_CONTRACT_FAST
     ShadeCtx c = shade_ctx(m, sp);
     double gwi = dot(c.gn, wi), gwo = dot(c.gn, wo);
     double swo = fabs(dot(c.fr.n, wo));

@@ -39,6 +39,7 @@ VSlice make_slice(Arena &a, int n, bool with_occl) {
     v.thr = a.get<double>((size_t)3 * n);
     v.mrough = a.get<double>(n);
     v.occl = with_occl ? a.get<unsigned char>(n) : nullptr;
+    v.erd = nullptr;
     return v;
 }
 
@@ -47,14 +48,20 @@ struct Queues {
     rt::HitRec *h_nee, *h_bsdf;
 };
 
-struct ChannelLayout { int nd, radiance_dim; };
+struct ChannelLayout { int nd, radiance_dim; ChannelsD ch; };
 ChannelLayout layout_of(const rdr_render_options &o, int max_generic) {
-    ChannelLayout l{0, -1};
+    ChannelLayout l;
+    l.nd = 0; l.radiance_dim = -1;
+    if (o.num_channels > kMaxChannels) throw std::runtime_error("render: too many channels");
+    if (max_generic > kMaxGeneric) throw std::runtime_error("render: generic textures wider than 16 channels are not supported");
+    l.ch.n = o.num_channels; l.ch.max_generic = max_generic; l.ch.radiance_off = -1;
+    for (int i = 0; i < kMaxChannels; ++i) l.ch.id[i] = i < o.num_channels ? o.channels[i] : 0;
     int d = 0;
     for (int i = 0; i < o.num_channels; ++i) {
         if (o.channels[i] == RDR_CH_RADIANCE) {
             if (l.radiance_dim != -1) throw std::runtime_error("Duplicated radiance channel");   // src/channels.cpp:24-26
-            l.radiance_dim = d;
+            l.radiance_dim = i;             // [quirk] channel index, see ChannelsD
+            l.ch.radiance_off = d;
         }
         int one = o.channels[i];
         int w = compute_num_channels(&one, 1, max_generic);
@@ -62,6 +69,7 @@ ChannelLayout layout_of(const rdr_render_options &o, int max_generic) {
         d += w;
     }
     l.nd = d;
+    l.ch.nd = d; l.ch.radiance_dim = l.radiance_dim;
     return l;
 }
 
@@ -191,10 +199,13 @@ struct Backward {
     Arena arena;
     AdjState adj;
 
+    ChannelsD ch;
+    double *multipliers = nullptr;     // [2P x nd], primary-edge channel weights (non-radiance channels only)
+
     Backward(const Scene &scene_, const rdr_render_options &opt_, const rdr_dscene_desc &ds, int P_, int B_,
-             const float *d_image_, float *screen_grad_, double weight_, int nd_, int radiance_dim_)
+             const float *d_image_, float *screen_grad_, double weight_, int nd_, int radiance_dim_, const ChannelsD &ch_)
         : scene(scene_), opt(opt_), P(P_), B(B_), d_image(d_image_), screen_grad(screen_grad_), weight(weight_),
-          nd(nd_), radiance_dim(radiance_dim_), grads(scene_, ds) {
+          nd(nd_), radiance_dim(radiance_dim_), grads(scene_, ds), ch(ch_) {
         adj.n = P;
         adj.thr = arena.get<double>((size_t)3 * P);
         adj.ray_dir = arena.get<double>((size_t)3 * P);
@@ -205,6 +216,11 @@ struct Backward {
             const int L = 2 * P;                      // edge lanes: two rays per sample slot
             ea = make_slice(arena, L, false);
             eb = make_slice(arena, L, false);
+            if (scene.has_mipmaps) {
+                // the reference's buffer is a fresh allocation per render call; fresh pages read as zero
+                ea.erd = eb.erd = arena.get<double>((size_t)12 * L);
+                exec::zero(ea.erd, sizeof(double) * 12 * L);
+            }
             for (int k = 0; k < 3; ++k) elist[k] = arena.get<int>(L);
             edge_contrib = arena.get<double>(L);
             edge_tmin = arena.get<double>(L);
@@ -213,6 +229,7 @@ struct Backward {
             sec_recs = arena.get<SecondaryEdgeRec>(P);
             sec_picks = arena.get<SecPick>(P);
             sec_mode = arena.get<unsigned char>(P);
+            if (!(ch.n == 1 && ch.id[0] == 0)) multipliers = arena.get<double>((size_t)L * nd);
         }
     }
 
@@ -247,7 +264,8 @@ struct Backward {
         SobolD rng_edge{scene.sobol_table, opt.seed + 131071U, sample_id};   // src/pathtracer.cpp:221-227
         const bool has_lights = scene.d.num_lights > 0;
         const bool edges_on = prim_recs != nullptr;
-        Sink esink{nullptr, edge_contrib, nd, radiance_dim, weight};
+        Sink esink{nullptr, edge_contrib, nd, radiance_dim, weight, ch, nullptr};
+        Sink psink{nullptr, edge_contrib, nd, radiance_dim, weight, ch, multipliers};
         int edim = 0;
         exec::zero(adj.thr, sizeof(double) * 3 * P);
         exec::zero(adj.ray_dir, sizeof(double) * 3 * P);
@@ -276,6 +294,7 @@ struct Backward {
                 exec::launch(n0, QueueRays{elist[0], ea, edge_tmin, q.bsdf});
                 exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
                 exec::launch(n0, RecordHits{elist[0], ea, q.h_bsdf});
+                if (ea.erd) exec::launch(n0, MirrorSurfDiff{scene.d, elist[0], ea});
                 exec::launch(nA, SecondaryEdgeWeights{scene.d, sec_recs, ea, hit_pos});
                 exec::zero(edge_contrib, sizeof(double) * lanes);
                 exec::launch(n0, ShadeRecorded{scene.d, elist[0], ea, esink});
@@ -285,18 +304,20 @@ struct Backward {
             }
         }
         exec::launch(P, AdjPrimary{scene.d, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
-                                   adj, screen_grad});
+                                   adj, screen_grad, ch});
         if (edges_on && scene.use_primary_edges) {
             // ---- primary (camera-visible silhouette) edges, :766-942 ----
             const EdgeSceneD &es = scene.edges->d;
             const int lanes = 2 * P;
             exec::zero(edge_contrib, sizeof(double) * lanes);
-            exec::launch(P, SamplePrimaryEdges{scene.d, es, rng_edge, edim, d_image, nd, radiance_dim, prim_recs, ea});
+            exec::launch(P, SamplePrimaryEdges{scene.d, es, rng_edge, edim, d_image, nd, radiance_dim, prim_recs, ea, multipliers});
             edim += 2;
             int n0 = exec::compact((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
+            if (ea.erd) exec::launch(n0, LoadLaneDiff{elist[0], ea});
             exec::launch(n0, QueueRays{elist[0], ea, nullptr, q.bsdf});
             exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
-            exec::launch(n0, ShadePrimary{scene.d, elist[0], ea, q.h_bsdf, esink});
+            exec::launch(n0, ShadePrimary{scene.d, elist[0], ea, q.h_bsdf, psink});
+            if (ea.erd) exec::launch(n0, MirrorSurfDiff{scene.d, elist[0], ea});
             int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
             edim += trace_edge_paths(rng_edge, edim, n1, 0, q, esink, true);
             exec::launch(P, PrimaryEdgeDerivatives{scene.d, grads.g, prim_recs, edge_contrib, screen_grad});
@@ -318,8 +339,9 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     const int B = opt.max_bounces;
     if (B < 0) throw std::runtime_error("render: max_bounces must be >= 0");
     ChannelLayout lay = layout_of(opt, scene.max_generic_texture_dimension);
-    if (lay.radiance_dim < 0 || lay.nd != 3)
-        throw std::runtime_error("render: only the radiance channel is implemented so far (G-buffer channels: SURVEY.md section 8f row 2)");
+    if (lay.radiance_dim < 0 && B > 0)
+        throw std::runtime_error("render: max_bounces > 0 needs the radiance channel (the reference writes path "
+                                 "contributions at the radiance offset, src/path_contribution.cpp:127-129)");
     const int total_spp = opt.total_samples > 0 ? opt.total_samples : opt.num_samples;
     const double weight = 1.0 / total_spp;
     const bool has_lights = scene.d.num_lights > 0;
@@ -335,12 +357,12 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     std::vector<int> num_active(B + 2, 0);
 
     std::unique_ptr<Backward> bwd;
-    if (d_image) bwd.reset(new Backward(scene, opt, *d_scene, P, B, d_image, screen_gradient_image, weight, lay.nd, lay.radiance_dim));
+    if (d_image) bwd.reset(new Backward(scene, opt, *d_scene, P, B, d_image, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch));
 
     for (int s = 0; s < opt.num_samples; ++s) {
         const int sample_id = opt.sample_offset + s;
         SobolD rng{scene.sobol_table, opt.seed, sample_id};
-        Sink sink{image, nullptr, lay.nd, lay.radiance_dim, weight};
+        Sink sink{image, nullptr, lay.nd, lay.radiance_dim, weight, lay.ch, nullptr};
 
         // ---- camera vertex ----
         exec::launch(P, GenPrimary{scene.d, rng, opt.sample_pixel_center, vs[0], q.bsdf});

@@ -148,6 +148,8 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         o.diffuse.channels = 3; o.specular.channels = 3; o.roughness.channels = 1; o.normal_map.channels = 3;
         o.compute_specular_lighting = in.compute_specular_lighting; o.two_sided = in.two_sided;
         o.use_vertex_color = in.use_vertex_color;
+        for (const TexD *t : {&o.diffuse, &o.specular, &o.roughness, &o.generic, &o.normal_map})
+            if (t->num_levels > 1) s.has_mipmaps = true;
         if (o.generic.num_levels > 0)
             s.max_generic_texture_dimension = std::max(s.max_generic_texture_dimension, o.generic.channels);
     }

@@ -49,6 +49,7 @@ RDR_FN void store_adj_point(const AdjState &a, int p, const Surf &s) {
 }
 
 RDR_FN V3 image_grad(const float *d_image, int nd, int radiance_dim, int pixel) {
+    if (radiance_dim < 0) return v3(0);
     const float *g = d_image + (size_t)nd * pixel + radiance_dim;
     return V3{(double)g[0], (double)g[1], (double)g[2]};
 }
@@ -217,23 +218,67 @@ struct AdjBounceNee {
 };
 
 // ---- adjoint of the camera vertex ------------------------------------------------------------------
+// Adjoint of the non-radiance G-buffer channels at the first hit: adds to the shading-point adjoint,
+// the ray-origin adjoint (depth) and the texture gradients (src/primary_contribution.cpp:487-700).
+RDR_FN void adj_first_hit_channels(const SceneD &sc, const GScene &g, const ChannelsD &ch, const float *d_image,
+                                   double weight, int p, int shape, const Surf &sp, const Ray &ray,
+                                   Surf &pt_bar, V3 &org_bar) {
+    const ShapeD &sh = sc.shapes[shape];
+    const MaterialD &m = sc.materials[sh.material_id];
+    const GMaterial &gm = g.materials[sh.material_id];
+    const float *gi = d_image + (size_t)ch.nd * p;
+    int d = 0;
+    for (int k = 0; k < ch.n; ++k) {
+        int id = ch.id[k];
+        int width = channel_width(id, ch.max_generic);
+        switch (id) {
+            case 2: {     // depth = |position - org|
+                double dist_bar = (double)gi[d] * weight;
+                V3 diff_bar = adj_len(sp.position - ray.org, dist_bar);
+                org_bar -= diff_bar; pt_bar.position += diff_bar;
+            } break;
+            case 3: pt_bar.position += weight * V3{(double)gi[d], (double)gi[d + 1], (double)gi[d + 2]}; break;
+            case 4: pt_bar.geom_normal += weight * V3{(double)gi[d], (double)gi[d + 1], (double)gi[d + 2]}; break;
+            case 5: pt_bar.frame.n += weight * V3{(double)gi[d], (double)gi[d + 1], (double)gi[d + 2]}; break;
+            case 6: pt_bar.uv += weight * V2{(double)gi[d], (double)gi[d + 1]}; break;
+            case 7: pt_bar.bary += weight * V2{(double)gi[d], (double)gi[d + 1]}; break;
+            case 8: {
+                V3 r_bar = weight * V3{(double)gi[d], (double)gi[d + 1], (double)gi[d + 2]};
+                if (m.use_vertex_color) pt_bar.color += r_bar; else adj_tex3(m.diffuse, sp, r_bar, gm.diffuse, pt_bar);
+            } break;
+            case 9: adj_tex3(m.specular, sp, weight * V3{(double)gi[d], (double)gi[d + 1], (double)gi[d + 2]}, gm.specular, pt_bar); break;
+            case 10: adj_tex1(m.roughness, sp, weight * (double)gi[d], gm.roughness, pt_bar); break;
+            case 11: {
+                if (m.generic.num_levels > 0) {
+                    double ob[kMaxGeneric];
+                    for (int j = 0; j < m.generic.channels; ++j) ob[j] = weight * (double)gi[d + j];
+                    adj_tex_fetch(m.generic, sp.uv, sp.du_dxy, sp.dv_dxy, ob, gm.generic, pt_bar.uv, pt_bar.du_dxy, pt_bar.dv_dxy);
+                }
+            } break;
+            case 12: pt_bar.color += weight * V3{(double)gi[d], (double)gi[d + 1], (double)gi[d + 2]}; break;
+            default: break;      // radiance handled by the caller; alpha and ids carry no gradient
+        }
+        d += width;
+    }
+}
+
 struct AdjPrimary {
     SceneD sc; GScene g; SobolD rng; int sample_center;
     VSlice v0; const float *d_image; int nd, radiance_dim; double weight;
-    AdjState adj; float *screen_grad;
+    AdjState adj; float *screen_grad; ChannelsD ch;
     RDR_FN void operator()(int p) const {
         int shape = v0.shape[p];
         Ray ray = load_ray(v0, p);
         RayDiff rd = load_rdiff(v0, p);
         // radiance channel: only the light intensity receives a gradient here
-        if (shape >= 0) {
+        if (shape >= 0 && radiance_dim >= 0) {
             const ShapeD &sh = sc.shapes[shape];
             if (sh.light_id >= 0 && g.light_intensity) {
                 RayDiff tmp;
                 Surf sp = surf_at(sh, v0.tri[p], ray, rd, tmp);
                 const LightD &l = sc.lights[sh.light_id];
                 if (dot(-ray.dir, sp.frame.n) > 0 && l.directly_visible) {
-                    V3 e_bar = weight * ld3(v0.thr, v0.n, p, 0) * image_grad(d_image, nd, radiance_dim, p);
+                    V3 e_bar = weight * ld3(v0.thr, v0.n, p, 0) * image_grad(d_image, nd, ch.radiance_off, p);
                     accum3(g.light_intensity + 3 * sh.light_id, e_bar);
                 }
             }
@@ -244,6 +289,11 @@ struct AdjPrimary {
         RayDiff prd_bar = raydiff_zero();
         {
             Surf pt_bar = load_adj_point(adj, p);
+            if (!(ch.n == 1 && ch.id[0] == 0)) {
+                RayDiff tmp;
+                Surf sp = surf_at(sc.shapes[shape], v0.tri[p], ray, rd, tmp);
+                adj_first_hit_channels(sc, g, ch, d_image, weight, p, shape, sp, ray, pt_bar, r_bar.org);
+            }
             TriGrad tg = trigrad_zero();
             adj_surf_at(sc.shapes[shape], v0.tri[p], ray, rd, pt_bar, raydiff_zero(), r_bar, prd_bar, tg);
             scatter_trigrad(sc.shapes[shape], g.shapes[shape], v0.tri[p], tg);

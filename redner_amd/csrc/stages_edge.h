@@ -84,10 +84,26 @@ struct ShadeRecorded {
     SceneD sc; const int *active; VSlice v; Sink sink;
     RDR_FN void operator()(int idx) const {
         int p = active[idx];
-        Ray ray = load_ray(v, p);
-        V3 e = direct_emission(sc, v.shape[p], v.tri[p], ray, load_rdiff(v, p));
-        V3 c = sink.weight * ld3(v.thr, v.n, p, 0) * e;
-        if (sink.edge_contrib) sink.edge_contrib[p] += sum(c);
+        shade_first_hit(sc, sink, v, p, v.shape[p], v.tri[p]);
+    }
+};
+// Mirrors of the reference's in-place differential buffer (VSlice::erd): transfer onto the surface
+// at a first hit (src/scene.cpp:585-591), and the per-lane read of the primary edge pass.
+struct MirrorSurfDiff {
+    SceneD sc; const int *active; VSlice v;
+    RDR_FN void operator()(int idx) const {
+        int p = active[idx];
+        if (v.shape[p] < 0) return;
+        RayDiff out;
+        surf_at(sc.shapes[v.shape[p]], v.tri[p], load_ray(v, p), load_rdiff(v, p), out);
+        st_rdiff(v.erd, v.n, p, out);
+    }
+};
+struct LoadLaneDiff {
+    const int *active; VSlice v;
+    RDR_FN void operator()(int idx) const {
+        int p = active[idx];
+        store_rdiff(v, p, ld_rdiff(v.erd, v.n, p));
     }
 };
 struct FillDouble { double *p; double value; RDR_FN void operator()(int i) const { p[i] = value; } };
@@ -97,8 +113,10 @@ struct SamplePrimaryEdges {
     SceneD sc; EdgeSceneD es; SobolD rng; int dim;
     const float *d_image; int nd, radiance_dim;
     PrimaryEdgeRec *recs; VSlice v;       // lanes 2*slot, 2*slot+1
+    double *multipliers;                  // [2P x nd] per-channel weights of the two rays, or null
     RDR_FN void operator()(int slot) const {
         int l0 = 2 * slot, l1 = 2 * slot + 1;
+        if (multipliers) for (int d = 0; d < 2 * nd; ++d) multipliers[(size_t)nd * l0 + d] = 0;
         PrimaryEdgeRec rec;
         rec.edge = EdgeD{-1, 0, 0, 0, 0};
         rec.edge_pt = v2(0, 0);
@@ -137,12 +155,20 @@ struct SamplePrimaryEdges {
         int vw = sc.cam.vp_x1 - sc.cam.vp_x0, vh = sc.cam.vp_y1 - sc.cam.vp_y0;
         int xi = iclamp(int(pt.x * sc.cam.width - sc.cam.vp_x0), 0, vw);
         int yi = iclamp(int(pt.y * sc.cam.height - sc.cam.vp_y0), 0, vh);
-        V3 dc = image_grad(d_image, nd, radiance_dim, yi * vw + xi);
+        V3 dc = radiance_dim >= 0 ? image_grad(d_image, nd, radiance_dim, yi * vw + xi) : v3(0);
         double pmf = es.primary_pmf[eid];
+        if (multipliers) {
+            for (int d = 0; d < nd; ++d) {
+                double dch = d_image[(size_t)nd * (yi * vw + xi) + d];
+                multipliers[(size_t)nd * l0 + d] = dch / pmf;
+                multipliers[(size_t)nd * l1 + d] = -dch / pmf;
+            }
+        }
         st3(v.thr, v.n, l0, 0, dc / pmf);
         st3(v.thr, v.n, l1, 0, -dc / pmf);
         primary_ray_with_diff(sc.cam, pt, rd);
-        store_rdiff(v, l0, rd); store_rdiff(v, l1, rd);
+        if (v.erd) st_rdiff(v.erd, v.n, slot, rd);            // [quirk] slot-indexed; lanes read theirs in LoadLaneDiff
+        else { store_rdiff(v, l0, rd); store_rdiff(v, l1, rd); }
     }
 };
 
@@ -664,6 +690,7 @@ struct SecEdgeFinish {
             brd.dir_dy = ddy - 2 * (-dot(wi, h) * c.sp.dn_dy + ddn_dy * h);
         }
         store_rdiff(ev, l0, brd); store_rdiff(ev, l1, brd);
+        if (ev.erd) { st_rdiff(ev.erd, ev.n, l0, brd); st_rdiff(ev.erd, ev.n, l1, brd); }
         V3 nt = ld3(a.v.thr, a.v.n, p, 0) * f * dc * ew / s.nee_pmf;
         st3(ev.thr, ev.n, l0, 0, nt);
         st3(ev.thr, ev.n, l1, 0, -nt);

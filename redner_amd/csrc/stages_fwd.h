@@ -33,7 +33,15 @@ struct VSlice {
     double *mrough;   // n     : running minimum roughness
     unsigned char *occl;   // n: the NEE shadow ray cast from this vertex was blocked
     int n;
+    // Edge sub-path slices only, and only when some texture has mip levels (otherwise null): the
+    // reference's single in-place `edge_ray_differentials` buffer (src/pathtracer.cpp:60), 12 x n.
+    // It is written per slot by the primary edge sampler but read per lane (src/edge.cpp:608 vs
+    // src/scene.cpp:585), so a primary edge ray starts from whatever differential an earlier stage
+    // left at its lane index.  Stages mirror every write the reference makes so that those stale
+    // reads see the same values.  [quirk]
+    double *erd;
 };
+RDR_FN void st_rdiff(double *b, int n, int i, const RayDiff &r);
 
 RDR_FN V3 ld3(const double *b, int n, int i, int k) { return V3{b[(size_t)(k) * n + i], b[(size_t)(k + 1) * n + i], b[(size_t)(k + 2) * n + i]}; }
 RDR_FN void st3(double *b, int n, int i, int k, V3 v) { b[(size_t)(k) * n + i] = v.x; b[(size_t)(k + 1) * n + i] = v.y; b[(size_t)(k + 2) * n + i] = v.z; }
@@ -43,10 +51,14 @@ RDR_FN void store_ray(const VSlice &v, int i, V3 o, V3 d) { st3(v.ray, v.n, i, 0
 RDR_FN RayDiff load_rdiff(const VSlice &v, int i) {
     return RayDiff{ld3(v.rdiff, v.n, i, 0), ld3(v.rdiff, v.n, i, 3), ld3(v.rdiff, v.n, i, 6), ld3(v.rdiff, v.n, i, 9)};
 }
-RDR_FN void store_rdiff(const VSlice &v, int i, const RayDiff &r) {
-    st3(v.rdiff, v.n, i, 0, r.org_dx); st3(v.rdiff, v.n, i, 3, r.org_dy);
-    st3(v.rdiff, v.n, i, 6, r.dir_dx); st3(v.rdiff, v.n, i, 9, r.dir_dy);
+RDR_FN void st_rdiff(double *b, int n, int i, const RayDiff &r) {
+    st3(b, n, i, 0, r.org_dx); st3(b, n, i, 3, r.org_dy);
+    st3(b, n, i, 6, r.dir_dx); st3(b, n, i, 9, r.dir_dy);
 }
+RDR_FN RayDiff ld_rdiff(const double *b, int n, int i) {
+    return RayDiff{ld3(b, n, i, 0), ld3(b, n, i, 3), ld3(b, n, i, 6), ld3(b, n, i, 9)};
+}
+RDR_FN void store_rdiff(const VSlice &v, int i, const RayDiff &r) { st_rdiff(v.rdiff, v.n, i, r); }
 
 RDR_FN void put_ray(rt::RayRec *q, int slot, const Ray &r, bool dead) {
     rt::RayRec rec;
@@ -57,11 +69,25 @@ RDR_FN void put_ray(rt::RayRec *q, int slot, const Ray &r, bool dead) {
 }
 
 // Where a stage deposits radiance: the image (camera paths) and/or a per-lane scalar (edge paths).
+constexpr int kMaxChannels = 16;
+constexpr int kMaxGeneric = 16;      // widest generic texture the G-buffer channels accept
+
+// Output channel list (src/channels.h:6-37): ids in request order, nd = total floats per pixel,
+// radiance_dim = offset of the radiance triple (-1 if not requested).
+// radiance_dim is the reference's `radiance_dimension`: the INDEX of the radiance channel in the channel list,
+// which path contributions and the edge estimators use as a dimension offset (src/channels.cpp:27,
+// src/path_contribution.cpp:126, src/edge.cpp:451) -- equal to the true offset only while every channel
+// before radiance is one float wide.  The first-hit emission uses the true offset, radiance_off.  [quirk]
+struct ChannelsD { int n; int id[kMaxChannels]; int nd, radiance_dim, radiance_off, max_generic; };
+
+// Where a stage deposits its result: the image (camera paths) and/or a per-lane scalar (edge paths).
 struct Sink {
     float *image;          // [num_pixels * nd], may be null
     double *edge_contrib;  // [lanes], may be null
     int nd, radiance_dim;  // channel layout (src/channels.cpp)
     double weight;         // 1 / spp
+    ChannelsD ch;
+    const double *multipliers;   // per lane x nd weights of the primary-edge estimator, or null
 };
 
 struct LightDraw { double light_sel, tri_sel; V2 uv; };
@@ -107,20 +133,107 @@ RDR_FN V3 direct_emission(const SceneD &sc, int shape, int tri, const Ray &ray, 
 
 // ---- stage: first-hit contribution -------------------------------------------------------------
 // Lanes: `active[idx]` (null = identity).  Records the hit ids of vertex `v` from queue slot idx.
+// Value of one non-radiance G-buffer channel at a first hit (src/primary_contribution.cpp:45-253).
+// Returns the number of components written to val (0: channel produces nothing here).
+RDR_FN int channel_value(const SceneD &sc, int channel, const ShapeD &sh, const Surf &sp, const Ray &ray,
+                         int shape_id, int tri_id, int max_generic, double *val) {
+    const MaterialD &m = sc.materials[sh.material_id];
+    switch (channel) {
+        case 1: val[0] = 1; return 1;                                                   // alpha
+        case 2: val[0] = len(sp.position - ray.org); return 1;                          // depth
+        case 3: val[0] = sp.position.x; val[1] = sp.position.y; val[2] = sp.position.z; return 3;
+        case 4: val[0] = sp.geom_normal.x; val[1] = sp.geom_normal.y; val[2] = sp.geom_normal.z; return 3;
+        case 5: {
+            V3 n = sp.frame.n;
+            if (has_normal_map(m)) n = perturbed_frame(m, sp).n;
+            val[0] = n.x; val[1] = n.y; val[2] = n.z; return 3;
+        }
+        case 6: val[0] = sp.uv.x; val[1] = sp.uv.y; return 2;
+        case 7: val[0] = sp.bary.x; val[1] = sp.bary.y; return 2;
+        case 8: { V3 r = m.use_vertex_color ? sp.color : tex3(m.diffuse, sp); val[0] = r.x; val[1] = r.y; val[2] = r.z; return 3; }
+        case 9: { V3 r = tex3(m.specular, sp); val[0] = r.x; val[1] = r.y; val[2] = r.z; return 3; }
+        case 10: val[0] = tex1(m.roughness, sp); return 1;
+        case 11: {
+            if (m.generic.num_levels <= 0) return 0;
+            tex_fetch(m.generic, sp.uv, sp.du_dxy, sp.dv_dxy, val);
+            return m.generic.channels;
+        }
+        case 12: val[0] = sp.color.x; val[1] = sp.color.y; val[2] = sp.color.z; return 3;
+        case 13: val[0] = shape_id; return 1;
+        case 14: val[0] = tri_id; return 1;
+        case 15: val[0] = sh.material_id; return 1;
+        default: return 0;
+    }
+}
+RDR_FN int channel_width(int channel, int max_generic) {
+    switch (channel) {
+        case 0: case 3: case 4: case 5: case 8: case 9: case 12: return 3;
+        case 6: case 7: return 2;
+        case 11: return max_generic;
+        default: return 1;
+    }
+}
+
+// First-hit contribution of lane p whose hit ids are (shape, tri): radiance (emission) plus every
+// requested G-buffer channel.  accumulate_primary_contribs, src/primary_contribution.cpp:6-436.
+RDR_FN void shade_first_hit(const SceneD &sc, const Sink &sink, const VSlice &v, int p, int shape, int tri) {
+    Ray ray = load_ray(v, p);
+    RayDiff rd = load_rdiff(v, p);
+    V3 e = direct_emission(sc, shape, tri, ray, rd);
+    V3 c = sink.weight * ld3(v.thr, v.n, p, 0) * e;
+    bool only_radiance = sink.ch.n == 1 && sink.ch.id[0] == 0;
+    if (only_radiance) {
+        if (sink.image) {
+            float *px = sink.image + (size_t)sink.nd * p + sink.radiance_dim;
+            px[0] += float(c.x); px[1] += float(c.y); px[2] += float(c.z);
+        }
+        if (sink.edge_contrib) sink.edge_contrib[p] += sum(c);
+        return;
+    }
+    Surf sp = surf_zero();
+    if (shape >= 0) { RayDiff tmp; sp = surf_at(sc.shapes[shape], tri, ray, rd, tmp); }
+    int d = 0;
+    for (int k = 0; k < sink.ch.n; ++k) {
+        int id = sink.ch.id[k];
+        int width = channel_width(id, sink.ch.max_generic);
+        if (id == 0) {
+            if (sink.image) {
+                float *px = sink.image + (size_t)sink.nd * p + d;
+                px[0] += float(c.x); px[1] += float(c.y); px[2] += float(c.z);
+            }
+            if (sink.edge_contrib) sink.edge_contrib[p] += sum(c);
+        } else if (shape >= 0) {
+            double val[kMaxGeneric];
+            int nv = channel_value(sc, id, sc.shapes[shape], sp, ray, shape, tri, sink.ch.max_generic, val);
+            bool is_id = id >= 13;
+            if (sink.image) {
+                float *px = sink.image + (size_t)sink.nd * p + d;
+                for (int j = 0; j < nv; ++j) {
+                    if (is_id) { px[j] = float(val[j]); continue; }      // ids: last sample wins
+                    double x = val[j] * sink.weight;
+                    if (sink.multipliers) x *= sink.multipliers[(size_t)sink.nd * p + d + j];
+                    px[j] += float(x);
+                }
+            }
+            if (sink.edge_contrib && sink.multipliers && !is_id) {
+                // [quirk] the edge estimator ignores the normal map for this channel (primary_contribution.cpp:306-316)
+                if (id == 5) { val[0] = sp.frame.n.x; val[1] = sp.frame.n.y; val[2] = sp.frame.n.z; }
+                double acc = 0;
+                for (int j = 0; j < nv; ++j) acc += (val[j] * sink.weight) * sink.multipliers[(size_t)sink.nd * p + d + j];
+                sink.edge_contrib[p] += acc;
+            }
+        }
+        d += width;
+    }
+}
+
 struct ShadePrimary {
     SceneD sc; const int *active; VSlice v; const rt::HitRec *hits; Sink sink;
     RDR_FN void operator()(int idx) const {
         int p = active ? active[idx] : idx;
         rt::HitRec h = hits[idx];
         v.shape[p] = h.shape; v.tri[p] = h.shape >= 0 ? h.prim : -1;
-        Ray ray = load_ray(v, p);
-        V3 e = direct_emission(sc, h.shape, h.prim, ray, load_rdiff(v, p));
-        V3 c = sink.weight * ld3(v.thr, v.n, p, 0) * e;
-        if (sink.image) {
-            float *px = sink.image + (size_t)sink.nd * p + sink.radiance_dim;
-            px[0] += float(c.x); px[1] += float(c.y); px[2] += float(c.z);
-        }
-        if (sink.edge_contrib) sink.edge_contrib[p] += sum(c);
+        shade_first_hit(sc, sink, v, p, h.shape, h.shape >= 0 ? h.prim : -1);
     }
 };
 
@@ -163,11 +276,13 @@ struct BounceSample {
         // BSDF ray
         V2 buv = v2(rng.draw(slot, dim + 4), rng.draw(slot, dim + 5));
         double bw = rng.draw(slot, dim + 6);
-        RayDiff wo_rd = raydiff_zero();
+        // a sampler that bails out (one-sided surface seen from behind) leaves the differential untouched
+        RayDiff wo_rd = vn.erd ? ld_rdiff(vn.erd, vn.n, p) : raydiff_zero();
         double next_mr;
         V3 dir = bsdf_sample_dir(*c.mat, c.sp, c.wi, buv, bw, c.mrough, c.rd_surf, wo_rd, next_mr);
         store_ray(vn, p, c.sp.position, dir);
         store_rdiff(vn, p, wo_rd);
+        if (vn.erd) st_rdiff(vn.erd, vn.n, p, wo_rd);
         vn.mrough[p] = next_mr;
         Ray nr = make_ray(c.sp.position, dir);
         put_ray(q_bsdf, idx, nr, len_sq(dir) <= 1e-3f);
@@ -254,6 +369,7 @@ struct BounceContrib {
         if (hb.shape >= 0) {
             RayDiff tmp;
             bp = surf_at(sc.shapes[hb.shape], hb.prim, load_ray(vn, p), load_rdiff(vn, p), tmp);
+            if (vn.erd) st_rdiff(vn.erd, vn.n, p, tmp);
         }
         V3 thr = ld3(v.thr, v.n, p, 0);
         BounceEval e = eval_bounce(sc, c, thr, !blocked, pk, lp, hb.shape, bp);

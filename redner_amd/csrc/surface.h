@@ -79,6 +79,7 @@ RDR_FN TriHit tri_hit(V3 p0, V3 p1, V3 p2, const Ray &ray, const RayDiff &rd) {
 RDR_FN void adj_tri_hit(V3 p0, V3 p1, V3 p2, const Ray &ray, const RayDiff &rd,
                         V3 uvt_bar, V2 udxy_bar, V2 vdxy_bar, V2 tdxy_bar,
                         V3 &p0_bar, V3 &p1_bar, V3 &p2_bar, DRay &ray_bar, RayDiff &rd_bar) {
+    RDR_CONTRACT_FAST
     V3 e1 = p1 - p0, e2 = p2 - p0;
     V3 pv = cross(ray.dir, e2), pv_x = cross(rd.dir_dx, e2), pv_y = cross(rd.dir_dy, e2);
     double div = clamp_divisor(dot(pv, e1));
@@ -231,6 +232,7 @@ RDR_FN TriGrad trigrad_zero() {
 RDR_FN void adj_surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff &rd,
                         const Surf &sp_bar, const RayDiff &new_rd_bar,
                         DRay &ray_bar, RayDiff &rd_bar, TriGrad &g) {
+    RDR_CONTRACT_FAST
     TriVerts tv = load_tri(sh, tri);
     TriAttr at = load_attr(sh, tri, tv);
     TriHit h = tri_hit(tv.p0, tv.p1, tv.p2, ray, rd);

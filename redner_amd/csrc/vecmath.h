@@ -13,6 +13,18 @@
 #include <math.h>
 #include <stdint.h>
 
+// Floating-point contract.  The device build runs with -ffp-contract=off because the geometric
+// predicates of the edge estimators (silhouette tests, LTC-space clipping) evaluate quantities that
+// are exactly zero up to rounding for edges lying in the shading point's own plane, so their sign --
+// and with it which edge a sample picks -- must be rounded exactly like the reference's CPU build.
+// Functions whose results only enter continuous quantities (BSDF values, adjoints) opt back in to
+// fused multiply-add with RDR_CONTRACT_FAST as their first statement.
+#if defined(__clang__)
+#define RDR_CONTRACT_FAST _Pragma("clang fp contract(fast)")
+#else
+#define RDR_CONTRACT_FAST
+#endif
+
 namespace rdr {
 
 struct V2 { double x, y; };

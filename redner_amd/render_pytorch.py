@@ -73,7 +73,7 @@ class Texture:
 
 class Material:
     def __init__(self, diffuse_reflectance=None, specular_reflectance=None, roughness=None,
-                 two_sided=False, use_vertex_color=False):
+                 generic_texture=None, normal_map=None, two_sided=False, use_vertex_color=False):
         def tex(t, default):
             if t is None:
                 t = torch.tensor(default)
@@ -83,6 +83,9 @@ class Material:
         self.compute_specular_lighting = specular_reflectance is not None
         self.specular_reflectance = tex(specular_reflectance, [0.0, 0.0, 0.0])
         self.roughness = tex(roughness, [1.0])
+        # optional (pyredner/material.py): N-channel texture for the generic_texture channel, RGB normal map
+        self.generic_texture = tex(generic_texture, None) if generic_texture is not None else None
+        self.normal_map = tex(normal_map, None) if normal_map is not None else None
         self.two_sided = two_sided
         self.use_vertex_color = use_vertex_color
 
@@ -172,6 +175,11 @@ class RenderFunction(torch.autograd.Function):
                 tex = getattr(m, name)
                 mm[name] = {'levels': [put(l, device) for l in tex.mipmap], 'constant': tex.constant,
                             'uv_scale': put(tex.uv_scale, device)}
+            for name in ('generic_texture', 'normal_map'):
+                tex = getattr(m, name)
+                mm[name] = None if tex is None else {
+                    'levels': [put(l, device) for l in tex.mipmap], 'constant': tex.constant,
+                    'uv_scale': put(tex.uv_scale, device)}
             meta['materials'].append(mm)
         meta['lights'] = [{'shape_id': l.shape_id, 'intensity': put(l.intensity, cpu), 'two_sided': l.two_sided,
                            'directly_visible': l.directly_visible} for l in scene.area_lights]
@@ -219,6 +227,8 @@ class RenderFunction(torch.autograd.Function):
         u.materials = []
 
         def make_tex(cls, tm):
+            if tm is None:
+                return cls([], [], [], 0, rd.float_ptr(0))
             levels = [T(i) for i in tm['levels']]
             if tm['constant']:
                 return cls([fp(levels[0])], [0], [0], int(levels[0].shape[0]), fp(T(tm['uv_scale'])))
@@ -229,8 +239,8 @@ class RenderFunction(torch.autograd.Function):
             u.materials.append(rd.Material(make_tex(rd.Texture3, mm['diffuse_reflectance']),
                                            make_tex(rd.Texture3, mm['specular_reflectance']),
                                            make_tex(rd.Texture1, mm['roughness']),
-                                           rd.TextureN([], [], [], 0, rd.float_ptr(0)),
-                                           rd.Texture3([], [], [], 0, rd.float_ptr(0)),
+                                           make_tex(rd.TextureN, mm['generic_texture']),
+                                           make_tex(rd.Texture3, mm['normal_map']),
                                            mm['compute_specular_lighting'], mm['two_sided'], mm['use_vertex_color']))
         u.area_lights = [rd.AreaLight(lm['shape_id'], fp(T(lm['intensity'])), lm['two_sided'], lm['directly_visible'])
                          for lm in meta['lights']]
@@ -291,6 +301,8 @@ class RenderFunction(torch.autograd.Function):
                     for sm in meta['shapes']]
 
         def d_tex(cls, tm):
+            if tm is None:
+                return cls([], [], [], 0, rd.float_ptr(0))
             levels = [zeros_like_arg(i) for i in tm['levels']]
             sc = zeros_like_arg(tm['uv_scale'])
             if tm['constant']:
@@ -301,8 +313,8 @@ class RenderFunction(torch.autograd.Function):
         d_materials = [rd.DMaterial(d_tex(rd.Texture3, mm['diffuse_reflectance']),
                                     d_tex(rd.Texture3, mm['specular_reflectance']),
                                     d_tex(rd.Texture1, mm['roughness']),
-                                    rd.TextureN([], [], [], 0, rd.float_ptr(0)),
-                                    rd.Texture3([], [], [], 0, rd.float_ptr(0))) for mm in meta['materials']]
+                                    d_tex(rd.TextureN, mm['generic_texture']),
+                                    d_tex(rd.Texture3, mm['normal_map'])) for mm in meta['materials']]
         d_lights = [rd.DAreaLight(fp(zeros_like_arg(lm['intensity']))) for lm in meta['lights']]
         index = device.index if device.index is not None else 0
         d_scene = rd.DScene(d_camera, d_shapes, d_materials, d_lights, None, device.type == 'cuda', index)

@@ -72,15 +72,34 @@ def export_bunny_box():
     print('bunny_box_scene.npz: %d shapes, %d triangles' % (len(scene.shapes), sum(s.indices.shape[0] for s in scene.shapes)))
 
 
-# name -> (scene builder, resolution, spp, max_bounces)
+ALL_CHANNELS = ['radiance', 'alpha', 'depth', 'position', 'geometry_normal', 'shading_normal', 'uv',
+                'barycentric_coordinates', 'diffuse_reflectance', 'specular_reflectance', 'roughness',
+                'generic_texture', 'vertex_color', 'shape_id', 'triangle_id', 'material_id']
+
+EDGE_SAFE_CHANNELS = [c for c in ALL_CHANNELS if c not in ('barycentric_coordinates', 'generic_texture')]
+
+# name -> (scene builder, resolution, spp, max_bounces[, channel names[, serialize_scene options]])
 CASES = {
     'single_triangle_64x64x4': ('single_triangle', 64, 4, 1),
     'two_triangles_64x64x16': ('two_triangles', 64, 16, 1),
     'bunny_box_32x32x4': ('bunny_box', 32, 4, 4),
+    # every output channel at once (tests/test_g_buffer.py renders them in groups) + mip-mapped textures
+    'textured_sphere_gbuffer_48x48x4': ('textured_sphere', 48, 4, 1, EDGE_SAFE_CHANNELS),
+    # The reference itself cannot run these two channels with edge sampling: its generic-texture scratch is
+    # sized for num_pixels lanes but the edge pass indexes 2*num_pixels (src/pathtracer.cpp:103 vs :829,
+    # heap overflow), and barycentric_coordinates segfaults in its edge pass.  Pinned without edge sampling.
+    # radiance after a 3-wide channel: the reference adds path contributions at the channel INDEX (src/channels.cpp:27)
+    'textured_sphere_radiance_last_48x48x2': ('textured_sphere', 48, 2, 2, ['position', 'radiance']),
+    'textured_sphere_generic_48x48x4': ('textured_sphere', 48, 4, 1,
+                                        ['radiance', 'barycentric_coordinates', 'generic_texture'],
+                                        {'use_primary_edge_sampling': False, 'use_secondary_edge_sampling': False}),
+    # render_albedo/render_g_buffer style: no radiance, no bounces (pyredner/render_utils.py)
+    'textured_sphere_albedo_48x48x4': ('textured_sphere', 48, 4, 0,
+                                       ['depth', 'shading_normal', 'diffuse_reflectance', 'uv']),
 }
 
 
-def render_case(backend, builder, res, spp, mb, device=torch.device('cpu'), grad_mode='sum'):
+def render_case(backend, builder, res, spp, mb, channels=None, opts=None, device=torch.device('cpu')):
     """Forward + backward of one case; returns {'image': ..., 'grad_<i>_<name>': ...}."""
     import scenes
     from redner_amd.render_pytorch import RenderFunction
@@ -91,34 +110,58 @@ def render_case(backend, builder, res, spp, mb, device=torch.device('cpu'), grad
         m.diffuse_reflectance.mipmap[0].requires_grad_(True)
     if sc.camera.position is not None:
         sc.camera.position.requires_grad_(True)
-    args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=backend.SamplerType.sobol, device=device,
-                                          backend=backend)
+    ch = None if channels is None else [getattr(backend.channels, c) for c in channels]
+    args = RenderFunction.serialize_scene(sc, spp, mb, channels=ch, sampler_type=backend.SamplerType.sobol,
+                                          device=device, backend=backend, **(opts or {}))
     img = RenderFunction.apply(1, *args)
     out = {'image': img.detach().cpu().numpy()}
     # upstream gradient: a fixed smooth pattern so every pixel/channel has a distinct weight
     h, w, c = img.shape
     yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
-    up = torch.stack([1.0 + 0.5 * torch.sin(0.37 * xx + 0.11 * yy), 1.0 + 0.5 * torch.cos(0.23 * yy),
-                      1.0 - 0.3 * torch.sin(0.19 * (xx + yy))], dim=2).to(img.device)
+    base = [1.0 + 0.5 * torch.sin(0.37 * xx + 0.11 * yy), 1.0 + 0.5 * torch.cos(0.23 * yy),
+            1.0 - 0.3 * torch.sin(0.19 * (xx + yy))]
+    up = torch.stack([base[k % 3] * (1.0 + 0.25 * (k // 3)) for k in range(c)], dim=2).to(img.device)
     (img * up).sum().backward()
+
+    def grab(key, t):
+        if t is not None and t.grad is not None:
+            out[key] = t.grad.cpu().numpy()
     for i, sh in enumerate(sc.shapes):
-        if sh.vertices.grad is not None:
-            out['grad_shape%d_vertices' % i] = sh.vertices.grad.cpu().numpy()
+        grab('grad_shape%d_vertices' % i, sh.vertices)
+        for name in ('uvs', 'normals', 'colors'):
+            grab('grad_shape%d_%s' % (i, name), getattr(sh, name))
     for i, l in enumerate(sc.area_lights):
-        out['grad_light%d_intensity' % i] = l.intensity.grad.cpu().numpy()
+        grab('grad_light%d_intensity' % i, l.intensity)
     for i, m in enumerate(sc.materials):
-        out['grad_mat%d_diffuse' % i] = m.diffuse_reflectance.mipmap[0].grad.cpu().numpy()
+        grab('grad_mat%d_diffuse' % i, m.diffuse_reflectance.mipmap[0])
+        for name, tex in (('diffuse', m.diffuse_reflectance), ('specular', m.specular_reflectance),
+                          ('roughness', m.roughness), ('generic', m.generic_texture), ('normal_map', m.normal_map)):
+            if tex is None:
+                continue
+            for lv, t in enumerate(tex.mipmap):
+                if name != 'diffuse' or lv > 0:
+                    grab('grad_mat%d_%s_L%d' % (i, name, lv), t)
     if sc.camera.position is not None:
-        out['grad_cam_position'] = sc.camera.position.grad.cpu().numpy()
+        grab('grad_cam_position', sc.camera.position)
     return out
 
 
 def main():
+    # The reference's primary-edge pass reads ray differentials from a scratch buffer at indices it never
+    # wrote (slot- vs lane-indexed, src/edge.cpp:608 vs src/scene.cpp:585), i.e. whatever malloc returned.
+    # Force every large allocation onto fresh zero pages so the fixtures do not depend on heap history;
+    # this only matters for scenes with mip-mapped textures.  glibc reads the variable at start-up.
+    if os.environ.get('MALLOC_MMAP_THRESHOLD_') != '65536':
+        os.environ['MALLOC_MMAP_THRESHOLD_'] = '65536'
+        os.execv(sys.executable, [sys.executable] + sys.argv)
     if not os.path.exists(os.path.join(HERE, 'bunny_box_scene.npz')) or '--scene' in sys.argv:
         export_bunny_box()
     ref = oracle_util.load_oracle()
-    for name, (builder, res, spp, mb) in CASES.items():
-        out = render_case(ref, builder, res, spp, mb)
+    only = [a for a in sys.argv[1:] if not a.startswith('--')]
+    for name, case in CASES.items():
+        if only and name not in only:
+            continue
+        out = render_case(ref, *case)
         np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
         print(name, {k: v.shape for k, v in out.items()})
 

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import torch
 
-from redner_amd.render_pytorch import Camera, Shape, Material, AreaLight, Scene
+from redner_amd.render_pytorch import Camera, Shape, Material, AreaLight, Scene, Texture
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -81,3 +81,70 @@ def bunny_box(device, resolution=(512, 512), vertex_grad=True):
     if vertex_grad:
         shapes[int(z['bunny_shape_id'])].vertices.requires_grad_(True)
     return Scene(cam, shapes, mats, lights)
+
+
+def _mip_chain(base):
+    """Box-filtered mip levels down to 1x1 ([H, W, C] tensors); stands in for pyredner.Texture's
+    own generation (pyredner/texture.py), which is host-side Python outside the hot path."""
+    levels = [base.contiguous()]
+    while levels[-1].shape[0] > 1 or levels[-1].shape[1] > 1:
+        t = levels[-1].permute(2, 0, 1)[None]
+        t = torch.nn.functional.avg_pool2d(t, 2, ceil_mode=True)
+        levels.append(t[0].permute(1, 2, 0).contiguous())
+    return levels
+
+
+def _procedural(h, w, c, phase, lo=0.1, hi=0.9):
+    yy, xx = np.meshgrid(np.arange(h) / h, np.arange(w) / w, indexing='ij')
+    chans = [0.5 + 0.5 * np.sin(2 * np.pi * ((k + 1) * xx + (k + 2) * 0.5 * yy) + phase + 0.7 * k) for k in range(c)]
+    return (lo + (hi - lo) * np.stack(chans, axis=2)).astype(np.float32)
+
+
+def textured_sphere(device, resolution=(48, 48)):
+    """G-buffer / mip-mapped texture scene in the spirit of tests/test_g_buffer.py and
+    tests/test_texture.py: a UV sphere with smooth normals, uvs, vertex colours and mip-mapped
+    diffuse / roughness / generic textures in front of a normal-mapped wall, one area light."""
+    cam = Camera(position=_t([0.3, 0.2, -5.0], 'cpu'), look_at=_t([0.0, 0.0, 0.0], 'cpu'),
+                 up=_t([0.0, 1.0, 0.0], 'cpu'), fov=_t([45.0], 'cpu'), clip_near=1e-2, resolution=resolution)
+    nu, nv, radius = 12, 8, 1.3
+    verts, uvs, cols = [], [], []
+    for j in range(nv + 1):
+        th = np.pi * j / nv
+        for i in range(nu + 1):
+            ph = 2 * np.pi * i / nu
+            verts.append([radius * np.sin(th) * np.cos(ph), radius * np.cos(th), radius * np.sin(th) * np.sin(ph)])
+            uvs.append([i / nu, j / nv])
+            cols.append([0.5 + 0.4 * np.cos(ph), 0.5 + 0.4 * np.sin(th), 0.5 + 0.4 * np.sin(ph + th)])
+    tris = []
+    for j in range(nv):
+        for i in range(nu):
+            a, b = j * (nu + 1) + i, j * (nu + 1) + i + 1
+            c, d = a + nu + 1, b + nu + 1
+            if j > 0:
+                tris.append([a, b, c])
+            if j < nv - 1:
+                tris.append([b, d, c])
+    verts = np.asarray(verts, np.float32)
+    normals = verts / np.linalg.norm(verts, axis=1, keepdims=True)
+    sphere = Shape(_t(verts, device, grad=True), _t(tris, device, torch.int32), 0,
+                   uvs=_t(np.asarray(uvs, np.float32), device, grad=True), normals=_t(normals, device, grad=True),
+                   colors=_t(np.asarray(cols, np.float32), device, grad=True))
+    wall = Shape(_t([[-3.0, -3.0, 2.5], [3.0, -3.0, 2.5], [-3.0, 3.0, 2.2], [3.0, 3.0, 2.2]], device, grad=True),
+                 _t([[0, 2, 1], [1, 2, 3]], device, torch.int32), 1,
+                 uvs=_t([[0.0, 0.0], [2.0, 0.0], [0.0, 2.0], [2.0, 2.0]], device))
+    light = Shape(_t([[-1.0, -1.0, -7.0], [1.0, -1.0, -7.0], [-1.0, 1.0, -7.0], [1.0, 1.0, -7.0]], device),
+                  _t([[0, 1, 2], [1, 3, 2]], device, torch.int32), 2)
+
+    def mips(arr, grad=True):
+        levels = _mip_chain(torch.from_numpy(arr))
+        return [l.to(device).requires_grad_(grad) for l in levels]
+
+    nm = _procedural(16, 16, 3, 0.3, 0.35, 0.65)
+    nm[..., 2] = 0.9                                   # mostly +z tangent-space normals
+    mats = [Material(diffuse_reflectance=Texture(mips(_procedural(32, 32, 3, 0.0)), uv_scale=_t([2.0, 1.0], device)),
+                     specular_reflectance=_t([0.15, 0.2, 0.25], device, grad=True),
+                     roughness=Texture(mips(_procedural(16, 16, 1, 1.0, 0.2, 0.7))),
+                     generic_texture=Texture(mips(_procedural(8, 8, 5, 2.0)))),
+            Material(diffuse_reflectance=_t([0.6, 0.55, 0.5], device, grad=True), normal_map=Texture(mips(nm))),
+            Material(diffuse_reflectance=_t([0.0, 0.0, 0.0], device))]
+    return Scene(cam, [sphere, wall, light], mats, [AreaLight(2, _t([25.0, 25.0, 25.0], 'cpu'))])

@@ -16,8 +16,7 @@ TOL = 1e-4
 
 
 def _check(backend, device, name):
-    builder, res, spp, mb = CASES[name]
-    out = render_case(backend, builder, res, spp, mb, device=device)
+    out = render_case(backend, *CASES[name], device=device)
     gold = np.load(os.path.join(GOLD, name + '.npz'))
     assert set(out.keys()) == set(gold.files)
     worst = 0.0

@@ -8,28 +8,28 @@ import pytest
 import torch
 
 import scenes
+from golden.make_golden import CASES as GOLDEN_CASES
 from oracle_util import rel_l2
 from redner_amd.render_pytorch import RenderFunction
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-CASES = [('single_triangle_64x64x4', 'single_triangle', 64, 4, 1),
-         ('two_triangles_64x64x16', 'two_triangles', 64, 16, 1),
-         ('bunny_box_32x32x4', 'bunny_box', 32, 4, 4)]
+CASES = [(name,) + tuple(case) for name, case in GOLDEN_CASES.items()]
 TOL = 1e-4
 
 
-def _render(backend, device, builder, res, spp, mb):
+def _render(backend, device, builder, res, spp, mb, channels=None, opts=None):
     sc = getattr(scenes, builder)(device, resolution=(res, res))
-    args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=backend.SamplerType.sobol, device=device,
-                                          backend=backend)
+    ch = None if channels is None else [getattr(backend.channels, c) for c in channels]
+    args = RenderFunction.serialize_scene(sc, spp, mb, channels=ch, sampler_type=backend.SamplerType.sobol,
+                                          device=device, backend=backend, **(opts or {}))
     with torch.no_grad():
         return RenderFunction.apply(1, *args)
 
 
 @pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
 def test_forward_hostsim(hostsim_backend, case):
-    name, builder, res, spp, mb = case
-    img = _render(hostsim_backend, torch.device('cpu'), builder, res, spp, mb)
+    img = _render(hostsim_backend, torch.device('cpu'), *case[1:])
+    name = case[0]
     gold = torch.from_numpy(np.load(os.path.join(GOLD, name + '.npz'))['image'])
     assert rel_l2(img, gold) < TOL
 
@@ -37,8 +37,8 @@ def test_forward_hostsim(hostsim_backend, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
 def test_forward_gpu(gpu_backend, case):
-    name, builder, res, spp, mb = case
-    img = _render(gpu_backend, torch.device('cuda:0'), builder, res, spp, mb)
+    img = _render(gpu_backend, torch.device('cuda:0'), *case[1:])
+    name = case[0]
     gold = torch.from_numpy(np.load(os.path.join(GOLD, name + '.npz'))['image'])
     assert torch.isfinite(img).all()
     assert rel_l2(img, gold) < TOL
