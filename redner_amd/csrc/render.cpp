@@ -73,8 +73,14 @@ ChannelLayout layout_of(const rdr_render_options &o, int max_generic) {
     return l;
 }
 
+// PCG streams are stateful, so a shard that starts at sample k > 0 cannot reproduce the single-process stream
+// (how far it has advanced depends on the earlier samples); shards draw from their own seeds instead.
+uint64_t pcg_stream_seed(const rdr_render_options &o) {
+    return (uint64_t)o.seed + (uint64_t)o.sample_offset * 0x9E3779B97F4A7C15ULL;
+}
+
 // One NEE + BSDF bounce over the live lanes of `v`; fills `vn` and the next live-lane list.
-int run_bounce(const Scene &scene, const SobolD &rng, int dim, int rng_shift,
+int run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng_shift,
                const int *active, int num_active, const VSlice &v, const VSlice &vn,
                const Queues &q, const Sink &sink, int *next_active) {
     exec::launch(num_active, BounceSample{scene.d, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
@@ -200,6 +206,7 @@ struct Backward {
     AdjState adj;
 
     ChannelsD ch;
+    uint64_t *pcg_edge = nullptr;      // PCG edge sampler: one state per slot (src/pathtracer.cpp:221-222)
     double *multipliers = nullptr;     // [2P x nd], primary-edge channel weights (non-radiance channels only)
 
     Backward(const Scene &scene_, const rdr_render_options &opt_, const rdr_dscene_desc &ds, int P_, int B_,
@@ -230,6 +237,10 @@ struct Backward {
             sec_picks = arena.get<SecPick>(P);
             sec_mode = arena.get<unsigned char>(P);
             if (!(ch.n == 1 && ch.id[0] == 0)) multipliers = arena.get<double>((size_t)L * nd);
+            if (opt.sampler_type == RDR_SAMPLER_INDEPENDENT) {
+                pcg_edge = arena.get<uint64_t>(P);
+                exec::launch(P, PcgInit{pcg_edge, pcg_stream_seed(opt) + 131071U});
+            }
         }
     }
 
@@ -243,8 +254,14 @@ struct Backward {
 
     // Path-trace the live edge lanes to the end, starting with `n_act` lanes listed in elist[1]
     // whose current vertex is in `ea`.  Returns the number of Sobol' dimensions consumed.
-    int trace_edge_paths(const SobolD &rng_edge, int edim, int n_act, int first_depth, const Queues &q, const Sink &sink,
-                         bool need_lights) {
+    // PCG edge sampler: the states of slots [0, n) move on by `count` numbers (one next_*_samples call group)
+    void edge_rng_consumed(int n, int count) {
+        if (pcg_edge) exec::launch(n, PcgAdvance{pcg_edge, count});
+    }
+    SamplerD edge_rng_at(const SamplerD &rng_edge, int edim) const { SamplerD r = rng_edge; r.pcg_base = edim; return r; }
+
+    int trace_edge_paths(const SamplerD &rng_edge, int edim, int n_act, int n_slots, int first_depth, const Queues &q,
+                         const Sink &sink, bool need_lights) {
         int used = 0;
         const bool has_lights = scene.d.num_lights > 0;
         int cur = 1;
@@ -252,16 +269,17 @@ struct Backward {
             const VSlice &m = (k % 2 == 0) ? ea : eb;
             const VSlice &nx = (k % 2 == 0) ? eb : ea;
             int nxt = (cur == 1) ? 2 : 1;
-            n_act = run_bounce(scene, rng_edge, edim + used, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt]);
+            n_act = run_bounce(scene, edge_rng_at(rng_edge, edim + used), edim + used, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt]);
+            edge_rng_consumed(n_slots, 7);
             cur = nxt;
             used += 7;
         }
         return used;
     }
 
-    void run_sample(int sample_id, std::vector<VSlice> &vs, int *active, std::vector<int> &num_active, const Queues &q) {
-        SobolD rng{scene.sobol_table, opt.seed, sample_id};
-        SobolD rng_edge{scene.sobol_table, opt.seed + 131071U, sample_id};   // src/pathtracer.cpp:221-227
+    void run_sample(int sample_id, const SamplerD &main_rng, std::vector<VSlice> &vs, int *active, std::vector<int> &num_active, const Queues &q) {
+        SamplerD rng = main_rng;
+        SamplerD rng_edge{scene.sobol_table, opt.seed + 131071U, sample_id, pcg_edge, 0};   // src/pathtracer.cpp:221-227
         const bool has_lights = scene.d.num_lights > 0;
         const bool edges_on = prim_recs != nullptr;
         Sink esink{nullptr, edge_contrib, nd, radiance_dim, weight, ch, nullptr};
@@ -282,7 +300,7 @@ struct Backward {
                 // ---- secondary (shadow / inter-reflection) edges at this vertex, :500-706 ----
                 const EdgeSceneD &es = scene.edges->d;
                 const int lanes = 2 * nA;
-                SecEdgeArgs sa{scene.d, es, rng, dim0 + 7 * d, rng_edge, edim, act, vs[d]};
+                SecEdgeArgs sa{scene.d, es, rng, dim0 + 7 * d, edge_rng_at(rng_edge, edim), edim, act, vs[d]};
                 exec::launch(nA, SecEdgeSetup{sa, sec_mode, sec_recs, sec_picks, ea, edge_tmin});
                 int nH = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 1});
                 exec::launch(nH, SecEdgePickH{sa, elist[0], sec_picks});
@@ -290,6 +308,7 @@ struct Backward {
                 exec::launch(nN, SecEdgePickN{sa, elist[0], sec_picks});
                 exec::launch(nA, SecEdgeFinish{sa, sec_mode, sec_picks, d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});
                 edim += 4;
+                edge_rng_consumed(nA, 4);
                 int n0 = exec::compact((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
                 exec::launch(n0, QueueRays{elist[0], ea, edge_tmin, q.bsdf});
                 exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
@@ -299,7 +318,7 @@ struct Backward {
                 exec::zero(edge_contrib, sizeof(double) * lanes);
                 exec::launch(n0, ShadeRecorded{scene.d, elist[0], ea, esink});
                 int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
-                edim += trace_edge_paths(rng_edge, edim, n1, d + 1, q, esink, false);
+                edim += trace_edge_paths(rng_edge, edim, n1, nA, d + 1, q, esink, false);
                 exec::launch(nA, SecondaryEdgeDerivatives{scene.d, grads.g, act, sec_recs, hit_pos, ea.n, edge_contrib, adj});
             }
         }
@@ -310,8 +329,9 @@ struct Backward {
             const EdgeSceneD &es = scene.edges->d;
             const int lanes = 2 * P;
             exec::zero(edge_contrib, sizeof(double) * lanes);
-            exec::launch(P, SamplePrimaryEdges{scene.d, es, rng_edge, edim, d_image, nd, radiance_dim, prim_recs, ea, multipliers});
+            exec::launch(P, SamplePrimaryEdges{scene.d, es, edge_rng_at(rng_edge, edim), edim, d_image, nd, radiance_dim, prim_recs, ea, multipliers});
             edim += 2;
+            edge_rng_consumed(P, 2);
             int n0 = exec::compact((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
             if (ea.erd) exec::launch(n0, LoadLaneDiff{elist[0], ea});
             exec::launch(n0, QueueRays{elist[0], ea, nullptr, q.bsdf});
@@ -319,7 +339,7 @@ struct Backward {
             exec::launch(n0, ShadePrimary{scene.d, elist[0], ea, q.h_bsdf, psink});
             if (ea.erd) exec::launch(n0, MirrorSurfDiff{scene.d, elist[0], ea});
             int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
-            edim += trace_edge_paths(rng_edge, edim, n1, 0, q, esink, true);
+            edim += trace_edge_paths(rng_edge, edim, n1, P, 0, q, esink, true);
             exec::launch(P, PrimaryEdgeDerivatives{scene.d, grads.g, prim_recs, edge_contrib, screen_grad});
         }
     }
@@ -330,8 +350,8 @@ struct Backward {
 
 void render(const Scene &scene, const rdr_render_options &opt, float *image, const float *d_image,
             const rdr_dscene_desc *d_scene, float *screen_gradient_image, float * /*debug_image*/) {
-    if (opt.sampler_type != RDR_SAMPLER_SOBOL)
-        throw std::runtime_error("render: only SamplerType.sobol is implemented (independent/PCG: SURVEY.md section 8f row 4)");
+    if (opt.sampler_type != RDR_SAMPLER_SOBOL && opt.sampler_type != RDR_SAMPLER_INDEPENDENT)
+        throw std::runtime_error("render: unknown sampler type");
     if (d_image && !d_scene) throw std::runtime_error("render: d_rendered_image given without d_scene");
     const CameraD &cam = scene.d.cam;
     const int P = (cam.vp_x1 - cam.vp_x0) * (cam.vp_y1 - cam.vp_y0);
@@ -345,7 +365,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     const int total_spp = opt.total_samples > 0 ? opt.total_samples : opt.num_samples;
     const double weight = 1.0 / total_spp;
     const bool has_lights = scene.d.num_lights > 0;
-    if (2 + 7 * B > kSobolDims) throw std::runtime_error("render: max_bounces exceeds the Sobol' table");
+    if (2 + 7 * B > kSamplerDims) throw std::runtime_error("render: max_bounces exceeds the Sobol' table");
 
     Arena arena;
     std::vector<VSlice> vs(B + 1);
@@ -359,9 +379,15 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     std::unique_ptr<Backward> bwd;
     if (d_image) bwd.reset(new Backward(scene, opt, *d_scene, P, B, d_image, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch));
 
+    uint64_t *pcg_main = nullptr;
+    if (opt.sampler_type == RDR_SAMPLER_INDEPENDENT) {
+        pcg_main = arena.get<uint64_t>(P);
+        exec::launch(P, PcgInit{pcg_main, pcg_stream_seed(opt)});
+    }
+
     for (int s = 0; s < opt.num_samples; ++s) {
         const int sample_id = opt.sample_offset + s;
-        SobolD rng{scene.sobol_table, opt.seed, sample_id};
+        SamplerD rng{scene.sobol_table, opt.seed, sample_id, pcg_main, 0};
         Sink sink{image, nullptr, lay.nd, lay.radiance_dim, weight, lay.ch, nullptr};
 
         // ---- camera vertex ----
@@ -379,7 +405,8 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
             dim += 7;
         }
 
-        if (bwd) bwd->run_sample(sample_id, vs, active, num_active, q);
+        if (bwd) bwd->run_sample(sample_id, rng, vs, active, num_active, q);
+        if (pcg_main) exec::launch(P, PcgAdvance{pcg_main, dim});     // every slot drew `dim` numbers this sample
     }
     if (bwd) bwd->flush();
     exec::sync();

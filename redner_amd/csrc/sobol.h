@@ -12,8 +12,8 @@
 namespace rdr {
 
 constexpr int kSobolBits = 52;
-constexpr int kSobolDims = 1024;
-constexpr int kSobolTableWords = kSobolBits * kSobolDims;
+constexpr int kSamplerDims = 1024;
+constexpr int kSobolTableWords = kSobolBits * kSamplerDims;
 
 RDR_FN uint64_t hash64shift(uint64_t key) {
     key = (~key) + (key << 21);
@@ -35,14 +35,61 @@ RDR_FN double sobol_value(const uint64_t *matrices, uint64_t index, uint32_t dim
     return r * (1.0 / (1ULL << kSobolBits));
 }
 
-// One sampler "view": which table, which sample of the sequence, which seed.
-struct SobolD {
+// ---- PCG32 ("independent" sampler) -----------------------------------------------------------------
+// Behavioural spec: src/pcg_sampler.cpp:8-50 (XSH-RR output, per-slot stream inc = 2*(slot+1)+1, seeding),
+// :76-146 (every next_*_samples call advances the state of each slot in the view by 2/4/3/2/4 numbers).
+// The reference stores the drawn numbers; here a number is regenerated from the slot's state at the start
+// of the current draw group plus a skip-ahead, so stages stay stateless and the host advances the states.
+constexpr uint64_t kPcgMult = 6364136223846793005ULL;
+RDR_FN uint64_t pcg_inc(int slot) { return ((((uint64_t)slot + 1) << 1u) | 1u); }
+RDR_FN uint64_t pcg_step(uint64_t state, uint64_t inc) { return state * kPcgMult + (inc | 1); }
+RDR_FN uint64_t pcg_seed_state(uint64_t seed, int slot) {
+    uint64_t inc = pcg_inc(slot);
+    uint64_t st = pcg_step(0U, inc);
+    st += (0x853c49e6748fea9bULL + seed);
+    return pcg_step(st, inc);
+}
+RDR_FN uint64_t pcg_advance(uint64_t state, uint64_t inc, uint32_t delta) {     // O(log delta) LCG skip-ahead
+    uint64_t acc_mult = 1, acc_plus = 0, cur_mult = kPcgMult, cur_plus = inc | 1;
+    while (delta > 0) {
+        if (delta & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+        cur_plus = (cur_mult + 1) * cur_plus;
+        cur_mult *= cur_mult;
+        delta >>= 1;
+    }
+    return acc_mult * state + acc_plus;
+}
+RDR_FN double pcg_output_double(uint64_t oldstate) {
+    uint32_t xorshifted = uint32_t(((oldstate >> 18u) ^ oldstate) >> 27u);
+    uint32_t rot = uint32_t(oldstate >> 59u);
+    uint32_t u = uint32_t((xorshifted >> rot) | (xorshifted << ((-rot) & 31)));
+    union { uint64_t u; double d; } x;
+    x.u = ((uint64_t)u << 20) | 0x3ff0000000000000ULL;
+    return x.d - 1.0;
+}
+
+// One sampler "view".  Sobol': which table, which sample of the sequence, which seed.  PCG (pcg_state != null):
+// per-slot states valid for dimension `pcg_base`; draw(slot, dim) is the (dim - pcg_base)-th number after it.
+struct SamplerD {
     const uint64_t *matrices;
     uint64_t seed;
     int sample_id;
+    const uint64_t *pcg_state;
+    int pcg_base;
     RDR_FN double draw(int slot, int dim) const {
+        if (pcg_state) return pcg_output_double(pcg_advance(pcg_state[slot], pcg_inc(slot), (uint32_t)(dim - pcg_base)));
         return sobol_value(matrices, (uint64_t)sample_id, (uint32_t)dim, sobol_scramble(seed, slot));
     }
+};
+
+// Host-launched maintenance of the PCG states.
+struct PcgInit {
+    uint64_t *state; uint64_t seed;
+    RDR_FN void operator()(int slot) const { state[slot] = pcg_seed_state(seed, slot); }
+};
+struct PcgAdvance {
+    uint64_t *state; int count;
+    RDR_FN void operator()(int slot) const { state[slot] = pcg_advance(state[slot], pcg_inc(slot), (uint32_t)count); }
 };
 
 } // namespace rdr

@@ -61,7 +61,7 @@ RDR_FN V3 image_grad(const float *d_image, int nd, int radiance_dim, int pixel) 
 //   AdjBounceNee     : next-event estimation; ADDS its share to the record.
 // (The reference does both in one functor, src/path_contribution.cpp:156-626; the sums are the same.)
 struct AdjBounceArgs {
-    SceneD sc; GScene g; SobolD rng; int dim;
+    SceneD sc; GScene g; SamplerD rng; int dim;
     const int *active; VSlice v, vn;
     const float *d_image; int nd, radiance_dim; double weight;
     AdjState adj;
@@ -263,7 +263,7 @@ RDR_FN void adj_first_hit_channels(const SceneD &sc, const GScene &g, const Chan
 }
 
 struct AdjPrimary {
-    SceneD sc; GScene g; SobolD rng; int sample_center;
+    SceneD sc; GScene g; SamplerD rng; int sample_center;
     VSlice v0; const float *d_image; int nd, radiance_dim; double weight;
     AdjState adj; float *screen_grad; ChannelsD ch;
     RDR_FN void operator()(int p) const {

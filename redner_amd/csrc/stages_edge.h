@@ -110,7 +110,7 @@ struct FillDouble { double *p; double value; RDR_FN void operator()(int i) const
 
 // ===================================== primary edges ================================================
 struct SamplePrimaryEdges {
-    SceneD sc; EdgeSceneD es; SobolD rng; int dim;
+    SceneD sc; EdgeSceneD es; SamplerD rng; int dim;
     const float *d_image; int nd, radiance_dim;
     PrimaryEdgeRec *recs; VSlice v;       // lanes 2*slot, 2*slot+1
     double *multipliers;                  // [2P x nd] per-channel weights of the two rays, or null
@@ -498,8 +498,8 @@ struct SecPre {
     Ray nee; Surf nee_pt; int nee_shape;
 };
 
-RDR_FN SecPre sec_prepare(const SceneD &sc, const EdgeSceneD &es, const SobolD &rng_main, int dim_main,
-                          const SobolD &rng_edge, int dim_edge, const VSlice &v, int p, int idx) {
+RDR_FN SecPre sec_prepare(const SceneD &sc, const EdgeSceneD &es, const SamplerD &rng_main, int dim_main,
+                          const SamplerD &rng_edge, int dim_edge, const VSlice &v, int p, int idx) {
     SecPre s;
     s.live = false;
     s.c = load_vertex(sc, v, p);
@@ -556,8 +556,8 @@ RDR_FN SecPre sec_prepare(const SceneD &sc, const EdgeSceneD &es, const SobolD &
 
 struct SecEdgeArgs {          // what every stage of the sampler needs
     SceneD sc; EdgeSceneD es;
-    SobolD rng_main; int dim_main;      // the forward sampler's light draw of this vertex
-    SobolD rng_edge; int dim_edge;      // edge sampler: 4 numbers per compacted slot
+    SamplerD rng_main; int dim_main;      // the forward sampler's light draw of this vertex
+    SamplerD rng_edge; int dim_edge;      // edge sampler: 4 numbers per compacted slot
     const int *active; VSlice v;        // main-path vertex
 };
 

@@ -91,13 +91,13 @@ struct Sink {
 };
 
 struct LightDraw { double light_sel, tri_sel; V2 uv; };
-RDR_FN LightDraw draw_light(const SobolD &rng, int slot, int dim) {
+RDR_FN LightDraw draw_light(const SamplerD &rng, int slot, int dim) {
     return LightDraw{rng.draw(slot, dim), rng.draw(slot, dim + 1), v2(rng.draw(slot, dim + 2), rng.draw(slot, dim + 3))};
 }
 
 // ---- stage: camera rays -------------------------------------------------------------------------
 struct GenPrimary {
-    SceneD sc; SobolD rng; int sample_center;
+    SceneD sc; SamplerD rng; int sample_center;
     VSlice v0; rt::RayRec *q;
     RDR_FN void operator()(int p) const {
         V2 s = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
@@ -256,7 +256,7 @@ RDR_FN VertexCtx load_vertex(const SceneD &sc, const VSlice &v, int p) {
 
 // ---- stage: draw the NEE point and the BSDF direction, emit both rays ---------------------------
 struct BounceSample {
-    SceneD sc; SobolD rng; int dim, rng_shift;
+    SceneD sc; SamplerD rng; int dim, rng_shift;
     const int *active; VSlice v, vn;
     rt::RayRec *q_nee, *q_bsdf;
     RDR_FN void operator()(int idx) const {
@@ -349,7 +349,7 @@ RDR_FN BounceEval eval_bounce(const SceneD &sc, const VertexCtx &c, V3 thr,
 
 // ---- stage: gather both query results, accumulate the bounce, advance the throughput ------------
 struct BounceContrib {
-    SceneD sc; SobolD rng; int dim, rng_shift;
+    SceneD sc; SamplerD rng; int dim, rng_shift;
     const int *active; VSlice v, vn;
     const rt::HitRec *h_nee, *h_bsdf;
     Sink sink;

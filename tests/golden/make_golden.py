@@ -88,6 +88,9 @@ CASES = {
     # The reference itself cannot run these two channels with edge sampling: its generic-texture scratch is
     # sized for num_pixels lanes but the edge pass indexes 2*num_pixels (src/pathtracer.cpp:103 vs :829,
     # heap overflow), and barycentric_coordinates segfaults in its edge pass.  Pinned without edge sampling.
+    # the default `independent` (PCG32) sampler; 3 bounces so the edge sampler's per-slot states diverge
+    'bunny_box_pcg_32x32x3': ('bunny_box', 32, 3, 3, None, {'sampler': 'independent'}),
+    'two_triangles_pcg_64x64x4': ('two_triangles', 64, 4, 1, None, {'sampler': 'independent'}),
     # radiance after a 3-wide channel: the reference adds path contributions at the channel INDEX (src/channels.cpp:27)
     'textured_sphere_radiance_last_48x48x2': ('textured_sphere', 48, 2, 2, ['position', 'radiance']),
     'textured_sphere_generic_48x48x4': ('textured_sphere', 48, 4, 1,
@@ -111,8 +114,10 @@ def render_case(backend, builder, res, spp, mb, channels=None, opts=None, device
     if sc.camera.position is not None:
         sc.camera.position.requires_grad_(True)
     ch = None if channels is None else [getattr(backend.channels, c) for c in channels]
-    args = RenderFunction.serialize_scene(sc, spp, mb, channels=ch, sampler_type=backend.SamplerType.sobol,
-                                          device=device, backend=backend, **(opts or {}))
+    opts = dict(opts or {})
+    sampler = getattr(backend.SamplerType, opts.pop('sampler', 'sobol'))
+    args = RenderFunction.serialize_scene(sc, spp, mb, channels=ch, sampler_type=sampler,
+                                          device=device, backend=backend, **opts)
     img = RenderFunction.apply(1, *args)
     out = {'image': img.detach().cpu().numpy()}
     # upstream gradient: a fixed smooth pattern so every pixel/channel has a distinct weight

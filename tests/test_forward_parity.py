@@ -20,8 +20,10 @@ TOL = 1e-4
 def _render(backend, device, builder, res, spp, mb, channels=None, opts=None):
     sc = getattr(scenes, builder)(device, resolution=(res, res))
     ch = None if channels is None else [getattr(backend.channels, c) for c in channels]
-    args = RenderFunction.serialize_scene(sc, spp, mb, channels=ch, sampler_type=backend.SamplerType.sobol,
-                                          device=device, backend=backend, **(opts or {}))
+    opts = dict(opts or {})
+    sampler = getattr(backend.SamplerType, opts.pop('sampler', 'sobol'))
+    args = RenderFunction.serialize_scene(sc, spp, mb, channels=ch, sampler_type=sampler,
+                                          device=device, backend=backend, **opts)
     with torch.no_grad():
         return RenderFunction.apply(1, *args)
 
