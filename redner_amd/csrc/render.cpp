@@ -7,6 +7,8 @@
 // the reference's, because sample-exact parity depends on it; how a bounce is cut into kernels
 // and what is kept in HBM is ours (stages_fwd.h / stages_bwd.h / stages_edge.h).
 #include "render.h"
+#include <cstdio>
+#include <cstdlib>
 #include "stages_fwd.h"
 #include "stages_bwd.h"
 #include "stages_edge.h"
@@ -71,6 +73,18 @@ ChannelLayout layout_of(const rdr_render_options &o, int max_generic) {
     l.nd = d;
     l.ch.nd = d; l.ch.radiance_dim = l.radiance_dim;
     return l;
+}
+
+// Debugging aid (RDR_DEBUG_DUMP=<dir>): stage buffers are written to <dir>/<tag>.bin so a GPU run can be
+// diffed against the CPU harness stage by stage.  Off unless the variable is set.
+void debug_dump(const char *tag, int sample, int depth, const void *dev_ptr, size_t bytes) {
+    static const char *dir = std::getenv("RDR_DEBUG_DUMP");
+    if (!dir || !dev_ptr) return;
+    std::vector<char> host(bytes);
+    exec::download(host.data(), dev_ptr, bytes);
+    char path[1024];
+    std::snprintf(path, sizeof(path), "%s/%s_s%d_d%d.bin", dir, tag, sample, depth);
+    if (FILE *f = std::fopen(path, "wb")) { std::fwrite(host.data(), 1, bytes, f); std::fclose(f); }
 }
 
 // PCG streams are stateful, so a shard that starts at sample k > 0 cannot reproduce the single-process stream
@@ -189,6 +203,7 @@ struct GradStore {
         g.cam.position = mirror(dc.position, 3); g.cam.look = mirror(dc.look, 3); g.cam.up = mirror(dc.up, 3);
         g.cam.cam_to_world = mirror(dc.cam_to_world, 16); g.cam.world_to_cam = mirror(dc.world_to_cam, 16);
         g.cam.intrinsic_mat_inv = mirror(dc.intrinsic_mat_inv, 9); g.cam.intrinsic_mat = mirror(dc.intrinsic_mat, 9);
+        g.cam.distortion = mirror(dc.distortion_params, 8);
         g.envmap = nullptr;
     }
     void flush() {
@@ -306,7 +321,10 @@ struct Backward {
                 exec::launch(nH, SecEdgePickH{sa, elist[0], sec_picks});
                 int nN = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 2});
                 exec::launch(nN, SecEdgePickN{sa, elist[0], sec_picks});
+                debug_dump("sec_mode", sample_id, d, sec_mode, (size_t)nA);
+                debug_dump("sec_picks", sample_id, d, sec_picks, sizeof(SecPick) * (size_t)nA);
                 exec::launch(nA, SecEdgeFinish{sa, sec_mode, sec_picks, d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});
+                debug_dump("sec_recs", sample_id, d, sec_recs, sizeof(SecondaryEdgeRec) * (size_t)nA);
                 edim += 4;
                 edge_rng_consumed(nA, 4);
                 int n0 = exec::compact((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});

@@ -79,11 +79,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
                     int primary_edges, int secondary_edges) {
     exec::select_device(use_gpu, gpu_index);   // throws when no gfx950 device / use_gpu == 0
     if (!cam) throw std::runtime_error("Scene: camera is required");
-    if (cam->camera_type != RDR_CAMERA_PERSPECTIVE)
-        throw std::runtime_error("Scene: only the perspective camera is implemented so far "
-                                 "(orthographic/fisheye/panorama: SURVEY.md section 8f row 3)");
-    if (cam->distortion_params)
-        throw std::runtime_error("Scene: lens distortion is not implemented yet (section 8f row 3)");
+    if (cam->camera_type < 0 || cam->camera_type > 3) throw std::runtime_error("Scene: unknown camera type");
     if (envmap)
         throw std::runtime_error("Scene: environment maps are not implemented yet (section 8f row 3)");
 
@@ -100,6 +96,11 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     c.clip_near = cam->clip_near; c.kind = cam->camera_type;
     c.vp_x0 = cam->viewport_beg[0]; c.vp_y0 = cam->viewport_beg[1];
     c.vp_x1 = cam->viewport_end[0]; c.vp_y1 = cam->viewport_end[1];
+    if (cam->distortion_params) {
+        c.distortion.defined = 1;
+        for (int i = 0; i < 6; ++i) c.distortion.k[i] = cam->distortion_params[i];
+        c.distortion.p[0] = cam->distortion_params[6]; c.distortion.p[1] = cam->distortion_params[7];
+    }
     c.intrinsic_mat_inv = m3_from(cam->intrinsic_mat_inv);
     c.intrinsic_mat = m3_from(cam->intrinsic_mat);
     if (cam->cam_to_world) {

@@ -50,6 +50,7 @@ struct LightD {
 
 enum CameraKind { CAM_PERSPECTIVE = 0, CAM_ORTHOGRAPHIC = 1, CAM_FISHEYE = 2, CAM_PANORAMA = 3 };
 
+struct DistortD { int defined; double k[6], p[2]; };    // Brown-Conrady lens distortion (src/camera_distortion.h:7-11)
 struct CameraD {
     int width, height;
     int use_look_at;
@@ -59,6 +60,7 @@ struct CameraD {
     float clip_near;
     int kind;
     int vp_x0, vp_y0, vp_x1, vp_y1;   // viewport_beg / viewport_end
+    DistortD distortion;
 };
 
 struct EnvmapD {
@@ -90,6 +92,7 @@ struct GCamera {
     double *position, *look, *up;          // 3 each (look-at parameterisation)
     double *cam_to_world, *world_to_cam;   // 16 each
     double *intrinsic_mat_inv, *intrinsic_mat;   // 9 each
+    double *distortion;                          // 8: k0..k5, p0, p1
 };
 struct GEnvmap { GTex values; double *world_to_env; };
 struct GScene {

@@ -139,17 +139,48 @@ struct SamplePrimaryEdges {
             store_rdiff(v, l0, raydiff_zero()); store_rdiff(v, l1, raydiff_zero());
             return;
         }
-        V2 pt = a_ss + t * (b_ss - a_ss);
+        const bool linear = linear_projection(sc.cam);
+        V2 pt;
+        V3 a_dir = v3(0), b_dir = v3(0), ab_dir = v3(0), pt3 = v3(0);
+        if (linear) {
+            pt = a_ss + t * (b_ss - a_ss);
+        } else {
+            // fisheye / panorama / distorted lenses: sample on the camera-space film, where the edge is straight (:486-512)
+            a_dir = screen_to_camera(sc.cam, a_ss); b_dir = screen_to_camera(sc.cam, b_ss);
+            ab_dir = b_dir - a_dir;
+            pt3 = a_dir + t * ab_dir;
+            pt = camera_to_screen(sc.cam, pt3);
+        }
         if (!in_screen(sc.cam, pt)) {
             store_rdiff(v, l0, raydiff_zero()); store_rdiff(v, l1, raydiff_zero());
             return;
         }
         rec.edge = edge; rec.edge_pt = pt;
         recs[slot] = rec;
-        V2 dn = normalize(a_ss - b_ss);
-        V2 hn = v2(dn.y, -dn.x);
-        double off = 1e-6f;
-        Ray up = primary_ray(sc.cam, pt + hn * off), lo = primary_ray(sc.cam, pt - hn * off);
+        Ray up, lo;
+        double jacobian = 1;
+        if (linear) {
+            V2 dn = normalize(a_ss - b_ss);
+            V2 hn = v2(dn.y, -dn.x);
+            double off = 1e-6f;
+            up = primary_ray(sc.cam, pt + hn * off); lo = primary_ray(sc.cam, pt - hn * off);
+        } else {
+            V3 hn = normalize(cross(a_dir, b_dir));
+            V3 a_loc = xfm_point(sc.cam.world_to_cam, a), b_loc = xfm_point(sc.cam.world_to_cam, b);
+            V3 e_loc = a_loc + t * b_loc;                                 // [quirk] not a point of the edge (:529)
+            double off = 1e-5f / len(e_loc);
+            up = primary_ray(sc.cam, camera_to_screen(sc.cam, normalize(pt3 + off * hn)));
+            lo = primary_ray(sc.cam, camera_to_screen(sc.cam, normalize(pt3 - off * hn)));
+            // |d alpha / d screen|^-1 and the stretch of the line parameterisation, by finite difference (:562-576)
+            V2 pt_bar = v2(0, 0);
+            adj_screen_to_camera(sc.cam, pt, cross(a_dir, b_dir), pt_bar);
+            double dirac_jacobian = 1.f / sqrt(pt_bar.x * pt_bar.x + pt_bar.y * pt_bar.y);
+            double jac_offset = 1e-6;
+            V3 pt3_delta = a_dir + (t + jac_offset) * ab_dir;
+            V2 pt_delta = camera_to_screen(sc.cam, pt3_delta);
+            double line_jacobian = len((pt_delta - pt) / off);
+            jacobian = line_jacobian * dirac_jacobian;
+        }
         store_ray(v, l0, up.org, up.dir);
         store_ray(v, l1, lo.org, lo.dir);
         int vw = sc.cam.vp_x1 - sc.cam.vp_x0, vh = sc.cam.vp_y1 - sc.cam.vp_y0;
@@ -160,12 +191,14 @@ struct SamplePrimaryEdges {
         if (multipliers) {
             for (int d = 0; d < nd; ++d) {
                 double dch = d_image[(size_t)nd * (yi * vw + xi) + d];
-                multipliers[(size_t)nd * l0 + d] = dch / pmf;
-                multipliers[(size_t)nd * l1 + d] = -dch / pmf;
+                multipliers[(size_t)nd * l0 + d] = linear ? dch / pmf : dch * jacobian / pmf;
+                multipliers[(size_t)nd * l1 + d] = linear ? -dch / pmf : -dch * jacobian / pmf;
             }
         }
-        st3(v.thr, v.n, l0, 0, dc / pmf);
-        st3(v.thr, v.n, l1, 0, -dc / pmf);
+        V3 w_up = dc / pmf, w_lo = -dc / pmf;
+        if (!linear) { w_up = w_up * jacobian; w_lo = w_lo * jacobian; }
+        st3(v.thr, v.n, l0, 0, w_up);
+        st3(v.thr, v.n, l1, 0, w_lo);
         primary_ray_with_diff(sc.cam, pt, rd);
         if (v.erd) st_rdiff(v.erd, v.n, slot, rd);            // [quirk] slot-indexed; lanes read theirs in LoadLaneDiff
         else { store_rdiff(v, l0, rd); store_rdiff(v, l1, rd); }
@@ -182,10 +215,20 @@ struct PrimaryEdgeDerivatives {
         V2 a_ss, b_ss;
         if (!project_segment(sc.cam, a, b, a_ss, b_ss)) return;
         V2 pt = rec.edge_pt;
-        // Eq. 8 of the paper: gradient of the edge equation w.r.t. its screen-space end points
-        V2 a_bar = v2(b_ss.y - pt.y, pt.x - b_ss.x);
-        V2 b_bar = v2(pt.y - a_ss.y, a_ss.x - pt.x);
-        V2 pt_bar = v2(a_ss.y - b_ss.y, b_ss.x - a_ss.x);
+        V2 a_bar = v2(0, 0), b_bar = v2(0, 0), pt_bar = v2(0, 0);
+        if (linear_projection(sc.cam)) {
+            // Eq. 8 of the paper: gradient of the edge equation w.r.t. its screen-space end points
+            a_bar = v2(b_ss.y - pt.y, pt.x - b_ss.x);
+            b_bar = v2(pt.y - a_ss.y, a_ss.x - pt.x);
+            pt_bar = v2(a_ss.y - b_ss.y, b_ss.x - a_ss.x);
+        } else {
+            // alpha(p) = dot(p, cross(a_dir, b_dir)) on the camera-space film (:734-749)
+            V3 a_dir = screen_to_camera(sc.cam, a_ss), b_dir = screen_to_camera(sc.cam, b_ss);
+            V3 e_dir = screen_to_camera(sc.cam, pt);
+            adj_screen_to_camera(sc.cam, a_ss, cross(b_dir, e_dir), a_bar);
+            adj_screen_to_camera(sc.cam, b_ss, cross(e_dir, a_dir), b_bar);
+            adj_screen_to_camera(sc.cam, b_ss, cross(a_dir, b_dir), pt_bar);     // [quirk] evaluated at b_ss, not at pt (:748)
+        }
         a_bar = a_bar * contrib; b_bar = b_bar * contrib; pt_bar = pt_bar * contrib;
         V3 pa_bar = v3(0), pb_bar = v3(0);
         adj_project_segment(sc.cam, a, b, a_bar, b_bar, g.cam, pa_bar, pb_bar);

@@ -30,7 +30,7 @@ class Camera:
 
     def __init__(self, position=None, look_at=None, up=None, fov=None, clip_near=1e-4,
                  resolution=(256, 256), viewport=None, cam_to_world=None, intrinsic_mat=None,
-                 camera_type=0):
+                 camera_type=0, distortion_params=None):
         self.position, self.look_at, self.up = position, look_at, up
         self.cam_to_world = cam_to_world
         self.world_to_cam = torch.inverse(cam_to_world).contiguous() if cam_to_world is not None else None
@@ -44,7 +44,8 @@ class Camera:
         self.clip_near = clip_near
         self.resolution = tuple(resolution)      # (height, width)
         self.viewport = viewport                  # (y0, x0, y1, x1) or None
-        self.camera_type = camera_type
+        self.camera_type = camera_type            # redner.CameraType: perspective / orthographic / fisheye / panorama
+        self.distortion_params = distortion_params   # 8 floats (k0..k5, p0, p1) or None
 
 
 class Shape:
@@ -147,7 +148,8 @@ class RenderFunction(torch.autograd.Function):
                 'channels': list(channels), 'sampler_type': sampler_type,
                 'sample_pixel_center': sample_pixel_center}
         cm = {}
-        for name in ('position', 'look_at', 'up', 'cam_to_world', 'world_to_cam', 'intrinsic_mat_inv', 'intrinsic_mat'):
+        for name in ('position', 'look_at', 'up', 'cam_to_world', 'world_to_cam', 'intrinsic_mat_inv', 'intrinsic_mat',
+                     'distortion_params'):
             t = getattr(cam, name)
             if t is not None and t.requires_grad:
                 needs_visibility = True
@@ -212,7 +214,7 @@ class RenderFunction(torch.autograd.Function):
                              fp(T(cm['up']) if use_look_at else None),
                              fp(None if use_look_at else T(cm['cam_to_world'])),
                              fp(None if use_look_at else T(cm['world_to_cam'])),
-                             fp(T(cm['intrinsic_mat_inv'])), fp(T(cm['intrinsic_mat'])), fp(None),
+                             fp(T(cm['intrinsic_mat_inv'])), fp(T(cm['intrinsic_mat'])), fp(T(cm['distortion_params'])),
                              cm['clip_near'], rd.CameraType(int(cm['camera_type'])),
                              rd.Vector2i(vp[1], vp[0]), rd.Vector2i(vp[3], vp[2]))
         u.shapes = []
@@ -295,7 +297,7 @@ class RenderFunction(torch.autograd.Function):
                               fp(None if use_look_at else zeros_like_arg(cm['cam_to_world'])),
                               fp(None if use_look_at else zeros_like_arg(cm['world_to_cam'])),
                               fp(zeros_like_arg(cm['intrinsic_mat_inv'])), fp(zeros_like_arg(cm['intrinsic_mat'])),
-                              fp(None))
+                              fp(zeros_like_arg(cm['distortion_params'])))
         d_shapes = [rd.DShape(fp(zeros_like_arg(sm['vertices'])), fp(zeros_like_arg(sm['uvs'])),
                               fp(zeros_like_arg(sm['normals'])), fp(zeros_like_arg(sm['colors'])))
                     for sm in meta['shapes']]

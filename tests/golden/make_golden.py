@@ -91,6 +91,15 @@ CASES = {
     # the default `independent` (PCG32) sampler; 3 bounces so the edge sampler's per-slot states diverge
     'bunny_box_pcg_32x32x3': ('bunny_box', 32, 3, 3, None, {'sampler': 'independent'}),
     'two_triangles_pcg_64x64x4': ('two_triangles', 64, 4, 1, None, {'sampler': 'independent'}),
+    # camera models and lens distortion (src/camera.h, src/camera_distortion.h)
+    'two_triangles_ortho_64x64x4': ('two_triangles_ortho', 64, 4, 1),
+    'two_triangles_distorted_64x64x4': ('two_triangles_distorted', 64, 4, 1),
+    'bunny_box_fisheye_32x32x4': ('bunny_box_fisheye', 32, 4, 2),
+    'bunny_box_panorama_32x32x4': ('bunny_box_panorama', 32, 4, 2),
+    # the same two without secondary edge sampling: the cases a GPU run can match sample for sample (see
+    # SAMPLE_EXACT_ON_CPU_ONLY below)
+    'bunny_box_fisheye_nosec_32x32x4': ('bunny_box_fisheye', 32, 4, 2, None, {'use_secondary_edge_sampling': False}),
+    'bunny_box_panorama_nosec_32x32x4': ('bunny_box_panorama', 32, 4, 2, None, {'use_secondary_edge_sampling': False}),
     # radiance after a 3-wide channel: the reference adds path contributions at the channel INDEX (src/channels.cpp:27)
     'textured_sphere_radiance_last_48x48x2': ('textured_sphere', 48, 2, 2, ['position', 'radiance']),
     'textured_sphere_generic_48x48x4': ('textured_sphere', 48, 4, 1,
@@ -100,6 +109,16 @@ CASES = {
     'textured_sphere_albedo_48x48x4': ('textured_sphere', 48, 4, 0,
                                        ['depth', 'shading_normal', 'diffuse_reflectance', 'uv']),
 }
+
+
+# Cases whose backward pass can only be reproduced sample-for-sample by a build that shares the oracle's libm
+# (the CPU harness).  The reference's hierarchical edge pick threads ONE random number through the whole tree
+# walk, rescaling it at every node (src/edge.cpp:1160-1230): ~100 rescalings amplify a 1-ulp difference in the
+# shading position to O(1), so the pick is chaotic in its inputs.  With a perspective / orthographic camera the
+# first-hit positions involve only + - * / sqrt and are bit-identical on the GPU; fisheye / panorama primary
+# rays go through sin/cos, where the GPU's libm and glibc differ in the last ulp.  Both picks are draws from
+# the same distribution (the estimator is unchanged), but they are different draws.
+SAMPLE_EXACT_ON_CPU_ONLY = {'bunny_box_fisheye_32x32x4', 'bunny_box_panorama_32x32x4'}
 
 
 def render_case(backend, builder, res, spp, mb, channels=None, opts=None, device=torch.device('cpu')):
@@ -113,6 +132,9 @@ def render_case(backend, builder, res, spp, mb, channels=None, opts=None, device
         m.diffuse_reflectance.mipmap[0].requires_grad_(True)
     if sc.camera.position is not None:
         sc.camera.position.requires_grad_(True)
+        if sc.camera.camera_type != 0 or sc.camera.distortion_params is not None:
+            for t in (sc.camera.look_at, sc.camera.up, sc.camera.intrinsic_mat, sc.camera.intrinsic_mat_inv):
+                t.requires_grad_(True)
     ch = None if channels is None else [getattr(backend.channels, c) for c in channels]
     opts = dict(opts or {})
     sampler = getattr(backend.SamplerType, opts.pop('sampler', 'sobol'))
@@ -148,6 +170,10 @@ def render_case(backend, builder, res, spp, mb, channels=None, opts=None, device
                     grab('grad_mat%d_%s_L%d' % (i, name, lv), t)
     if sc.camera.position is not None:
         grab('grad_cam_position', sc.camera.position)
+    for name in ('look_at', 'up', 'intrinsic_mat', 'intrinsic_mat_inv', 'distortion_params'):
+        t = getattr(sc.camera, name)
+        if t is not None and t.requires_grad:
+            grab('grad_cam_' + name, t)
     return out
 
 

@@ -148,3 +148,39 @@ def textured_sphere(device, resolution=(48, 48)):
             Material(diffuse_reflectance=_t([0.6, 0.55, 0.5], device, grad=True), normal_map=Texture(mips(nm))),
             Material(diffuse_reflectance=_t([0.0, 0.0, 0.0], device))]
     return Scene(cam, [sphere, wall, light], mats, [AreaLight(2, _t([25.0, 25.0, 25.0], 'cpu'))])
+
+
+# ---- non-pinhole cameras and lens distortion (tests/test_camera_distortion.py, test_fisheye in the reference) ----
+def two_triangles_ortho(device, resolution=(64, 64)):
+    sc = two_triangles(device, resolution)
+    c = sc.camera
+    sc.camera = Camera(position=c.position, look_at=c.look_at, up=c.up, clip_near=c.clip_near, resolution=resolution,
+                       intrinsic_mat=_t([[0.4, 0.0, 0.0], [0.0, 0.4, 0.0], [0.0, 0.0, 1.0]], 'cpu'), camera_type=1)
+    return sc
+
+
+def two_triangles_distorted(device, resolution=(64, 64)):
+    sc = two_triangles(device, resolution)
+    c = sc.camera
+    sc.camera = Camera(position=c.position, look_at=c.look_at, up=c.up, fov=_t([45.0], 'cpu'), clip_near=c.clip_near,
+                       resolution=resolution,
+                       distortion_params=_t([0.10, -0.05, 0.01, 0.02, 0.01, -0.005, 0.01, -0.008], 'cpu', grad=True))
+    return sc
+
+
+def _bunny_box_inside(device, resolution, camera_type):
+    sc = bunny_box(device, resolution)
+    z = np.load(os.path.join(GOLDEN, 'bunny_box_scene.npz'))
+    pos = np.array([0.1, 1.2, 0.8], np.float32)      # inside the box, so every direction sees geometry
+    sc.camera = Camera(position=_t(pos, 'cpu'), look_at=_t([0.0, 0.6, 0.0], 'cpu'), up=_t([0.0, 1.0, 0.0], 'cpu'),
+                       fov=_t([45.0], 'cpu'), clip_near=float(z['clip_near']), resolution=resolution,
+                       camera_type=camera_type)
+    return sc
+
+
+def bunny_box_fisheye(device, resolution=(32, 32)):
+    return _bunny_box_inside(device, resolution, 2)
+
+
+def bunny_box_panorama(device, resolution=(32, 32)):
+    return _bunny_box_inside(device, resolution, 3)
