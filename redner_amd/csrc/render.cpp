@@ -205,6 +205,15 @@ struct GradStore {
         g.cam.intrinsic_mat_inv = mirror(dc.intrinsic_mat_inv, 9); g.cam.intrinsic_mat = mirror(dc.intrinsic_mat, 9);
         g.cam.distortion = mirror(dc.distortion_params, 8);
         g.envmap = nullptr;
+        if (scene.d.envmap && ds.envmap) {
+            GEnvmap h_envmap;
+            h_envmap.values = mirror_tex(scene.h_envmap.values, ds.envmap->values);
+            h_envmap.world_to_env = mirror(ds.envmap->world_to_env, 16);
+            if (!counting) {
+                g.envmap = arena.get<GEnvmap>(1);
+                exec::upload(g.envmap, &h_envmap, sizeof(GEnvmap));
+            }
+        }
     }
     void flush() {
         for (const Pair &p : pairs) exec::launch((int)p.count, FlushGrad{p.acc, p.out, stride, replicas});
@@ -247,6 +256,9 @@ struct Backward {
             edge_contrib = arena.get<double>(L);
             edge_tmin = arena.get<double>(L);
             hit_pos = arena.get<double>((size_t)3 * L);
+            // only written on hits; lanes that reach the environment light read what an earlier hit left there,
+            // like the reference's never-cleared edge_surface_points (src/pathtracer.cpp:594-600); fresh pages are 0
+            exec::zero(hit_pos, sizeof(double) * 3 * L);
             prim_recs = arena.get<PrimaryEdgeRec>(P);
             sec_recs = arena.get<SecondaryEdgeRec>(P);
             sec_picks = arena.get<SecPick>(P);

@@ -80,8 +80,6 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     exec::select_device(use_gpu, gpu_index);   // throws when no gfx950 device / use_gpu == 0
     if (!cam) throw std::runtime_error("Scene: camera is required");
     if (cam->camera_type < 0 || cam->camera_type > 3) throw std::runtime_error("Scene: unknown camera type");
-    if (envmap)
-        throw std::runtime_error("Scene: environment maps are not implemented yet (section 8f row 3)");
 
     std::unique_ptr<Scene> sp(new Scene());
     Scene &s = *sp;
@@ -164,7 +162,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     }
 
     // ---- light PMF / CDF, per-light area CDF (src/scene.cpp:38-61, 197-253) ----
-    int num_lights = num_area_lights;
+    int num_lights = num_area_lights + (envmap ? 1 : 0);       // the environment light is the last entry (:197-202)
     s.light_pmf.assign(num_lights, 0); s.light_cdf.assign(num_lights, 0); s.light_areas.assign(num_area_lights, 0);
     s.area_cdf_offset.assign(num_area_lights, 0);
     {
@@ -187,6 +185,29 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
             float lum = 0.212671f * I[0] + 0.715160f * I[1] + 0.072169f * I[2];   // fp32, as luminance<float>
             s.light_pmf[l] = total * lum * double(M_PI);
             total_importance += s.light_pmf[l];
+        }
+        if (envmap) {
+            // bounding sphere of all vertices in fp32 (:161-195).  [quirk] the z extent is taken from y (:184,187)
+            float inf = std::numeric_limits<float>::infinity();
+            float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+            for (int i = 0; i < num_shapes; ++i) {
+                float smn[3] = {inf, inf, inf}, smx[3] = {-inf, -inf, -inf};
+                const std::vector<float> &v = s.h_vertices[i];
+                for (size_t k = 0; k + 2 < v.size(); k += 3)
+                    for (int c = 0; c < 3; ++c) { smn[c] = std::min(smn[c], v[k + c]); smx[c] = std::max(smx[c], v[k + c]); }
+                mn[0] = std::min(smn[0], mn[0]); mn[1] = std::min(smn[1], mn[1]); mn[2] = std::min(smn[1], mn[2]);
+                mx[0] = std::max(smx[0], mx[0]); mx[1] = std::max(smx[1], mx[1]); mx[2] = std::max(smx[1], mx[2]);
+            }
+            float radius = 0;
+            if (num_shapes > 0) {
+                float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+                radius = 0.5f * std::sqrt(dx * dx + dy * dy + dz * dz);
+            }
+            double r = radius;                 // Sphere::radius is a Real holding the fp32 result
+            double surface_area = 4 * double(M_PI) * (r * r);
+            int envmap_id = num_area_lights;
+            s.light_pmf[envmap_id] = surface_area > 0 ? surface_area / (double)envmap->pdf_norm : 1.0;
+            total_importance += s.light_pmf[envmap_id];
         }
         if (num_lights > 0) {
             if (!(total_importance > 0)) throw std::runtime_error("Scene: total light importance must be positive");
@@ -214,6 +235,24 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     s.d.materials = to_device(s, s.materials.data(), s.materials.size());
     s.d.lights = to_device(s, s.lights.data(), s.lights.size());
     s.d.envmap = nullptr;
+    if (envmap) {
+        EnvmapD e;
+        std::memset(&e, 0, sizeof(e));
+        e.values = convert_tex(envmap->values);
+        e.values.channels = 3;
+        if (e.values.num_levels < 1 || e.values.width[0] <= 0 || e.values.height[0] <= 0)
+            throw std::runtime_error("Scene: the environment map needs a 2-D RGB texture");
+        if (!envmap->env_to_world || !envmap->world_to_env || !envmap->sample_cdf_ys || !envmap->sample_cdf_xs)
+            throw std::runtime_error("Scene: environment map transforms and sampling tables are required");
+        e.env_to_world = m4_from(envmap->env_to_world);
+        e.world_to_env = m4_from(envmap->world_to_env);
+        e.sample_cdf_ys = envmap->sample_cdf_ys; e.sample_cdf_xs = envmap->sample_cdf_xs;
+        e.pdf_norm = (double)envmap->pdf_norm;
+        e.directly_visible = envmap->directly_visible;
+        if (e.values.num_levels > 1) s.has_mipmaps = true;
+        s.h_envmap = e;
+        s.d.envmap = to_device(s, &s.h_envmap, 1);
+    }
     s.d.num_shapes = num_shapes; s.d.num_materials = num_materials;
     s.d.num_area_lights = num_area_lights; s.d.num_lights = num_lights;
     s.d.light_pmf = to_device(s, s.light_pmf.data(), s.light_pmf.size());

@@ -135,6 +135,27 @@ struct AdjBounceScatter {
                 in_dir_bar -= wi_bar;
                 scatter_trigrad(bsh, g.shapes[bshape], btri, tg);
             }
+        } else if (sc.envmap != nullptr) {
+            // the BSDF ray reached the environment light (src/path_contribution.cpp:520-600); MIS weight and
+            // pdf are treated as constants, nothing flows into the sampling procedure
+            V3 wo = load_ray(vn, p).dir;
+            double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough);
+            if (len_sq(wo) > 0 && pdf_b > 0) {
+                V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
+                V3 Le = envmap_eval(*sc.envmap, wo, raydiff_zero());
+                double pdf_nee = envmap_pdf(*sc.envmap, wo) * sc.light_pmf[sc.num_lights - 1];
+                double mis = 1 / (1 + sq(pdf_nee / pdf_b));
+                V3 sc_contrib = (mis / pdf_b) * f * Le;
+                V3 scb = pc_bar * thr;
+                thr_bar += pc_bar * sc_contrib;
+                double w = mis / pdf_b;
+                V3 f_bar = w * scb * Le, Le_bar = w * scb * f;
+                V3 wo_bar = v3(0), wi_bar = v3(0);
+                RayDiff rd_bar = raydiff_zero();
+                adj_envmap_eval(*sc.envmap, wo, raydiff_zero(), Le_bar, g.envmap, wo_bar, rd_bar);
+                adj_bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough, f_bar, gm, sp_bar, wi_bar, wo_bar);
+                in_dir_bar -= wi_bar;
+            }
         }
         st3(adj.thr, adj.n, p, 0, thr_bar);
         st3(adj.ray_dir, adj.n, p, 0, in_dir_bar);
@@ -142,15 +163,56 @@ struct AdjBounceScatter {
     }
 };
 
+// Adds one estimator's share to the adjoint record written by AdjBounceScatter.
+RDR_FN void adj_record_add(const AdjState &adj, int p, V3 thr_bar, V3 in_dir_bar, const Surf &sp_bar) {
+    st3(adj.thr, adj.n, p, 0, ld3(adj.thr, adj.n, p, 0) + thr_bar);
+    st3(adj.ray_dir, adj.n, p, 0, ld3(adj.ray_dir, adj.n, p, 0) + in_dir_bar);
+    Surf cur = load_adj_point(adj, p);
+    cur.position += sp_bar.position;
+    cur.frame.x += sp_bar.frame.x; cur.frame.y += sp_bar.frame.y; cur.frame.n += sp_bar.frame.n;
+    cur.dpdu += sp_bar.dpdu; cur.uv += sp_bar.uv; cur.du_dxy += sp_bar.du_dxy; cur.dv_dxy += sp_bar.dv_dxy;
+    cur.color += sp_bar.color;
+    store_adj_point(adj, p, cur);
+}
+
 struct AdjBounceNee {
     AdjBounceArgs a;
+    // next-event estimation towards the environment light (src/path_contribution.cpp:295-338)
+    RDR_FN void envmap_nee(int p, const LightDraw &ld) const {
+        const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v;
+        V3 wo = envmap_sample(*sc.envmap, ld.uv);
+        double pdf_nee = envmap_pdf(*sc.envmap, wo) * sc.light_pmf[sc.num_lights - 1];
+        if (!(pdf_nee > 0)) return;
+        VertexCtx c = load_vertex(sc, v, p);
+        const GMaterial &gm = g.materials[c.shape->material_id];
+        V3 thr = ld3(v.thr, v.n, p, 0);
+        V3 pc_bar = a.weight * image_grad(a.d_image, a.nd, a.radiance_dim, p);
+        V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
+        V3 Le = envmap_eval(*sc.envmap, wo, raydiff_zero());
+        double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough);
+        double mis = 1 / (1 + sq(pdf_b / pdf_nee));
+        V3 nee = (mis / pdf_nee) * f * Le;
+        V3 nee_bar = pc_bar * thr;
+        V3 thr_bar = pc_bar * nee;
+        double w = mis / pdf_nee;
+        V3 f_bar = w * nee_bar * Le, Le_bar = w * nee_bar * f;
+        V3 wo_bar = v3(0), wi_bar = v3(0);
+        RayDiff rd_bar = raydiff_zero();
+        adj_envmap_eval(*sc.envmap, wo, raydiff_zero(), Le_bar, g.envmap, wo_bar, rd_bar);
+        Surf sp_bar = surf_zero();
+        adj_bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough, f_bar, gm, sp_bar, wi_bar, wo_bar);
+        adj_record_add(a.adj, p, thr_bar, -wi_bar, sp_bar);
+    }
     RDR_FN void operator()(int idx) const {
         const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v; const AdjState &adj = a.adj;
         int p = a.active[idx];
         if (v.occl[p]) return;
         LightDraw ld = draw_light(a.rng, p, a.dim);
         LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
-        if (pk.shape_id < 0) return;
+        if (pk.shape_id < 0) {
+            if (sc.envmap != nullptr) envmap_nee(p, ld);
+            return;
+        }
         const ShapeD &lsh = sc.shapes[pk.shape_id];
         if (lsh.light_id < 0) return;
         VertexCtx c = load_vertex(sc, v, p);
@@ -205,15 +267,7 @@ struct AdjBounceNee {
         TriVerts tv = load_tri(lsh, pk.tri_id);
         double *gv = g.shapes[pk.shape_id].vertices;
         accum3(gv + 3 * tv.i0, lv_bar[0]); accum3(gv + 3 * tv.i1, lv_bar[1]); accum3(gv + 3 * tv.i2, lv_bar[2]);
-        // add to the record written by AdjBounceScatter
-        st3(adj.thr, adj.n, p, 0, ld3(adj.thr, adj.n, p, 0) + thr_bar);
-        st3(adj.ray_dir, adj.n, p, 0, ld3(adj.ray_dir, adj.n, p, 0) + in_dir_bar);
-        Surf cur = load_adj_point(adj, p);
-        cur.position += sp_bar.position;
-        cur.frame.x += sp_bar.frame.x; cur.frame.y += sp_bar.frame.y; cur.frame.n += sp_bar.frame.n;
-        cur.dpdu += sp_bar.dpdu; cur.uv += sp_bar.uv; cur.du_dxy += sp_bar.du_dxy; cur.dv_dxy += sp_bar.dv_dxy;
-        cur.color += sp_bar.color;
-        store_adj_point(adj, p, cur);
+        adj_record_add(adj, p, thr_bar, in_dir_bar, sp_bar);
     }
 };
 
@@ -283,7 +337,20 @@ struct AdjPrimary {
                 }
             }
         }
-        if (shape < 0) return;    // a miss carries zero adjoints: nothing flows to the camera
+        if (shape < 0) {
+            // a miss only carries an adjoint when it looks at the environment light (primary_contribution.cpp:469-485);
+            // the ray-differential adjoint of the lookup is dropped there (primary_intersection.cpp consumes it on hits only)
+            if (sc.envmap == nullptr || !sc.envmap->directly_visible || radiance_dim < 0 || len_sq(ray.dir) <= 0) return;
+            V3 e_bar = weight * ld3(v0.thr, v0.n, p, 0) * image_grad(d_image, nd, ch.radiance_off, p);
+            DRay mr_bar = dray_zero();
+            RayDiff mrd_bar = raydiff_zero();
+            adj_envmap_eval(*sc.envmap, ray.dir, rd, e_bar, g.envmap, mr_bar.dir, mrd_bar);
+            V2 ms = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
+            V2 mscr_bar = v2(0, 0);
+            adj_primary_ray(sc.cam, pixel_to_screen(sc.cam, p, ms), mr_bar, g.cam, screen_grad ? &mscr_bar : nullptr);
+            if (screen_grad) { screen_grad[2 * p] += (float)mscr_bar.x; screen_grad[2 * p + 1] += (float)mscr_bar.y; }
+            return;
+        }
         DRay r_bar = dray_zero();
         r_bar.dir = ld3(adj.ray_dir, adj.n, p, 0);
         RayDiff prd_bar = raydiff_zero();

@@ -503,6 +503,10 @@ RDR_DEV_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCt
         jac = len(tau * ((b - a) - omega * (dot(b - a, ln) / dot(omega, ln))));
         const ShapeD &lsh = sc.shapes[nee_shape];
         pdf_nee = sc.light_pmf[lsh.light_id] / sc.light_areas[lsh.light_id];
+    } else {
+        // environment light (:1349-1353)
+        jac = 1 / len_sq(ip - nee.org);
+        pdf_nee = envmap_pdf(*sc.envmap, nee.dir);
     }
     if (pmf <= 0 || jac <= 0 || pdf_nee <= 0) return -1;
     weight = 1 / (2 * es.edge_bounds_expand * pmf * jac * pdf_nee);
@@ -558,6 +562,8 @@ RDR_FN SecPre sec_prepare(const SceneD &sc, const EdgeSceneD &es, const SamplerD
         s.nee_pt = sample_tri(sc.shapes[pk.shape_id], pk.tri_id, ld.uv);
         s.nee = shadow_ray_to(s.c.sp.position, s.nee_pt.position);
         s.nee.tmax = len(s.nee_pt.position - s.nee.org);
+    } else if (sc.envmap != nullptr) {
+        s.nee = make_ray(s.c.sp.position, envmap_sample(*sc.envmap, ld.uv));     // tmax = inf (:1381-1385)
     }
     s.edge_sel = rng_edge.draw(idx, dim_edge); s.resample_sel = rng_edge.draw(idx, dim_edge + 1);
     s.bsdf_comp = rng_edge.draw(idx, dim_edge + 2); s.t_sel = rng_edge.draw(idx, dim_edge + 3);
@@ -753,7 +759,16 @@ RDR_FN V3 isect_jacobian(V3 org, V3 dir, V3 p, V3 n, V3 l) {
 struct SecondaryEdgeWeights {
     SceneD sc; const SecondaryEdgeRec *recs; VSlice ev; double *hit_pos;   // hit_pos: 3 x n, stride ev.n
     RDR_FN void scale_lane(const SecondaryEdgeRec &rec, int l) const {
-        if (ev.shape[l] < 0) return;
+        if (ev.shape[l] < 0) {
+            if (sc.envmap != nullptr) {
+                // the edge ray reaches the environment light (:1900-1912)
+                V3 a = edge_v0(sc.shapes, rec.edge), b = edge_v1(sc.shapes, rec.edge);
+                double dirac_j = len(cross(a - rec.sp_pos, b - rec.sp_pos));
+                double line_j = 1 / len_sq(rec.edge_pt - rec.sp_pos);
+                st3(ev.thr, ev.n, l, 0, ld3(ev.thr, ev.n, l, 0) * (line_j / dirac_j));
+            }
+            return;
+        }
         RayDiff tmp;
         Surf hp = surf_at(sc.shapes[ev.shape[l]], ev.tri[l], load_ray(ev, l), load_rdiff(ev, l), tmp);
         st3(hit_pos, ev.n, l, 0, hp.position);
@@ -777,6 +792,7 @@ struct SecondaryEdgeWeights {
         int light0 = ev.shape[l0] >= 0 ? sc.shapes[ev.shape[l0]].light_id : -1;
         int light1 = ev.shape[l1] >= 0 ? sc.shapes[ev.shape[l1]].light_id : -1;
         bool hit_light = light0 != -1 || light1 != -1;
+        if (!hit_light && sc.envmap != nullptr) hit_light = envmap_pdf(*sc.envmap, normalize(rec.edge_pt - rec.sp_pos)) > 0;
         if (rec.use_nee_ray) {
             if (hit_light) {
                 st3(ev.thr, ev.n, l0, 0, ld3(ev.thr, ev.n, l0, 0) * 0.5f);

@@ -20,6 +20,7 @@
 #include "bvh.h"
 #include "camera.h"
 #include "lights.h"
+#include "envmap.h"
 #include "sobol.h"
 
 namespace rdr {
@@ -114,7 +115,10 @@ struct GenPrimary {
 // Emission seen directly along `ray` at a hit (src/primary_contribution.cpp:13-31).
 RDR_FN V3 direct_emission(const SceneD &sc, int shape, int tri, const Ray &ray, const RayDiff &rd) {
     V3 e = v3(0);
-    if (shape < 0) return e;
+    if (shape < 0) {
+        if (sc.envmap != nullptr && sc.envmap->directly_visible) e = envmap_eval(*sc.envmap, ray.dir, rd);
+        return e;
+    }
     const ShapeD &sh = sc.shapes[shape];
     if (sh.light_id >= 0) {
         const LightD &l = sc.lights[sh.light_id];
@@ -269,6 +273,9 @@ struct BounceSample {
         if (pk.shape_id >= 0) {
             Surf lp = sample_tri(sc.shapes[pk.shape_id], pk.tri_id, ld.uv);
             put_ray(q_nee, idx, shadow_ray_to(c.sp.position, lp.position), false);
+        } else if (sc.envmap != nullptr) {
+            Ray er = make_ray(c.sp.position, envmap_sample(*sc.envmap, ld.uv));      // tmin 1e-3f, tmax inf (:709-711)
+            put_ray(q_nee, idx, er, false);
         } else {
             Ray dead = make_ray(c.sp.position, v3(0));
             put_ray(q_nee, idx, dead, true);
@@ -297,8 +304,8 @@ struct BounceEval {
 
 // NEE + BSDF-hit emission with power-2 MIS (src/path_contribution.cpp:24-118).
 RDR_FN BounceEval eval_bounce(const SceneD &sc, const VertexCtx &c, V3 thr,
-                              bool nee_visible, const LightPick &pk, const Surf &lp,
-                              int bshape, const Surf &bp) {
+                              bool nee_visible, const LightPick &pk, const Surf &lp, V2 light_uv,
+                              int bshape, const Surf &bp, V3 bsdf_dir) {
     BounceEval r;
     r.nee = r.scatter = r.next_thr = v3(0);
     r.next_thr_valid = false;
@@ -318,6 +325,17 @@ RDR_FN BounceEval eval_bounce(const SceneD &sc, const VertexCtx &c, V3 thr,
                 double mis = 1 / (1 + sq(pdf_b / pdf_nee));
                 r.nee = (mis * g / pdf_nee) * f * v3f(l.intensity);
             }
+        }
+    } else if (nee_visible && sc.envmap != nullptr) {
+        // environment light: wo is the sampled direction itself, no geometry term (:51-70)
+        V3 wo = envmap_sample(*sc.envmap, light_uv);
+        double pdf_nee = envmap_pdf(*sc.envmap, wo) * sc.light_pmf[sc.num_lights - 1];
+        if (pdf_nee > 0) {
+            V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
+            V3 Le = envmap_eval(*sc.envmap, wo, raydiff_zero());
+            double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough);
+            double mis = 1 / (1 + sq(pdf_b / pdf_nee));
+            r.nee = (mis / pdf_nee) * f * Le;
         }
     }
     if (bshape >= 0) {
@@ -342,6 +360,17 @@ RDR_FN BounceEval eval_bounce(const SceneD &sc, const VertexCtx &c, V3 thr,
             r.next_thr = thr * (f / pdf_b);
         } else {
             r.next_thr = v3(0);
+        }
+    } else if (sc.envmap != nullptr) {
+        // the BSDF-sampled ray left the scene: it sees the environment light (:99-118)
+        V3 wo = bsdf_dir;
+        double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough);
+        if (len_sq(wo) > 0 && pdf_b > 1e-20f) {
+            V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
+            V3 Le = envmap_eval(*sc.envmap, wo, raydiff_zero());
+            double pdf_nee = envmap_pdf(*sc.envmap, wo) * sc.light_pmf[sc.num_lights - 1];
+            double mis = 1 / (1 + sq(pdf_nee / pdf_b));
+            r.scatter = (mis / pdf_b) * f * Le;
         }
     }
     return r;
@@ -372,7 +401,7 @@ struct BounceContrib {
             if (vn.erd) st_rdiff(vn.erd, vn.n, p, tmp);
         }
         V3 thr = ld3(v.thr, v.n, p, 0);
-        BounceEval e = eval_bounce(sc, c, thr, !blocked, pk, lp, hb.shape, bp);
+        BounceEval e = eval_bounce(sc, c, thr, !blocked, pk, lp, ld.uv, hb.shape, bp, load_ray(vn, p).dir);
         if (e.next_thr_valid) st3(vn.thr, vn.n, p, 0, e.next_thr);
         V3 pc = thr * (e.nee + e.scatter);
         if (sink.image) {

@@ -97,9 +97,32 @@ class AreaLight:
         self.two_sided, self.directly_visible = two_sided, directly_visible
 
 
+class EnvironmentMap:
+    """Latitude-longitude environment light (pyredner/envmap.py): `values` is a Texture (or an [H, W, 3] tensor),
+    the sampling tables are rebuilt from level 0 exactly as pyredner.EnvironmentMap.generate_envmap_pdf does."""
+
+    def __init__(self, values, env_to_world=None, directly_visible=True):
+        self.values = values if isinstance(values, Texture) else Texture(values)
+        self.env_to_world = env_to_world if env_to_world is not None else torch.eye(4, 4)
+        self.world_to_env = torch.inverse(self.env_to_world).contiguous()
+        self.directly_visible = directly_visible
+        t = self.values.mipmap[0].detach()
+        lum = 0.212671 * t[:, :, 0] + 0.715160 * t[:, :, 1] + 0.072169 * t[:, :, 2]
+        cdf_xs_ = torch.cumsum(lum, dim=1)
+        y_weight = torch.sin(math.pi * (torch.arange(lum.shape[0], dtype=torch.float32, device=lum.device) + 0.5)
+                             / float(lum.shape[0]))
+        cdf_ys_ = torch.cumsum(cdf_xs_[:, -1] * y_weight, dim=0)
+        self.pdf_norm = (lum.shape[0] * lum.shape[1]) / (cdf_ys_[-1].item() * (2 * math.pi * math.pi))
+        cdf_xs = (cdf_xs_ - cdf_xs_[:, 0:1]) / torch.max(cdf_xs_[:, (lum.shape[1] - 1):lum.shape[1]],
+                                                        1e-8 * torch.ones(cdf_xs_.shape[0], 1, device=lum.device))
+        cdf_ys = (cdf_ys_ - cdf_ys_[0]) / torch.max(cdf_ys_[-1], torch.tensor([1e-8], device=lum.device))
+        self.sample_cdf_ys, self.sample_cdf_xs = cdf_ys.contiguous(), cdf_xs.contiguous()
+
+
 class Scene:
-    def __init__(self, camera, shapes, materials, area_lights):
+    def __init__(self, camera, shapes, materials, area_lights, envmap=None):
         self.camera, self.shapes, self.materials, self.area_lights = camera, shapes, materials, area_lights
+        self.envmap = envmap
 
 
 def _data_ptr(t):
@@ -185,6 +208,13 @@ class RenderFunction(torch.autograd.Function):
             meta['materials'].append(mm)
         meta['lights'] = [{'shape_id': l.shape_id, 'intensity': put(l.intensity, cpu), 'two_sided': l.two_sided,
                            'directly_visible': l.directly_visible} for l in scene.area_lights]
+        meta['envmap'] = None
+        if scene.envmap is not None:
+            em = scene.envmap
+            meta['envmap'] = {'levels': [put(l, device) for l in em.values.mipmap], 'uv_scale': put(em.values.uv_scale, device),
+                              'env_to_world': put(em.env_to_world, cpu), 'world_to_env': put(em.world_to_env, cpu),
+                              'sample_cdf_ys': put(em.sample_cdf_ys, device), 'sample_cdf_xs': put(em.sample_cdf_xs, device),
+                              'pdf_norm': em.pdf_norm, 'directly_visible': em.directly_visible}
         meta['use_primary_edge_sampling'] = bool(use_primary_edge_sampling and needs_visibility)
         meta['use_secondary_edge_sampling'] = bool(use_secondary_edge_sampling and needs_visibility)
         return [meta] + tensors
@@ -248,7 +278,16 @@ class RenderFunction(torch.autograd.Function):
                          for lm in meta['lights']]
         device = meta['device']
         index = device.index if device.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
-        u.scene = rd.Scene(u.camera, u.shapes, u.materials, u.area_lights, None, device.type == 'cuda', index,
+        u.envmap = None
+        if meta['envmap'] is not None:
+            em = meta['envmap']
+            levels = [T(i) for i in em['levels']]
+            values = rd.Texture3([fp(l) for l in levels], [int(l.shape[1]) for l in levels], [int(l.shape[0]) for l in levels],
+                                 3, fp(T(em['uv_scale'])))
+            u.envmap = rd.EnvironmentMap(values, fp(T(em['env_to_world'])), fp(T(em['world_to_env'])),
+                                         fp(T(em['sample_cdf_ys'])), fp(T(em['sample_cdf_xs'])), em['pdf_norm'],
+                                         em['directly_visible'])
+        u.scene = rd.Scene(u.camera, u.shapes, u.materials, u.area_lights, u.envmap, device.type == 'cuda', index,
                            meta['use_primary_edge_sampling'], meta['use_secondary_edge_sampling'])
         u.options = rd.RenderOptions(seed[0], meta['num_samples'][0], meta['max_bounces'], meta['channels'],
                                      meta['sampler_type'], meta['sample_pixel_center'])
@@ -319,7 +358,14 @@ class RenderFunction(torch.autograd.Function):
                                     d_tex(rd.Texture3, mm['normal_map'])) for mm in meta['materials']]
         d_lights = [rd.DAreaLight(fp(zeros_like_arg(lm['intensity']))) for lm in meta['lights']]
         index = device.index if device.index is not None else 0
-        d_scene = rd.DScene(d_camera, d_shapes, d_materials, d_lights, None, device.type == 'cuda', index)
+        d_envmap = None
+        if meta['envmap'] is not None:
+            em = meta['envmap']
+            levels = [zeros_like_arg(i) for i in em['levels']]
+            d_values = rd.Texture3([fp(l) for l in levels], [int(l.shape[1]) for l in levels], [int(l.shape[0]) for l in levels],
+                                   3, fp(zeros_like_arg(em['uv_scale'])))
+            d_envmap = rd.DEnvironmentMap(d_values, fp(zeros_like_arg(em['world_to_env'])))
+        d_scene = rd.DScene(d_camera, d_shapes, d_materials, d_lights, d_envmap, device.type == 'cuda', index)
         u.options.seed = ctx.seed[1]
         u.options.num_samples = meta['num_samples'][1]
         if 'sample_offset' in meta:

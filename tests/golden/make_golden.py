@@ -100,6 +100,8 @@ CASES = {
     # SAMPLE_EXACT_ON_CPU_ONLY below)
     'bunny_box_fisheye_nosec_32x32x4': ('bunny_box_fisheye', 32, 4, 2, None, {'use_secondary_edge_sampling': False}),
     'bunny_box_panorama_nosec_32x32x4': ('bunny_box_panorama', 32, 4, 2, None, {'use_secondary_edge_sampling': False}),
+    # environment light only: NEE / BSDF-miss lookups, envmap adjoint, edge rays that reach the environment
+    'envmap_sphere_48x48x4': ('envmap_sphere', 48, 4, 2),
     # radiance after a 3-wide channel: the reference adds path contributions at the channel INDEX (src/channels.cpp:27)
     'textured_sphere_radiance_last_48x48x2': ('textured_sphere', 48, 2, 2, ['position', 'radiance']),
     'textured_sphere_generic_48x48x4': ('textured_sphere', 48, 4, 1,
@@ -168,6 +170,10 @@ def render_case(backend, builder, res, spp, mb, channels=None, opts=None, device
             for lv, t in enumerate(tex.mipmap):
                 if name != 'diffuse' or lv > 0:
                     grab('grad_mat%d_%s_L%d' % (i, name, lv), t)
+    if getattr(sc, 'envmap', None) is not None:
+        for lv, t in enumerate(sc.envmap.values.mipmap):
+            grab('grad_envmap_L%d' % lv, t)
+        grab('grad_envmap_env_to_world', sc.envmap.env_to_world)
     if sc.camera.position is not None:
         grab('grad_cam_position', sc.camera.position)
     for name in ('look_at', 'up', 'intrinsic_mat', 'intrinsic_mat_inv', 'distortion_params'):

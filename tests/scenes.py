@@ -184,3 +184,28 @@ def bunny_box_fisheye(device, resolution=(32, 32)):
 
 def bunny_box_panorama(device, resolution=(32, 32)):
     return _bunny_box_inside(device, resolution, 3)
+
+
+def envmap_sphere(device, resolution=(48, 48)):
+    """Environment-lit scene in the spirit of tests/test_envmap.py / test_teapot_reflectance.py: a glossy
+    UV sphere with smooth normals on a diffuse ground quad, lit only by a mip-mapped lat-long map."""
+    from redner_amd.render_pytorch import EnvironmentMap
+    base = textured_sphere(device, resolution)
+    sphere = base.shapes[0]
+    ground = Shape(_t([[-4.0, -1.4, -4.0], [4.0, -1.45, -4.0], [-4.0, -1.5, 4.0], [4.0, -1.35, 4.0]], device, grad=True),
+                   _t([[0, 2, 1], [1, 2, 3]], device, torch.int32), 1)
+    mats = [Material(diffuse_reflectance=_t([0.3, 0.25, 0.2], device, grad=True),
+                     specular_reflectance=_t([0.4, 0.4, 0.45], device, grad=True),
+                     roughness=_t([0.25], device, grad=True)),
+            Material(diffuse_reflectance=_t([0.5, 0.5, 0.5], device, grad=True))]
+    h, w = 16, 32
+    yy, xx = np.meshgrid((np.arange(h) + 0.5) / h, (np.arange(w) + 0.5) / w, indexing='ij')
+    sky = 0.3 + 0.7 * (1 - yy)
+    sun = 30.0 * np.exp(-((xx - 0.3) ** 2 + (yy - 0.25) ** 2) / 0.004)
+    img = np.stack([sky + sun, 0.9 * sky + 0.9 * sun, 1.2 * sky + 0.7 * sun], axis=2).astype(np.float32)
+    levels = [l.to(device).requires_grad_(True) for l in _mip_chain(torch.from_numpy(img))]
+    ang = 0.4
+    e2w = _t([[np.cos(ang), 0.0, np.sin(ang), 0.0], [0.0, 1.0, 0.0, 0.0],
+              [-np.sin(ang), 0.0, np.cos(ang), 0.0], [0.0, 0.0, 0.0, 1.0]], 'cpu', grad=True)
+    env = EnvironmentMap(Texture(levels), env_to_world=e2w)
+    return Scene(base.camera, [sphere, ground], mats, [], envmap=env)
