@@ -212,17 +212,19 @@ RDR_FN void accum_outer3(double *g, V3 a, V3 b, int rows) {          // g[r][c] 
     for (int r = 0; r < rows; ++r) for (int c = 0; c < 3; ++c) accum(g + 3 * r + c, av[r] * bv[c]);
 }
 // Tail shared by every camera model: undo the lens distortion on the way back to the screen position.
-RDR_FN void adj_screen_tail(const CameraD &cam, V2 screen, V2 distorted_bar, const GCamera &g, V2 *screen_bar) {
+RDR_FN void adj_screen_tail(const CameraD &cam, V2 screen, V2 distorted_bar, const GCamera &g, bool want, V2 &screen_bar) {
     V2 sb = v2(0, 0);
     adj_inverse_distort(cam.distortion, screen, distorted_bar, g.distortion, sb);
-    if (screen_bar) { screen_bar->x += sb.x; screen_bar->y += sb.y; }
+    if (want) { screen_bar.x += sb.x; screen_bar.y += sb.y; }
 }
 
 // Adjoint of primary_ray(): pushes ray_bar into the camera gradient; optionally returns the
 // screen-position adjoint.
-RDR_FN void adj_primary_ray(const CameraD &cam, V2 screen_in, const DRay &ray_bar, const GCamera &g, V2 *screen_bar) {
+// (want_screen_bar + reference instead of a nullable pointer: a pointer that may be null keeps the target in memory)
+RDR_FN void adj_primary_ray(const CameraD &cam, V2 screen_in, const DRay &ray_bar, const GCamera &g, bool want_screen_bar,
+                            V2 &screen_bar) {
     V2 screen = inverse_distort(cam.distortion, screen_in);
-    const bool want_screen = cam.distortion.defined || screen_bar != nullptr;
+    const bool want_screen = cam.distortion.defined || want_screen_bar;
     double ar = aspect_of(cam);
     M4 c2w_bar = m4_zero();
     switch (cam.kind) {
@@ -239,7 +241,7 @@ RDR_FN void adj_primary_ray(const CameraD &cam, V2 screen_in, const DRay &ray_ba
             scatter_cam_to_world(cam, c2w_bar, g);
             if (want_screen) {
                 V3 pt_bar = mul_t(cam.intrinsic_mat_inv, lorg_bar);
-                adj_screen_tail(cam, screen_in, v2(pt_bar.x * 2, pt_bar.y * (-2 / ar)), g, screen_bar);
+                adj_screen_tail(cam, screen_in, v2(pt_bar.x * 2, pt_bar.y * (-2 / ar)), g, want_screen_bar, screen_bar);
             }
         } break;
         case kCamFisheye: {
@@ -267,7 +269,7 @@ RDR_FN void adj_primary_ray(const CameraD &cam, V2 screen_in, const DRay &ray_ba
                 double y_bar = phi_bar * (x / (x * x + y * y));
                 x_bar += (r_bar * (x / r));
                 y_bar += (r_bar * (y / r));
-                adj_screen_tail(cam, screen_in, v2(2 * x_bar, 2 * y_bar), g, screen_bar);
+                adj_screen_tail(cam, screen_in, v2(2 * x_bar, 2 * y_bar), g, want_screen_bar, screen_bar);
             }
         } break;
         case kCamPanorama: {
@@ -286,7 +288,7 @@ RDR_FN void adj_primary_ray(const CameraD &cam, V2 screen_in, const DRay &ray_ba
                 double st_bar = dir_bar.x * cp + dir_bar.z * sp, ct_bar = dir_bar.y;
                 double phi_bar = cp_bar * (-sp) + sp_bar * cp;
                 double theta_bar = ct_bar * (-st) + st_bar * ct;
-                adj_screen_tail(cam, screen_in, v2(phi_bar * double(2 * M_PI), theta_bar * double(M_PI)), g, screen_bar);
+                adj_screen_tail(cam, screen_in, v2(phi_bar * double(2 * M_PI), theta_bar * double(M_PI)), g, want_screen_bar, screen_bar);
             }
         } break;
         default: {
@@ -304,7 +306,7 @@ RDR_FN void adj_primary_ray(const CameraD &cam, V2 screen_in, const DRay &ray_ba
             scatter_cam_to_world(cam, c2w_bar, g);
             if (want_screen) {
                 V3 pt_bar = mul_t(cam.intrinsic_mat_inv, dir_bar);
-                adj_screen_tail(cam, screen_in, v2(pt_bar.x * 2, pt_bar.y * (-2 / ar)), g, screen_bar);
+                adj_screen_tail(cam, screen_in, v2(pt_bar.x * 2, pt_bar.y * (-2 / ar)), g, want_screen_bar, screen_bar);
             }
         } break;
     }

@@ -18,6 +18,7 @@
 #include <string>
 
 #define RDR_FN __host__ __device__ inline
+#define RDR_INLINE_CALL [[clang::always_inline]]
 // Per-lane traversal stacks live in LDS (one column per thread of the 256-thread workgroup, entry k
 // of lane t at [k * 256 + t]: conflict-free), not in scratch: large scratch frames make the HSA
 // runtime re-allocate scratch per dispatch (tens of ms, see profiles/r1_notes.md).
@@ -109,7 +110,9 @@ inline void set_replicas(size_t stride_doubles, int replicas) {
 template <class F>
 __global__ void __launch_bounds__(256) stage_kernel(F f, int n) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) f(i);
+    // a stage body that is instantiated twice (plain + LeanStage) must still be inlined into each kernel:
+    // an out-of-line call would pass the whole functor through scratch
+    if (i < n) { RDR_INLINE_CALL f(i); }
 }
 
 template <class F>

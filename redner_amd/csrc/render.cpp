@@ -57,7 +57,8 @@ ChannelLayout layout_of(const rdr_render_options &o, int max_generic) {
     if (o.num_channels > kMaxChannels) throw std::runtime_error("render: too many channels");
     if (max_generic > kMaxGeneric) throw std::runtime_error("render: generic textures wider than 16 channels are not supported");
     l.ch.n = o.num_channels; l.ch.max_generic = max_generic; l.ch.radiance_off = -1;
-    for (int i = 0; i < kMaxChannels; ++i) l.ch.id[i] = i < o.num_channels ? o.channels[i] : 0;
+    l.ch.id = nullptr;                 // device copy made by render()
+    l.ch.radiance_only = o.num_channels == 1 && o.channels[0] == RDR_CH_RADIANCE;
     int d = 0;
     for (int i = 0; i < o.num_channels; ++i) {
         if (o.channels[i] == RDR_CH_RADIANCE) {
@@ -93,14 +94,25 @@ uint64_t pcg_stream_seed(const rdr_render_options &o) {
     return (uint64_t)o.seed + (uint64_t)o.sample_offset * 0x9E3779B97F4A7C15ULL;
 }
 
+bool scene_is_lean(const Scene &scene, const ChannelsD &ch) {
+    const CameraD &c = scene.d.cam;
+    return scene.d.envmap == nullptr && c.kind == kCamPerspective && !c.distortion.defined && ch.radiance_only;
+}
+
+// Launch `f`, or its lean specialisation when the scene allows it (see LeanStage in stages_fwd.h).
+template <class F> void launch_v(bool lean, int n, const F &f) {
+    if (lean) exec::launch(n, LeanStage<F>{f}); else exec::launch(n, f);
+}
+
 // One NEE + BSDF bounce over the live lanes of `v`; fills `vn` and the next live-lane list.
 int run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng_shift,
                const int *active, int num_active, const VSlice &v, const VSlice &vn,
                const Queues &q, const Sink &sink, int *next_active) {
-    exec::launch(num_active, BounceSample{scene.d, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
+    const bool lean = scene_is_lean(scene, sink.ch);
+    launch_v(lean, num_active, BounceSample{scene.d, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
     exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true);
     exec::trace(scene.bvh, q.bsdf, q.h_bsdf, num_active, false);
-    exec::launch(num_active, BounceContrib{scene.d, rng, dim, rng_shift, active, v, vn, q.h_nee, q.h_bsdf, sink});
+    launch_v(lean, num_active, BounceContrib{scene.d, rng, dim, rng_shift, active, v, vn, q.h_nee, q.h_bsdf, sink});
     return exec::compact(active, num_active, next_active, KeepHit{vn.shape});
 }
 
@@ -230,6 +242,7 @@ struct Backward {
     AdjState adj;
 
     ChannelsD ch;
+    bool lean = false;                 // the scene qualifies for the lean stage specialisations
     uint64_t *pcg_edge = nullptr;      // PCG edge sampler: one state per slot (src/pathtracer.cpp:221-222)
     double *multipliers = nullptr;     // [2P x nd], primary-edge channel weights (non-radiance channels only)
 
@@ -237,6 +250,7 @@ struct Backward {
              const float *d_image_, float *screen_grad_, double weight_, int nd_, int radiance_dim_, const ChannelsD &ch_)
         : scene(scene_), opt(opt_), P(P_), B(B_), d_image(d_image_), screen_grad(screen_grad_), weight(weight_),
           nd(nd_), radiance_dim(radiance_dim_), grads(scene_, ds), ch(ch_) {
+        lean = scene_is_lean(scene, ch);
         adj.n = P;
         adj.thr = arena.get<double>((size_t)3 * P);
         adj.ray_dir = arena.get<double>((size_t)3 * P);
@@ -263,7 +277,7 @@ struct Backward {
             sec_recs = arena.get<SecondaryEdgeRec>(P);
             sec_picks = arena.get<SecPick>(P);
             sec_mode = arena.get<unsigned char>(P);
-            if (!(ch.n == 1 && ch.id[0] == 0)) multipliers = arena.get<double>((size_t)L * nd);
+            if (!ch.radiance_only) multipliers = arena.get<double>((size_t)L * nd);
             if (opt.sampler_type == RDR_SAMPLER_INDEPENDENT) {
                 pcg_edge = arena.get<uint64_t>(P);
                 exec::launch(P, PcgInit{pcg_edge, pcg_stream_seed(opt) + 131071U});
@@ -321,21 +335,21 @@ struct Backward {
             if (nA <= 0) continue;
             const int *act = active + (size_t)d * P;
             AdjBounceArgs ba{scene.d, grads.g, rng, dim0 + 7 * d, act, vs[d], vs[d + 1], d_image, nd, radiance_dim, weight, adj};
-            exec::launch(nA, AdjBounceScatter{ba});
-            exec::launch(nA, AdjBounceNee{ba});
+            launch_v(lean, nA, AdjBounceScatter{ba});
+            launch_v(lean, nA, AdjBounceNee{ba});
             if (edges_on && scene.use_secondary_edges) {
                 // ---- secondary (shadow / inter-reflection) edges at this vertex, :500-706 ----
                 const EdgeSceneD &es = scene.edges->d;
                 const int lanes = 2 * nA;
                 SecEdgeArgs sa{scene.d, es, rng, dim0 + 7 * d, edge_rng_at(rng_edge, edim), edim, act, vs[d]};
-                exec::launch(nA, SecEdgeSetup{sa, sec_mode, sec_recs, sec_picks, ea, edge_tmin});
+                launch_v(lean, nA, SecEdgeSetup{sa, sec_mode, sec_recs, sec_picks, ea, edge_tmin});
                 int nH = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 1});
-                exec::launch(nH, SecEdgePickH{sa, elist[0], sec_picks});
+                launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
                 int nN = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 2});
-                exec::launch(nN, SecEdgePickN{sa, elist[0], sec_picks});
+                launch_v(lean, nN, SecEdgePickN{sa, elist[0], sec_picks});
                 debug_dump("sec_mode", sample_id, d, sec_mode, (size_t)nA);
                 debug_dump("sec_picks", sample_id, d, sec_picks, sizeof(SecPick) * (size_t)nA);
-                exec::launch(nA, SecEdgeFinish{sa, sec_mode, sec_picks, d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});
+                launch_v(lean, nA, SecEdgeFinish{sa, sec_mode, sec_picks, d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});
                 debug_dump("sec_recs", sample_id, d, sec_recs, sizeof(SecondaryEdgeRec) * (size_t)nA);
                 edim += 4;
                 edge_rng_consumed(nA, 4);
@@ -344,33 +358,33 @@ struct Backward {
                 exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
                 exec::launch(n0, RecordHits{elist[0], ea, q.h_bsdf});
                 if (ea.erd) exec::launch(n0, MirrorSurfDiff{scene.d, elist[0], ea});
-                exec::launch(nA, SecondaryEdgeWeights{scene.d, sec_recs, ea, hit_pos});
+                launch_v(lean, nA, SecondaryEdgeWeights{scene.d, sec_recs, ea, hit_pos});
                 exec::zero(edge_contrib, sizeof(double) * lanes);
-                exec::launch(n0, ShadeRecorded{scene.d, elist[0], ea, esink});
+                launch_v(lean, n0, ShadeRecorded{scene.d, elist[0], ea, esink});
                 int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
                 edim += trace_edge_paths(rng_edge, edim, n1, nA, d + 1, q, esink, false);
                 exec::launch(nA, SecondaryEdgeDerivatives{scene.d, grads.g, act, sec_recs, hit_pos, ea.n, edge_contrib, adj});
             }
         }
-        exec::launch(P, AdjPrimary{scene.d, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
+        launch_v(lean, P, AdjPrimary{scene.d, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
                                    adj, screen_grad, ch});
         if (edges_on && scene.use_primary_edges) {
             // ---- primary (camera-visible silhouette) edges, :766-942 ----
             const EdgeSceneD &es = scene.edges->d;
             const int lanes = 2 * P;
             exec::zero(edge_contrib, sizeof(double) * lanes);
-            exec::launch(P, SamplePrimaryEdges{scene.d, es, edge_rng_at(rng_edge, edim), edim, d_image, nd, radiance_dim, prim_recs, ea, multipliers});
+            launch_v(lean, P, SamplePrimaryEdges{scene.d, es, edge_rng_at(rng_edge, edim), edim, d_image, nd, radiance_dim, prim_recs, ea, multipliers});
             edim += 2;
             edge_rng_consumed(P, 2);
             int n0 = exec::compact((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
             if (ea.erd) exec::launch(n0, LoadLaneDiff{elist[0], ea});
             exec::launch(n0, QueueRays{elist[0], ea, nullptr, q.bsdf});
             exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
-            exec::launch(n0, ShadePrimary{scene.d, elist[0], ea, q.h_bsdf, psink});
+            launch_v(lean, n0, ShadePrimary{scene.d, elist[0], ea, q.h_bsdf, psink});
             if (ea.erd) exec::launch(n0, MirrorSurfDiff{scene.d, elist[0], ea});
             int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
             edim += trace_edge_paths(rng_edge, edim, n1, P, 0, q, esink, true);
-            exec::launch(P, PrimaryEdgeDerivatives{scene.d, grads.g, prim_recs, edge_contrib, screen_grad});
+            launch_v(lean, P, PrimaryEdgeDerivatives{scene.d, grads.g, prim_recs, edge_contrib, screen_grad});
         }
     }
     void flush() { grads.flush(); }
@@ -398,6 +412,11 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     if (2 + 7 * B > kSamplerDims) throw std::runtime_error("render: max_bounces exceeds the Sobol' table");
 
     Arena arena;
+    {
+        int *ids = arena.get<int>(kMaxChannels);
+        exec::upload(ids, opt.channels, sizeof(int) * opt.num_channels);
+        lay.ch.id = ids;
+    }
     std::vector<VSlice> vs(B + 1);
     for (int d = 0; d <= B; ++d) vs[d] = make_slice(arena, P, d < B);
     int *active = arena.get<int>((size_t)(B + 1) * P);
@@ -415,15 +434,16 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         exec::launch(P, PcgInit{pcg_main, pcg_stream_seed(opt)});
     }
 
+    const bool lean = scene_is_lean(scene, lay.ch);
     for (int s = 0; s < opt.num_samples; ++s) {
         const int sample_id = opt.sample_offset + s;
         SamplerD rng{scene.sobol_table, opt.seed, sample_id, pcg_main, 0};
         Sink sink{image, nullptr, lay.nd, lay.radiance_dim, weight, lay.ch, nullptr};
 
         // ---- camera vertex ----
-        exec::launch(P, GenPrimary{scene.d, rng, opt.sample_pixel_center, vs[0], q.bsdf});
+        launch_v(lean, P, GenPrimary{scene.d, rng, opt.sample_pixel_center, vs[0], q.bsdf});
         exec::trace(scene.bvh, q.bsdf, q.h_bsdf, P, false);
-        exec::launch(P, ShadePrimary{scene.d, nullptr, vs[0], q.h_bsdf, sink});
+        launch_v(lean, P, ShadePrimary{scene.d, nullptr, vs[0], q.h_bsdf, sink});
         std::fill(num_active.begin(), num_active.end(), 0);
         num_active[0] = exec::compact((const int *)nullptr, P, active, KeepHit{vs[0].shape});
 

@@ -69,6 +69,7 @@ struct AdjBounceArgs {
 
 struct AdjBounceScatter {
     AdjBounceArgs a;
+    RDR_FN void make_lean() { lean_scene(a.sc); a.nd = 3; a.radiance_dim = 0; }
     RDR_FN void operator()(int idx) const {
         const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v, &vn = a.vn; const AdjState &adj = a.adj;
         int p = a.active[idx];
@@ -177,6 +178,7 @@ RDR_FN void adj_record_add(const AdjState &adj, int p, V3 thr_bar, V3 in_dir_bar
 
 struct AdjBounceNee {
     AdjBounceArgs a;
+    RDR_FN void make_lean() { lean_scene(a.sc); a.nd = 3; a.radiance_dim = 0; }
     // next-event estimation towards the environment light (src/path_contribution.cpp:295-338)
     RDR_FN void envmap_nee(int p, const LightDraw &ld) const {
         const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v;
@@ -320,6 +322,7 @@ struct AdjPrimary {
     SceneD sc; GScene g; SamplerD rng; int sample_center;
     VSlice v0; const float *d_image; int nd, radiance_dim; double weight;
     AdjState adj; float *screen_grad; ChannelsD ch;
+    RDR_FN void make_lean() { lean_scene(sc); lean_channels(ch); nd = 3; radiance_dim = 0; }
     RDR_FN void operator()(int p) const {
         int shape = v0.shape[p];
         Ray ray = load_ray(v0, p);
@@ -347,7 +350,7 @@ struct AdjPrimary {
             adj_envmap_eval(*sc.envmap, ray.dir, rd, e_bar, g.envmap, mr_bar.dir, mrd_bar);
             V2 ms = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
             V2 mscr_bar = v2(0, 0);
-            adj_primary_ray(sc.cam, pixel_to_screen(sc.cam, p, ms), mr_bar, g.cam, screen_grad ? &mscr_bar : nullptr);
+            RDR_INLINE_CALL adj_primary_ray(sc.cam, pixel_to_screen(sc.cam, p, ms), mr_bar, g.cam, screen_grad != nullptr, mscr_bar);
             if (screen_grad) { screen_grad[2 * p] += (float)mscr_bar.x; screen_grad[2 * p + 1] += (float)mscr_bar.y; }
             return;
         }
@@ -356,7 +359,7 @@ struct AdjPrimary {
         RayDiff prd_bar = raydiff_zero();
         {
             Surf pt_bar = load_adj_point(adj, p);
-            if (!(ch.n == 1 && ch.id[0] == 0)) {
+            if (!ch.radiance_only) {
                 RayDiff tmp;
                 Surf sp = surf_at(sc.shapes[shape], v0.tri[p], ray, rd, tmp);
                 adj_first_hit_channels(sc, g, ch, d_image, weight, p, shape, sp, ray, pt_bar, r_bar.org);
@@ -374,10 +377,10 @@ struct AdjPrimary {
         r_bar.org += (prd_bar.org_dx * -sx + prd_bar.org_dy * -sy) / delta;
         r_bar.dir += (prd_bar.dir_dx * -sx + prd_bar.dir_dy * -sy) / delta;
         V2 scr_bar = v2(0, 0);
-        V2 *sb = screen_grad ? &scr_bar : nullptr;
-        adj_primary_ray(sc.cam, screen, r_bar, g.cam, sb);
-        adj_primary_ray(sc.cam, screen + v2(delta, 0), rx_bar, g.cam, sb);
-        adj_primary_ray(sc.cam, screen + v2(0, delta), ry_bar, g.cam, sb);
+        const bool sb = screen_grad != nullptr;
+        RDR_INLINE_CALL adj_primary_ray(sc.cam, screen, r_bar, g.cam, sb, scr_bar);
+        RDR_INLINE_CALL adj_primary_ray(sc.cam, screen + v2(delta, 0), rx_bar, g.cam, sb, scr_bar);
+        RDR_INLINE_CALL adj_primary_ray(sc.cam, screen + v2(0, delta), ry_bar, g.cam, sb, scr_bar);
         if (screen_grad) {
             screen_grad[2 * p] += (float)scr_bar.x;
             screen_grad[2 * p + 1] += (float)scr_bar.y;

@@ -82,6 +82,7 @@ struct RecordHits {
 // First-hit emission for lanes whose hit ids are already recorded.
 struct ShadeRecorded {
     SceneD sc; const int *active; VSlice v; Sink sink;
+    RDR_FN void make_lean() { lean_scene(sc); lean_channels(sink.ch); sink.multipliers = nullptr; }
     RDR_FN void operator()(int idx) const {
         int p = active[idx];
         shade_first_hit(sc, sink, v, p, v.shape[p], v.tri[p]);
@@ -114,6 +115,7 @@ struct SamplePrimaryEdges {
     const float *d_image; int nd, radiance_dim;
     PrimaryEdgeRec *recs; VSlice v;       // lanes 2*slot, 2*slot+1
     double *multipliers;                  // [2P x nd] per-channel weights of the two rays, or null
+    RDR_FN void make_lean() { lean_scene(sc); multipliers = nullptr; nd = 3; radiance_dim = 0; }
     RDR_FN void operator()(int slot) const {
         int l0 = 2 * slot, l1 = 2 * slot + 1;
         if (multipliers) for (int d = 0; d < 2 * nd; ++d) multipliers[(size_t)nd * l0 + d] = 0;
@@ -207,6 +209,7 @@ struct SamplePrimaryEdges {
 
 struct PrimaryEdgeDerivatives {
     SceneD sc; GScene g; const PrimaryEdgeRec *recs; const double *edge_contrib; float *screen_grad;
+    RDR_FN void make_lean() { lean_scene(sc); }
     RDR_FN void operator()(int slot) const {
         const PrimaryEdgeRec &rec = recs[slot];
         if (rec.edge.shape_id < 0) return;
@@ -613,6 +616,7 @@ struct SecEdgeArgs {          // what every stage of the sampler needs
 // mode[slot]: 0 = no sample, 1 = hierarchical pick, 2 = NEE-billboard pick.  Also resets the slot's outputs.
 struct SecEdgeSetup {
     SecEdgeArgs a; unsigned char *mode; SecondaryEdgeRec *recs; SecPick *picks; VSlice ev; double *edge_tmin;
+    RDR_FN void make_lean() { lean_scene(a.sc); }
     RDR_FN void operator()(int idx) const {
         int p = a.active[idx];
         int l0 = 2 * idx, l1 = 2 * idx + 1;
@@ -641,6 +645,7 @@ struct KeepMode {
 
 struct SecEdgePickH {
     SecEdgeArgs a; const int *slots; SecPick *picks;
+    RDR_FN void make_lean() { lean_scene(a.sc); }
     RDR_FN void operator()(int i) const {
         int idx = slots[i];
         SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
@@ -651,6 +656,7 @@ struct SecEdgePickH {
 };
 struct SecEdgePickN {
     SecEdgeArgs a; const int *slots; SecPick *picks;
+    RDR_FN void make_lean() { lean_scene(a.sc); }
     RDR_FN void operator()(int i) const {
         int idx = slots[i];
         SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
@@ -665,6 +671,7 @@ struct SecEdgeFinish {
     SecEdgeArgs a; const unsigned char *mode; const SecPick *picks;
     const float *d_image; int nd, radiance_dim;
     SecondaryEdgeRec *recs; VSlice ev; double *edge_tmin;
+    RDR_FN void make_lean() { lean_scene(a.sc); nd = 3; radiance_dim = 0; }
     RDR_FN void operator()(int idx) const {
         if (mode[idx] == 0) return;
         SecPick pkd = picks[idx];
@@ -758,6 +765,7 @@ RDR_FN V3 isect_jacobian(V3 org, V3 dir, V3 p, V3 n, V3 l) {
 
 struct SecondaryEdgeWeights {
     SceneD sc; const SecondaryEdgeRec *recs; VSlice ev; double *hit_pos;   // hit_pos: 3 x n, stride ev.n
+    RDR_FN void make_lean() { lean_scene(sc); }
     RDR_FN void scale_lane(const SecondaryEdgeRec &rec, int l) const {
         if (ev.shape[l] < 0) {
             if (sc.envmap != nullptr) {

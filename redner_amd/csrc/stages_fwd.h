@@ -79,7 +79,9 @@ constexpr int kMaxGeneric = 16;      // widest generic texture the G-buffer chan
 // which path contributions and the edge estimators use as a dimension offset (src/channels.cpp:27,
 // src/path_contribution.cpp:126, src/edge.cpp:451) -- equal to the true offset only while every channel
 // before radiance is one float wide.  The first-hit emission uses the true offset, radiance_off.  [quirk]
-struct ChannelsD { int n; int id[kMaxChannels]; int nd, radiance_dim, radiance_off, max_generic; };
+// The ids live in device memory, not in the functor: a run-time index into a functor member would force the whole
+// (kilobyte-sized) functor out of the kernel-argument segment into per-lane scratch.
+struct ChannelsD { int n; const int *id; int radiance_only; int nd, radiance_dim, radiance_off, max_generic; };
 
 // Where a stage deposits its result: the image (camera paths) and/or a per-lane scalar (edge paths).
 struct Sink {
@@ -91,6 +93,18 @@ struct Sink {
     const double *multipliers;   // per lane x nd weights of the primary-edge estimator, or null
 };
 
+// ---- lean specialisation ---------------------------------------------------------------------------
+// Most scenes have a pinhole camera without lens distortion, no environment light and render radiance only.
+// For them the host launches LeanStage<Stage>: the stage's scene copy gets those facts written in as constants,
+// so after inlining the compiler drops the other camera models, the environment-light estimators and the
+// G-buffer channels -- and with them the registers (and scratch) those paths would pin.
+RDR_FN void lean_scene(SceneD &sc) { sc.envmap = nullptr; sc.cam.kind = kCamPerspective; sc.cam.distortion.defined = 0; }
+RDR_FN void lean_channels(ChannelsD &ch) { ch.n = 1; ch.radiance_only = 1; ch.radiance_dim = 0; ch.radiance_off = 0; ch.nd = 3; }
+template <class Stage> struct LeanStage {
+    Stage f;
+    RDR_FN void operator()(int i) const { Stage g = f; g.make_lean(); RDR_INLINE_CALL g(i); }
+};
+
 struct LightDraw { double light_sel, tri_sel; V2 uv; };
 RDR_FN LightDraw draw_light(const SamplerD &rng, int slot, int dim) {
     return LightDraw{rng.draw(slot, dim), rng.draw(slot, dim + 1), v2(rng.draw(slot, dim + 2), rng.draw(slot, dim + 3))};
@@ -100,6 +114,7 @@ RDR_FN LightDraw draw_light(const SamplerD &rng, int slot, int dim) {
 struct GenPrimary {
     SceneD sc; SamplerD rng; int sample_center;
     VSlice v0; rt::RayRec *q;
+    RDR_FN void make_lean() { lean_scene(sc); }
     RDR_FN void operator()(int p) const {
         V2 s = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
         RayDiff rd;
@@ -185,7 +200,7 @@ RDR_FN void shade_first_hit(const SceneD &sc, const Sink &sink, const VSlice &v,
     RayDiff rd = load_rdiff(v, p);
     V3 e = direct_emission(sc, shape, tri, ray, rd);
     V3 c = sink.weight * ld3(v.thr, v.n, p, 0) * e;
-    bool only_radiance = sink.ch.n == 1 && sink.ch.id[0] == 0;
+    bool only_radiance = sink.ch.radiance_only != 0;
     if (only_radiance) {
         if (sink.image) {
             float *px = sink.image + (size_t)sink.nd * p + sink.radiance_dim;
@@ -233,6 +248,7 @@ RDR_FN void shade_first_hit(const SceneD &sc, const Sink &sink, const VSlice &v,
 
 struct ShadePrimary {
     SceneD sc; const int *active; VSlice v; const rt::HitRec *hits; Sink sink;
+    RDR_FN void make_lean() { lean_scene(sc); lean_channels(sink.ch); sink.multipliers = nullptr; }
     RDR_FN void operator()(int idx) const {
         int p = active ? active[idx] : idx;
         rt::HitRec h = hits[idx];
@@ -261,6 +277,7 @@ RDR_FN VertexCtx load_vertex(const SceneD &sc, const VSlice &v, int p) {
 // ---- stage: draw the NEE point and the BSDF direction, emit both rays ---------------------------
 struct BounceSample {
     SceneD sc; SamplerD rng; int dim, rng_shift;
+    RDR_FN void make_lean() { lean_scene(sc); }
     const int *active; VSlice v, vn;
     rt::RayRec *q_nee, *q_bsdf;
     RDR_FN void operator()(int idx) const {
@@ -382,6 +399,7 @@ struct BounceContrib {
     const int *active; VSlice v, vn;
     const rt::HitRec *h_nee, *h_bsdf;
     Sink sink;
+    RDR_FN void make_lean() { lean_scene(sc); lean_channels(sink.ch); }
     RDR_FN void operator()(int idx) const {
         int p = active[idx];
         int slot = p >> rng_shift;

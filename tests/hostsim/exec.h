@@ -13,6 +13,7 @@
 #include <string>
 
 #define RDR_FN inline
+#define RDR_INLINE_CALL
 #define RDR_DEV_FN inline
 #define RDR_STACK_DECL(T, name, N) T name[N]
 #define RDR_STACK_AT(name, k) name[k]
