@@ -534,6 +534,7 @@ EdgeData *build_edge_data(Scene &scene) {
                 if (nd.edge_id == -1 && nd.child0 >= 0) { todo.push_back({nd.child0, depth + 1}); todo.push_back({nd.child1, depth + 1}); }
             }
             if (max_depth + 2 > 64) throw std::runtime_error("edge hierarchy deeper than the traversal stack (64)");
+            ed->max_stack = std::max(ed->max_stack, max_depth + 2);
         }
     }
 
@@ -549,9 +550,26 @@ EdgeData *build_edge_data(Scene &scene) {
     d.edges = (const EdgeD *)up(edges.data(), sizeof(EdgeD) * edges.size());
     d.primary_pmf = ed->primary_pmf.empty() ? nullptr : (const double *)up(ed->primary_pmf.data(), sizeof(double) * ne);
     d.primary_cdf = ed->primary_cdf.empty() ? nullptr : (const double *)up(ed->primary_cdf.data(), sizeof(double) * ne);
-    d.cs_nodes = ed->cs_nodes.empty() ? nullptr : (const EdgeNode *)up(ed->cs_nodes.data(), sizeof(EdgeNode) * ed->cs_nodes.size());
-    d.ncs_nodes = ed->ncs_nodes.empty() ? nullptr : (const EdgeNode *)up(ed->ncs_nodes.data(), sizeof(EdgeNode) * ed->ncs_nodes.size());
+    auto compact = [&](const std::vector<EdgeNode> &nodes) -> const EdgeNodeC * {
+        if (nodes.empty()) return nullptr;
+        std::vector<EdgeNodeC> c(nodes.size());
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            const EdgeNode &n = nodes[i];
+            const double lo[3] = {n.p_min.x, n.p_min.y, n.p_min.z}, hi[3] = {n.p_max.x, n.p_max.y, n.p_max.z};
+            for (int k = 0; k < 3; ++k) {
+                c[i].p_min[k] = (float)lo[k]; c[i].p_max[k] = (float)hi[k];
+                if ((double)c[i].p_min[k] != lo[k] || (double)c[i].p_max[k] != hi[k])
+                    throw std::runtime_error("edge hierarchy: spatial bounds are not fp32 values");   // cannot happen: vertices are fp32
+            }
+            c[i].dx_min = n.d_min.x; c[i].dx_max = n.d_max.x; c[i].wlen = n.wlen;
+            c[i].child0 = n.child0; c[i].child1 = n.child1; c[i].edge_id = n.edge_id; c[i].pad = 0;
+        }
+        return (const EdgeNodeC *)up(c.data(), sizeof(EdgeNodeC) * c.size());
+    };
+    d.cs_nodes = compact(ed->cs_nodes);
+    d.ncs_nodes = compact(ed->ncs_nodes);
     d.edge_bounds_expand = ed->edge_bounds_expand;
+    d.max_stack = ed->max_stack;
     d.cam_org = cam_org;
     d.ltc = scene.ltc_table;
     return ed.release();

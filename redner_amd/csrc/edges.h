@@ -28,19 +28,35 @@ struct EdgeNode {
     int parent, child0, child1, edge_id;   // edge_id >= 0 marks a leaf
 };
 
+// What the samplers read, 64 bytes per node (one or two per cache line instead of a 128-byte EdgeNode):
+//  * spatial bounds are unions of fp32 vertex coordinates, hence exact in fp32;
+//  * of the Hough-space bounds only the x interval can ever decide the reference's sphere/box test: its loop
+//    returns at the first axis whose partial distance is within the radius, and partial sums only grow, so the
+//    verdict is the x term's (src/aabb.h:158-170).  [quirk]
+struct EdgeNodeC {
+    float p_min[3], p_max[3];
+    double dx_min, dx_max;
+    double wlen;
+    int child0, child1, edge_id, pad;
+};
+static_assert(sizeof(EdgeNodeC) == 64, "EdgeNodeC must stay one half cache line");
+RDR_FN V3 node_pmin(const EdgeNodeC &n) { return V3{(double)n.p_min[0], (double)n.p_min[1], (double)n.p_min[2]}; }
+RDR_FN V3 node_pmax(const EdgeNodeC &n) { return V3{(double)n.p_max[0], (double)n.p_max[1], (double)n.p_max[2]}; }
+
 constexpr int kEdgeTreeBit = 1 << 30;
 
 struct EdgeSceneD {
     const EdgeD *edges;
     int num_edges;
     const double *primary_pmf, *primary_cdf;
-    const EdgeNode *cs_nodes, *ncs_nodes;    // null when the tree is empty
+    const EdgeNodeC *cs_nodes, *ncs_nodes;   // null when the tree is empty
     double edge_bounds_expand;
+    int max_stack;           // entries the NEE-mode traversal can need: deepest leaf level + 1
     V3 cam_org;
     const float *ltc;                         // tabM, 128 x 128 x 9
 };
 
-RDR_FN const EdgeNode &edge_node(const EdgeSceneD &es, int ref) {
+RDR_FN const EdgeNodeC &edge_node(const EdgeSceneD &es, int ref) {
     return (ref & kEdgeTreeBit) ? es.ncs_nodes[ref & (kEdgeTreeBit - 1)] : es.cs_nodes[ref];
 }
 RDR_FN bool edge_ref_is_3d(int ref) { return (ref & kEdgeTreeBit) == 0; }
@@ -137,6 +153,7 @@ struct EdgeData {
     std::vector<double> primary_pmf, primary_cdf;
     std::vector<EdgeNode> cs_nodes, ncs_nodes;   // [internal | leaves]
     int cs_leaves = 0, ncs_leaves = 0;
+    int max_stack = 2;             // see EdgeSceneD::max_stack
     double edge_bounds_expand = 0;
     EdgeSceneD d;            // device view
 };

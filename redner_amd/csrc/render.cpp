@@ -346,7 +346,18 @@ struct Backward {
                 int nH = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 1});
                 launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
                 int nN = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 2});
-                launch_v(lean, nN, SecEdgePickN{sa, elist[0], sec_picks});
+                const int need = es.max_stack;
+                if (need <= 24) launch_v(lean, nN, SecEdgePickN<24>{sa, elist[0], sec_picks});
+                else if (need <= 32) launch_v(lean, nN, SecEdgePickN<32>{sa, elist[0], sec_picks});
+                else if (need <= 48) launch_v(lean, nN, SecEdgePickN<48>{sa, elist[0], sec_picks});
+                else launch_v(lean, nN, SecEdgePickN<64>{sa, elist[0], sec_picks});
+                if (nH == 0 && nN == 0) {
+                    // no slot samples an edge here (typically: every path already passed a diffuse vertex,
+                    // src/edge.cpp:1396-1401); only the sampler bookkeeping of the skipped stages remains
+                    edim += 4;
+                    edge_rng_consumed(nA, 4);
+                    continue;
+                }
                 debug_dump("sec_mode", sample_id, d, sec_mode, (size_t)nA);
                 debug_dump("sec_picks", sample_id, d, sec_picks, sizeof(SecPick) * (size_t)nA);
                 launch_v(lean, nA, SecEdgeFinish{sa, sec_mode, sec_picks, d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});

@@ -285,28 +285,26 @@ RDR_FN double ltc_bound(V3 lo, V3 hi, const LtcCtx &c) {
     return ml.z / nrm;
 }
 // Sphere/box overlap (Arvo), early-out form of src/aabb.h:158-174.
-RDR_FN bool sphere_box(V3 ctr, double radius, V3 lo, V3 hi) {
+// Only the x axis can decide (see EdgeNodeC): the first partial sum is the smallest one.
+RDR_FN bool sphere_box_x(double cx, double radius, double lo_x, double hi_x) {
     double dmin_ = 0, r2 = sq(radius);
-    for (int i = 0; i < 3; ++i) {
-        double ci = comp(ctr, i), li = comp(lo, i), hi_ = comp(hi, i);
-        if (ci < li) dmin_ += sq(ci - li);
-        else if (ci > hi_) dmin_ += sq(ci - hi_);
-        if (dmin_ <= r2) return true;
-    }
-    return false;
+    if (cx < lo_x) dmin_ += sq(cx - lo_x);
+    else if (cx > hi_x) dmin_ += sq(cx - hi_x);
+    return dmin_ <= r2;
 }
 RDR_FN bool may_hold_silhouette(const EdgeSceneD &es, int ref, V3 p) {
     if (edge_ref_is_3d(ref)) return true;
-    const EdgeNode &nd = edge_node(es, ref);
-    return sphere_box(0.5f * (p - es.cam_org), 0.5f * len(es.cam_org - p), nd.d_min, nd.d_max);
+    const EdgeNodeC &nd = edge_node(es, ref);
+    return sphere_box_x((0.5f * (p - es.cam_org)).x, 0.5f * len(es.cam_org - p), nd.dx_min, nd.dx_max);
 }
 RDR_FN double node_importance(const EdgeSceneD &es, int ref, const LtcCtx &c) {
-    const EdgeNode &nd = edge_node(es, ref);
+    const EdgeNodeC &nd = edge_node(es, ref);
     if (!edge_ref_is_3d(ref)) {
-        if (!sphere_box(0.5f * (c.pos - es.cam_org), 0.5f * len(es.cam_org - c.pos), nd.d_min, nd.d_max)) return 0;
+        if (!sphere_box_x((0.5f * (c.pos - es.cam_org)).x, 0.5f * len(es.cam_org - c.pos), nd.dx_min, nd.dx_max)) return 0;
     }
-    double brdf = ltc_bound(nd.p_min, nd.p_max, c);
-    V3 ctr = 0.5f * (nd.p_min + nd.p_max);
+    V3 lo = node_pmin(nd), hi = node_pmax(nd);
+    double brdf = ltc_bound(lo, hi, c);
+    V3 ctr = 0.5f * (lo + hi);
     return brdf * nd.wlen / dmax(len(c.pos - ctr), 1e-3);
 }
 
@@ -386,9 +384,11 @@ RDR_FN bool ray_box_expand(V3 lo, V3 hi, const Ray &r, double expand) {
 
 constexpr int kHSamples = 16;
 // hierarchical pick: every stack entry carries >= 1 of the 16 samples, so <= 16 entries are live
-constexpr int kHStack = 20;
-// NEE pick: depth-first with both children pushed: <= tree depth + 1 entries (checked at scene build)
-constexpr int kNStack = 64;
+// (three LDS columns per lane -- int, byte, double -- 13 B per entry: 3 workgroups fit in a CU's 160 KB)
+constexpr int kHStack = 16;
+// NEE pick: depth-first with both children pushed: <= tree depth + 1 entries.  The kernel is instantiated for a
+// few stack sizes and the host picks the smallest that covers the scene's trees (EdgeSceneD::max_stack).
+constexpr int kNStackMax = 64;
 
 struct HItem { int ref, num; double pmf; };
 
@@ -396,7 +396,10 @@ struct HItem { int ref, num; double pmf; };
 // and keeping one leaf by reservoir sampling.  Returns the edge id or -1; weight = 1/pmf.
 RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c,
                                       double sample, double resample, double &weight) {
-    RDR_STACK_DECL(HItem, stack, kHStack);
+    RDR_STACK_DECL(int, st_ref, kHStack);
+    RDR_STACK_DECL(unsigned char, st_num, kHStack);
+    RDR_STACK_DECL(double, st_pmf, kHStack);
+#define RDR_H_PUSH(r, n, p) { RDR_STACK_AT(st_ref, sp) = (r); RDR_STACK_AT(st_num, sp) = (unsigned char)(n); RDR_STACK_AT(st_pmf, sp) = (p); sp++; }
     int sp = 0;
     int selected = -1;
     double edge_w = 0, wsum = 0;
@@ -410,12 +413,12 @@ RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, co
         if (sample < prob) { n_cs++; sample /= prob; }
         else { n_ncs++; sample = (sample - prob) / (1 - prob); }
     }
-    if (n_cs > 0) { RDR_STACK_AT(stack, sp) = HItem{0, n_cs, prob_cs}; sp++; }
-    if (n_ncs > 0) { RDR_STACK_AT(stack, sp) = HItem{kEdgeTreeBit, n_ncs, prob_ncs}; sp++; }
+    if (n_cs > 0) RDR_H_PUSH(0, n_cs, prob_cs)
+    if (n_ncs > 0) RDR_H_PUSH(kEdgeTreeBit, n_ncs, prob_ncs)
     while (sp > 0) {
         --sp;
-        HItem it = RDR_STACK_AT(stack, sp);
-        const EdgeNode &nd = edge_node(es, it.ref);
+        HItem it = HItem{RDR_STACK_AT(st_ref, sp), (int)RDR_STACK_AT(st_num, sp), RDR_STACK_AT(st_pmf, sp)};
+        const EdgeNodeC &nd = edge_node(es, it.ref);
         if (nd.edge_id != -1) {
             double w = it.num * leaf_importance_h(sc, es, it.ref, c) / it.pmf;
             if (w > 0) {
@@ -434,7 +437,7 @@ RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, co
             int tree = it.ref & kEdgeTreeBit;
             int c0 = nd.child0 | tree, c1 = nd.child1 | tree;
             double i0, i1;
-            if (box_contains(nd.p_min, nd.p_max, c.pos)) { i0 = i1 = 1; }
+            if (box_contains(node_pmin(nd), node_pmax(nd), c.pos)) { i0 = i1 = 1; }
             else { i0 = node_importance(es, c0, c); i1 = node_importance(es, c1, c); }
             if (i0 > 0 || i1 > 0) {
                 double p0 = i0 / (i0 + i1), p1 = 1 - p0;
@@ -445,8 +448,8 @@ RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, co
                     if (sample < prob) { s0++; sample /= prob; }
                     else { s1++; sample = (sample - prob) / (1 - prob); }
                 }
-                if (s0 > 0 && sp < kHStack) { RDR_STACK_AT(stack, sp) = HItem{c0, s0, it.pmf * p0}; sp++; }
-                if (s1 > 0 && sp < kHStack) { RDR_STACK_AT(stack, sp) = HItem{c1, s1, it.pmf * p1}; sp++; }
+                if (s0 > 0 && sp < kHStack) RDR_H_PUSH(c0, s0, it.pmf * p0)
+                if (s1 > 0 && sp < kHStack) RDR_H_PUSH(c1, s1, it.pmf * p1)
             }
         }
     }
@@ -454,12 +457,14 @@ RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, co
     double pmf_h = edge_w * kHSamples / wsum;
     weight = 1 / pmf_h;
     return selected;
+#undef RDR_H_PUSH
 }
 
 // NEE-billboard pick: gather every edge whose billboard the NEE ray crosses, keep one.
+template <int NS>
 RDR_DEV_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c, const Ray &nee, bool nee_valid,
                              const Surf &nee_pt, int nee_shape, double resample, double &weight, V3 &edge_pt, V3 &mwt) {
-    RDR_STACK_DECL(int, stack, kNStack);
+    RDR_STACK_DECL(int, stack, NS);
     int sp = 0;
     int selected = -1;
     double edge_w = 0, wsum = 0;
@@ -468,7 +473,7 @@ RDR_DEV_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCt
     while (sp > 0) {
         --sp;
         int ref = RDR_STACK_AT(stack, sp);
-        const EdgeNode &nd = edge_node(es, ref);
+        const EdgeNodeC &nd = edge_node(es, ref);
         if (nd.edge_id != -1) {
             double w = leaf_importance_l(sc, es, ref, c, nee, nee_valid);
             if (w > 0) {
@@ -482,11 +487,11 @@ RDR_DEV_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCt
             int tree = ref & kEdgeTreeBit;
             int ch[2] = {nd.child0 | tree, nd.child1 | tree};
             for (int k = 0; k < 2; ++k) {
-                const EdgeNode &cn = edge_node(es, ch[k]);
+                const EdgeNodeC &cn = edge_node(es, ch[k]);
                 bool ok = may_hold_silhouette(es, ch[k], c.pos);
                 if (ok && nee_valid) ok = may_hold_silhouette(es, ch[k], nee_pt.position);
-                if (ok) ok = ray_box_expand(cn.p_min, cn.p_max, nee, es.edge_bounds_expand);
-                if (ok && sp < kNStack) { RDR_STACK_AT(stack, sp) = ch[k]; sp++; }
+                if (ok) ok = ray_box_expand(node_pmin(cn), node_pmax(cn), nee, es.edge_bounds_expand);
+                if (ok && sp < NS) { RDR_STACK_AT(stack, sp) = ch[k]; sp++; }
             }
         }
     }
@@ -654,7 +659,7 @@ struct SecEdgePickH {
         picks[idx] = SecPick{eid, ew, v3(0), v3(0)};
     }
 };
-struct SecEdgePickN {
+template <int NS> struct SecEdgePickN {
     SecEdgeArgs a; const int *slots; SecPick *picks;
     RDR_FN void make_lean() { lean_scene(a.sc); }
     RDR_FN void operator()(int i) const {
@@ -662,7 +667,7 @@ struct SecEdgePickN {
         SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
         double ew = 0;
         V3 sample_p = v3(0), mwt = v3(0);
-        int eid = pick_edge_nee(a.sc, a.es, s.lc, s.nee, s.nee_valid, s.nee_pt, s.nee_shape, s.resample_sel, ew, sample_p, mwt);
+        int eid = pick_edge_nee<NS>(a.sc, a.es, s.lc, s.nee, s.nee_valid, s.nee_pt, s.nee_shape, s.resample_sel, ew, sample_p, mwt);
         picks[idx] = SecPick{eid, ew, sample_p, mwt};
     }
 };
