@@ -27,6 +27,7 @@ struct BvhD {              // device/host view
     const float *tris;     // 9 floats per slot
     const int *ids;        // 2 ints per slot
     int num_nodes, num_tris;
+    int stack_need;        // entries a traversal can need (hierarchy depth + 2); picks the kernel's LDS stack size
 };
 
 struct Counters { unsigned long long nodes, tris; };

@@ -46,11 +46,14 @@ CompactScratch &compact_scratch(int nblocks) {
     return s;
 }
 
-template <bool ANY, bool COUNT>
+// STACK: entries of the per-lane LDS stack column.  The kernel waits on node fetches about two thirds of the
+// time (profiles/r1_notes.md), so waves per SIMD matter: 40 entries allow 4, 24 allow 6, 16 allow 8.  The host
+// picks the smallest instantiation that covers the scene's hierarchy depth.
+template <bool ANY, bool COUNT, int STACK>
 __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays,
                                                     rt::HitRec *__restrict__ hits, int n,
                                                     unsigned long long *counters) {
-    __shared__ int stack_tile[rt::kTraverseStack * 256];     // 40 KiB: per-lane stack columns
+    __shared__ int stack_tile[STACK * 256];                   // per-lane stack columns
     int *stack = stack_tile + threadIdx.x;
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -117,14 +120,25 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n,
         p.a = get_event(); p.b = get_event(); p.any = any;
         check(hipEventRecord(p.a, s), "hipEventRecord");
     }
+#define RDR_TRACE_LAUNCH(ANY_, COUNT_, STACK_, ctr) \
+    hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr)
+#define RDR_TRACE_BY_STACK(ANY_, COUNT_, ctr)                                  \
+    do {                                                                       \
+        if (bvh.stack_need <= 16) RDR_TRACE_LAUNCH(ANY_, COUNT_, 16, ctr);      \
+        else if (bvh.stack_need <= 24) RDR_TRACE_LAUNCH(ANY_, COUNT_, 24, ctr); \
+        else if (bvh.stack_need <= 32) RDR_TRACE_LAUNCH(ANY_, COUNT_, 32, ctr); \
+        else RDR_TRACE_LAUNCH(ANY_, COUNT_, rt::kTraverseStack, ctr);          \
+    } while (0)
     if (st.counting) {
         if (!g_counters) { g_counters = (unsigned long long *)dmalloc(32); zero(g_counters, 32); }
-        if (any) hipLaunchKernelGGL((trace_kernel<true, true>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, g_counters + 2);
-        else hipLaunchKernelGGL((trace_kernel<false, true>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, g_counters);
+        if (any) RDR_TRACE_BY_STACK(true, true, g_counters + 2);
+        else RDR_TRACE_BY_STACK(false, true, g_counters);
     } else {
-        if (any) hipLaunchKernelGGL((trace_kernel<true, false>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, (unsigned long long *)nullptr);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, (unsigned long long *)nullptr);
+        if (any) RDR_TRACE_BY_STACK(true, false, (unsigned long long *)nullptr);
+        else RDR_TRACE_BY_STACK(false, false, (unsigned long long *)nullptr);
     }
+#undef RDR_TRACE_BY_STACK
+#undef RDR_TRACE_LAUNCH
     check(hipGetLastError(), "trace launch");
     if (st.timing) {
         check(hipEventRecord(p.b, s), "hipEventRecord");

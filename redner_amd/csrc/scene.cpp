@@ -225,6 +225,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         s.bvh_host = rt::build_bvh(meshes);
         s.bvh.num_nodes = (int)s.bvh_host.nodes.size();
         s.bvh.num_tris = (int)s.bvh_host.ids.size() / 2;
+        s.bvh.stack_need = s.bvh_host.depth + 2;
         s.bvh.nodes = to_device(s, s.bvh_host.nodes.data(), s.bvh_host.nodes.size());
         s.bvh.tris = to_device(s, s.bvh_host.tris.data(), s.bvh_host.tris.size());
         s.bvh.ids = to_device(s, s.bvh_host.ids.data(), s.bvh_host.ids.size());
