@@ -550,24 +550,38 @@ EdgeData *build_edge_data(Scene &scene) {
     d.edges = (const EdgeD *)up(edges.data(), sizeof(EdgeD) * edges.size());
     d.primary_pmf = ed->primary_pmf.empty() ? nullptr : (const double *)up(ed->primary_pmf.data(), sizeof(double) * ne);
     d.primary_cdf = ed->primary_cdf.empty() ? nullptr : (const double *)up(ed->primary_cdf.data(), sizeof(double) * ne);
-    auto compact = [&](const std::vector<EdgeNode> &nodes) -> const EdgeNodeC * {
+    // [internal | leaves]: n - 1 interior nodes first, then the n leaves (see TreeBuilder)
+    auto fatten = [&](const std::vector<EdgeNode> &nodes, int num_leaves, int tree_bit, int &root) -> const EdgeNodeP * {
+        root = kNoEdgeTree;
         if (nodes.empty()) return nullptr;
-        std::vector<EdgeNodeC> c(nodes.size());
-        for (size_t i = 0; i < nodes.size(); ++i) {
+        const int num_inner = (int)nodes.size() - num_leaves;
+        auto to_f32 = [](double x) {
+            float f = (float)x;
+            if ((double)f != x) throw std::runtime_error("edge hierarchy: spatial bounds are not fp32 values");   // vertices are fp32
+            return f;
+        };
+        auto ref_of = [&](int idx) { return idx >= num_inner ? ~nodes[idx].edge_id : idx; };
+        root = nodes[0].edge_id != -1 ? ~nodes[0].edge_id : (0 | tree_bit);
+        if (num_inner <= 0) return nullptr;               // a single edge: the root reference is the leaf
+        std::vector<EdgeNodeP> out(num_inner);
+        for (int i = 0; i < num_inner; ++i) {
             const EdgeNode &n = nodes[i];
+            EdgeNodeP &o = out[i];
             const double lo[3] = {n.p_min.x, n.p_min.y, n.p_min.z}, hi[3] = {n.p_max.x, n.p_max.y, n.p_max.z};
-            for (int k = 0; k < 3; ++k) {
-                c[i].p_min[k] = (float)lo[k]; c[i].p_max[k] = (float)hi[k];
-                if ((double)c[i].p_min[k] != lo[k] || (double)c[i].p_max[k] != hi[k])
-                    throw std::runtime_error("edge hierarchy: spatial bounds are not fp32 values");   // cannot happen: vertices are fp32
+            for (int k = 0; k < 3; ++k) { o.p_min[k] = to_f32(lo[k]); o.p_max[k] = to_f32(hi[k]); }
+            const int ch[2] = {n.child0, n.child1};
+            for (int c = 0; c < 2; ++c) {
+                const EdgeNode &cn = nodes[ch[c]];
+                const double clo[3] = {cn.p_min.x, cn.p_min.y, cn.p_min.z}, chi[3] = {cn.p_max.x, cn.p_max.y, cn.p_max.z};
+                for (int k = 0; k < 3; ++k) { o.c_pmin[c][k] = to_f32(clo[k]); o.c_pmax[c][k] = to_f32(chi[k]); }
+                o.c_dx_min[c] = cn.d_min.x; o.c_dx_max[c] = cn.d_max.x; o.c_wlen[c] = cn.wlen;
+                o.c_ref[c] = ref_of(ch[c]);
             }
-            c[i].dx_min = n.d_min.x; c[i].dx_max = n.d_max.x; c[i].wlen = n.wlen;
-            c[i].child0 = n.child0; c[i].child1 = n.child1; c[i].edge_id = n.edge_id; c[i].pad = 0;
         }
-        return (const EdgeNodeC *)up(c.data(), sizeof(EdgeNodeC) * c.size());
+        return (const EdgeNodeP *)up(out.data(), sizeof(EdgeNodeP) * out.size());
     };
-    d.cs_nodes = compact(ed->cs_nodes);
-    d.ncs_nodes = compact(ed->ncs_nodes);
+    d.cs_nodes = fatten(ed->cs_nodes, ed->cs_leaves, 0, d.cs_root);
+    d.ncs_nodes = fatten(ed->ncs_nodes, ed->ncs_leaves, kEdgeTreeBit, d.ncs_root);
     d.edge_bounds_expand = ed->edge_bounds_expand;
     d.max_stack = ed->max_stack;
     d.cam_org = cam_org;

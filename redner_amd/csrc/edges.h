@@ -28,20 +28,24 @@ struct EdgeNode {
     int parent, child0, child1, edge_id;   // edge_id >= 0 marks a leaf
 };
 
-// What the samplers read, 64 bytes per node (one or two per cache line instead of a 128-byte EdgeNode):
+// What the samplers read: one 128-byte line per INTERIOR node holding everything a traversal step needs about
+// both children -- their spatial bounds, Hough x-interval, weight and reference -- plus the node's own bounds
+// (for the "shading point inside this node" test).  Leaves are not nodes here: a leaf child is a negative
+// reference, ~edge_id, and its bounds/weight sit in its parent like any child's.  One dependent fetch per level
+// instead of three (self, child 0, child 1 with the 128-byte EdgeNode), and no fetch at all for leaves.
 //  * spatial bounds are unions of fp32 vertex coordinates, hence exact in fp32;
 //  * of the Hough-space bounds only the x interval can ever decide the reference's sphere/box test: its loop
 //    returns at the first axis whose partial distance is within the radius, and partial sums only grow, so the
 //    verdict is the x term's (src/aabb.h:158-170).  [quirk]
-struct EdgeNodeC {
-    float p_min[3], p_max[3];
-    double dx_min, dx_max;
-    double wlen;
-    int child0, child1, edge_id, pad;
+struct EdgeNodeP {
+    float p_min[3], p_max[3];            // own bounds
+    float c_pmin[2][3], c_pmax[2][3];    // children
+    double c_dx_min[2], c_dx_max[2];
+    double c_wlen[2];
+    int c_ref[2];                        // >= 0: interior node index (tree bit NOT included); < 0: ~edge_id
 };
-static_assert(sizeof(EdgeNodeC) == 64, "EdgeNodeC must stay one half cache line");
-RDR_FN V3 node_pmin(const EdgeNodeC &n) { return V3{(double)n.p_min[0], (double)n.p_min[1], (double)n.p_min[2]}; }
-RDR_FN V3 node_pmax(const EdgeNodeC &n) { return V3{(double)n.p_max[0], (double)n.p_max[1], (double)n.p_max[2]}; }
+static_assert(sizeof(EdgeNodeP) == 128, "EdgeNodeP must stay one cache line");
+RDR_FN V3 v3_of(const float *p) { return V3{(double)p[0], (double)p[1], (double)p[2]}; }
 
 constexpr int kEdgeTreeBit = 1 << 30;
 
@@ -49,17 +53,19 @@ struct EdgeSceneD {
     const EdgeD *edges;
     int num_edges;
     const double *primary_pmf, *primary_cdf;
-    const EdgeNodeC *cs_nodes, *ncs_nodes;   // null when the tree is empty
+    const EdgeNodeP *cs_nodes, *ncs_nodes;   // interior nodes; may be null for a one-edge tree
+    int cs_root, ncs_root;                   // root references; kNoEdgeTree when the tree is empty
     double edge_bounds_expand;
     int max_stack;           // entries the NEE-mode traversal can need: deepest leaf level + 1
     V3 cam_org;
     const float *ltc;                         // tabM, 128 x 128 x 9
 };
 
-RDR_FN const EdgeNodeC &edge_node(const EdgeSceneD &es, int ref) {
+constexpr int kNoEdgeTree = 0x7fffffff;
+// Interior references carry the tree in bit 30 (set = the 6-D tree of non-camera-silhouette edges).
+RDR_FN const EdgeNodeP &edge_node(const EdgeSceneD &es, int ref) {
     return (ref & kEdgeTreeBit) ? es.ncs_nodes[ref & (kEdgeTreeBit - 1)] : es.cs_nodes[ref];
 }
-RDR_FN bool edge_ref_is_3d(int ref) { return (ref & kEdgeTreeBit) == 0; }
 
 // ---- fp32 vertex helpers (comparisons and lengths are done in float, like the reference) --------
 struct F3 { float x, y, z; };

@@ -292,20 +292,21 @@ RDR_FN bool sphere_box_x(double cx, double radius, double lo_x, double hi_x) {
     else if (cx > hi_x) dmin_ += sq(cx - hi_x);
     return dmin_ <= r2;
 }
-RDR_FN bool may_hold_silhouette(const EdgeSceneD &es, int ref, V3 p) {
-    if (edge_ref_is_3d(ref)) return true;
-    const EdgeNodeC &nd = edge_node(es, ref);
-    return sphere_box_x((0.5f * (p - es.cam_org)).x, 0.5f * len(es.cam_org - p), nd.dx_min, nd.dx_max);
+// Can the subtree with Hough x-interval [dx_min, dx_max] hold an edge that is a silhouette seen from p?
+// (3-D tree: always; src/edge.cpp contains_silhouette)
+RDR_FN bool may_hold_silhouette(const EdgeSceneD &es, bool tree3d, double dx_min, double dx_max, V3 p) {
+    if (tree3d) return true;
+    return sphere_box_x((0.5f * (p - es.cam_org)).x, 0.5f * len(es.cam_org - p), dx_min, dx_max);
 }
-RDR_FN double node_importance(const EdgeSceneD &es, int ref, const LtcCtx &c) {
-    const EdgeNodeC &nd = edge_node(es, ref);
-    if (!edge_ref_is_3d(ref)) {
-        if (!sphere_box_x((0.5f * (c.pos - es.cam_org)).x, 0.5f * len(es.cam_org - c.pos), nd.dx_min, nd.dx_max)) return 0;
+// Importance of child k of `nd` (src/edge.cpp:885-928).
+RDR_FN double node_importance(const EdgeSceneD &es, const EdgeNodeP &nd, int k, bool tree3d, const LtcCtx &c) {
+    if (!tree3d) {
+        if (!sphere_box_x((0.5f * (c.pos - es.cam_org)).x, 0.5f * len(es.cam_org - c.pos), nd.c_dx_min[k], nd.c_dx_max[k])) return 0;
     }
-    V3 lo = node_pmin(nd), hi = node_pmax(nd);
+    V3 lo = v3_of(nd.c_pmin[k]), hi = v3_of(nd.c_pmax[k]);
     double brdf = ltc_bound(lo, hi, c);
     V3 ctr = 0.5f * (lo + hi);
-    return brdf * nd.wlen / dmax(len(c.pos - ctr), 1e-3);
+    return brdf * nd.c_wlen[k] / dmax(len(c.pos - ctr), 1e-3);
 }
 
 // LTC line integral of an edge seen from the shading point (clipped to the tangent plane).
@@ -339,16 +340,16 @@ RDR_FN double edge_line_importance(const SceneD &sc, const EdgeD &e, const LtcCt
     }
     return 0;
 }
-RDR_FN double leaf_importance_h(const SceneD &sc, const EdgeSceneD &es, int ref, const LtcCtx &c) {
-    const EdgeD &e = es.edges[edge_node(es, ref).edge_id];
+RDR_FN double leaf_importance_h(const SceneD &sc, const EdgeSceneD &es, int eid, const LtcCtx &c) {
+    const EdgeD &e = es.edges[eid];
     if (!edge_is_silhouette(sc.shapes, c.pos, e)) return 0;
     return edge_line_importance(sc, e, c);
 }
 // Leaf weight for the NEE-billboard mode: the edge must be a silhouette from both ends of the NEE
 // segment and the NEE ray must pass within `edge_bounds_expand` of it.
-RDR_FN double leaf_importance_l(const SceneD &sc, const EdgeSceneD &es, int ref, const LtcCtx &c,
+RDR_FN double leaf_importance_l(const SceneD &sc, const EdgeSceneD &es, int eid, const LtcCtx &c,
                                 const Ray &nee, bool nee_valid) {
-    const EdgeD &e = es.edges[edge_node(es, ref).edge_id];
+    const EdgeD &e = es.edges[eid];
     if (!edge_is_silhouette(sc.shapes, c.pos, e)) return 0;
     if (nee_valid) {
         if (!edge_is_silhouette(sc.shapes, nee.org + nee.tmax * nee.dir, e)) return 0;
@@ -403,7 +404,7 @@ RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, co
     int sp = 0;
     int selected = -1;
     double edge_w = 0, wsum = 0;
-    double imp_cs = es.cs_nodes ? 1.0 : 0.0, imp_ncs = es.ncs_nodes ? 1.0 : 0.0;
+    double imp_cs = es.cs_root != kNoEdgeTree ? 1.0 : 0.0, imp_ncs = es.ncs_root != kNoEdgeTree ? 1.0 : 0.0;
     if (imp_cs <= 0 && imp_ncs <= 0) return -1;
     double prob_cs = imp_cs / (imp_cs + imp_ncs), prob_ncs = 1 - prob_cs;
     double exp_cs = kHSamples * prob_cs, exp_ncs = kHSamples * prob_ncs;
@@ -413,20 +414,20 @@ RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, co
         if (sample < prob) { n_cs++; sample /= prob; }
         else { n_ncs++; sample = (sample - prob) / (1 - prob); }
     }
-    if (n_cs > 0) RDR_H_PUSH(0, n_cs, prob_cs)
-    if (n_ncs > 0) RDR_H_PUSH(kEdgeTreeBit, n_ncs, prob_ncs)
+    if (n_cs > 0) RDR_H_PUSH(es.cs_root, n_cs, prob_cs)
+    if (n_ncs > 0) RDR_H_PUSH(es.ncs_root, n_ncs, prob_ncs)
     while (sp > 0) {
         --sp;
         HItem it = HItem{RDR_STACK_AT(st_ref, sp), (int)RDR_STACK_AT(st_num, sp), RDR_STACK_AT(st_pmf, sp)};
-        const EdgeNodeC &nd = edge_node(es, it.ref);
-        if (nd.edge_id != -1) {
-            double w = it.num * leaf_importance_h(sc, es, it.ref, c) / it.pmf;
+        if (it.ref < 0) {
+            const int leaf_edge = ~it.ref;
+            double w = it.num * leaf_importance_h(sc, es, leaf_edge, c) / it.pmf;
             if (w > 0) {
                 double prev = wsum;
                 wsum += w;
                 double nw = w / wsum;
                 if (resample <= nw || prev == 0) {
-                    selected = nd.edge_id;
+                    selected = leaf_edge;
                     edge_w = w * it.pmf;
                     resample /= nw;
                 } else {
@@ -434,11 +435,14 @@ RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, co
                 }
             }
         } else {
-            int tree = it.ref & kEdgeTreeBit;
-            int c0 = nd.child0 | tree, c1 = nd.child1 | tree;
+            const EdgeNodeP &nd = edge_node(es, it.ref);
+            const int tree = it.ref & kEdgeTreeBit;
+            const bool tree3d = tree == 0;
+            int c0 = nd.c_ref[0] < 0 ? nd.c_ref[0] : (nd.c_ref[0] | tree);
+            int c1 = nd.c_ref[1] < 0 ? nd.c_ref[1] : (nd.c_ref[1] | tree);
             double i0, i1;
-            if (box_contains(node_pmin(nd), node_pmax(nd), c.pos)) { i0 = i1 = 1; }
-            else { i0 = node_importance(es, c0, c); i1 = node_importance(es, c1, c); }
+            if (box_contains(v3_of(nd.p_min), v3_of(nd.p_max), c.pos)) { i0 = i1 = 1; }
+            else { i0 = node_importance(es, nd, 0, tree3d, c); i1 = node_importance(es, nd, 1, tree3d, c); }
             if (i0 > 0 || i1 > 0) {
                 double p0 = i0 / (i0 + i1), p1 = 1 - p0;
                 double e0 = it.num * p0, e1 = it.num * p1;
@@ -468,30 +472,30 @@ RDR_DEV_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCt
     int sp = 0;
     int selected = -1;
     double edge_w = 0, wsum = 0;
-    if (es.cs_nodes) { RDR_STACK_AT(stack, sp) = 0; sp++; }
-    if (es.ncs_nodes) { RDR_STACK_AT(stack, sp) = kEdgeTreeBit; sp++; }
+    if (es.cs_root != kNoEdgeTree) { RDR_STACK_AT(stack, sp) = es.cs_root; sp++; }
+    if (es.ncs_root != kNoEdgeTree) { RDR_STACK_AT(stack, sp) = es.ncs_root; sp++; }
     while (sp > 0) {
         --sp;
         int ref = RDR_STACK_AT(stack, sp);
-        const EdgeNodeC &nd = edge_node(es, ref);
-        if (nd.edge_id != -1) {
-            double w = leaf_importance_l(sc, es, ref, c, nee, nee_valid);
+        if (ref < 0) {
+            const int leaf_edge = ~ref;
+            double w = leaf_importance_l(sc, es, leaf_edge, c, nee, nee_valid);
             if (w > 0) {
                 double prev = wsum;
                 wsum += w;
                 double nw = w / wsum;
-                if (resample <= nw || prev == 0) { selected = nd.edge_id; edge_w = w; resample /= nw; }
+                if (resample <= nw || prev == 0) { selected = leaf_edge; edge_w = w; resample /= nw; }
                 else resample = (resample - nw) / (1 - nw);
             }
         } else {
-            int tree = ref & kEdgeTreeBit;
-            int ch[2] = {nd.child0 | tree, nd.child1 | tree};
+            const EdgeNodeP &nd = edge_node(es, ref);
+            const int tree = ref & kEdgeTreeBit;
+            const bool tree3d = tree == 0;
             for (int k = 0; k < 2; ++k) {
-                const EdgeNodeC &cn = edge_node(es, ch[k]);
-                bool ok = may_hold_silhouette(es, ch[k], c.pos);
-                if (ok && nee_valid) ok = may_hold_silhouette(es, ch[k], nee_pt.position);
-                if (ok) ok = ray_box_expand(node_pmin(cn), node_pmax(cn), nee, es.edge_bounds_expand);
-                if (ok && sp < NS) { RDR_STACK_AT(stack, sp) = ch[k]; sp++; }
+                bool ok = may_hold_silhouette(es, tree3d, nd.c_dx_min[k], nd.c_dx_max[k], c.pos);
+                if (ok && nee_valid) ok = may_hold_silhouette(es, tree3d, nd.c_dx_min[k], nd.c_dx_max[k], nee_pt.position);
+                if (ok) ok = ray_box_expand(v3_of(nd.c_pmin[k]), v3_of(nd.c_pmax[k]), nee, es.edge_bounds_expand);
+                if (ok && sp < NS) { RDR_STACK_AT(stack, sp) = nd.c_ref[k] < 0 ? nd.c_ref[k] : (nd.c_ref[k] | tree); sp++; }
             }
         }
     }
