@@ -548,6 +548,22 @@ EdgeData *build_edge_data(Scene &scene) {
     EdgeSceneD &d = ed->d;
     d.num_edges = ne;
     d.edges = (const EdgeD *)up(edges.data(), sizeof(EdgeD) * edges.size());
+    {
+        // per-edge geometry records, from the host copies of the shapes
+        std::vector<EdgeGeom> geom(edges.size());
+        std::vector<ShapeD> hs(scene.shapes.begin(), scene.shapes.end());
+        for (size_t i = 0; i < hs.size(); ++i) { hs[i].vertices = scene.h_vertices[i].data(); hs[i].indices = scene.h_indices[i].data(); }
+        for (size_t i = 0; i < edges.size(); ++i) {
+            const EdgeD &e = edges[i];
+            EdgeGeom &g = geom[i];
+            F3 a = edge_v0f(hs.data(), e), b = edge_v1f(hs.data(), e);
+            F3 o0 = e.f0 != -1 ? edge_opp0f(hs.data(), e) : a, o1 = e.f1 != -1 ? edge_opp1f(hs.data(), e) : b;
+            g.v0[0] = a.x; g.v0[1] = a.y; g.v0[2] = a.z; g.v1[0] = b.x; g.v1[1] = b.y; g.v1[2] = b.z;
+            g.o0[0] = o0.x; g.o0[1] = o0.y; g.o0[2] = o0.z; g.o1[0] = o1.x; g.o1[1] = o1.y; g.o1[2] = o1.z;
+            g.f0 = e.f0; g.f1 = e.f1; g.has_normals = scene.shapes[e.shape_id].normals != nullptr; g.pad = 0;
+        }
+        d.geom = (const EdgeGeom *)up(geom.data(), sizeof(EdgeGeom) * geom.size());
+    }
     d.primary_pmf = ed->primary_pmf.empty() ? nullptr : (const double *)up(ed->primary_pmf.data(), sizeof(double) * ne);
     d.primary_cdf = ed->primary_cdf.empty() ? nullptr : (const double *)up(ed->primary_cdf.data(), sizeof(double) * ne);
     // [internal | leaves]: n - 1 interior nodes first, then the n leaves (see TreeBuilder)

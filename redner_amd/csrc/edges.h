@@ -49,8 +49,10 @@ RDR_FN V3 v3_of(const float *p) { return V3{(double)p[0], (double)p[1], (double)
 
 constexpr int kEdgeTreeBit = 1 << 30;
 
+struct EdgeGeom;
 struct EdgeSceneD {
     const EdgeD *edges;
+    const EdgeGeom *geom;                    // one per edge, same order
     int num_edges;
     const double *primary_pmf, *primary_cdf;
     const EdgeNodeP *cs_nodes, *ncs_nodes;   // interior nodes; may be null for a one-edge tree
@@ -138,6 +140,35 @@ RDR_FN bool edge_is_silhouette(const ShapeD *shapes, V3 p, const EdgeD &e) {
     if (l0 < 1e-20 || l1 < 1e-20) return false;
     n0 = n0 / sqrt(l0); n1 = n1 / sqrt(l1);
     if (!shapes[e.shape_id].normals) return !(dot(n0, n1) >= 1 - 1e-6f);
+    bool ff0 = dot(p - o0, n0) > 0.f, ff1 = dot(p - o1, n1) > 0.f;
+    return (ff0 && !ff1) || (!ff0 && ff1);
+}
+
+// Everything the samplers need about one edge in one 64-byte record (built per Scene from the same fp32 vertex
+// data): the two end points and the third corner of each adjacent face.  Replaces the chain
+// EdgeD -> ShapeD -> index buffer -> vertex buffer (four dependent fetches) in the edge-pick leaf tests.
+struct EdgeGeom {
+    float v0[3], v1[3], o0[3], o1[3];
+    int f0, f1;              // -1: no such face
+    int has_normals;         // the shape has shading normals (silhouette = front/back-facing flip)
+    int pad;
+};
+static_assert(sizeof(EdgeGeom) == 64, "EdgeGeom must stay 64 bytes");
+
+// edge_is_silhouette on an EdgeGeom (same arithmetic, src/edge.h:155-204)
+RDR_FN bool edge_is_silhouette_g(const EdgeGeom &g, V3 p) {
+    V3 a = V3{(double)g.v0[0], (double)g.v0[1], (double)g.v0[2]}, b = V3{(double)g.v1[0], (double)g.v1[1], (double)g.v1[2]};
+    V3 o0 = V3{(double)g.o0[0], (double)g.o0[1], (double)g.o0[2]}, o1 = V3{(double)g.o1[0], (double)g.o1[1], (double)g.o1[2]};
+    if (g.f0 == -1 || g.f1 == -1) {
+        if (g.f0 != -1) { if (len_sq(cross(a - o0, b - o0)) < 1e-20) return false; }
+        if (g.f1 != -1) { if (len_sq(cross(b - o1, a - o1)) < 1e-20) return false; }
+        return true;
+    }
+    V3 n0 = cross(a - o0, b - o0), n1 = cross(b - o1, a - o1);
+    double l0 = len_sq(n0), l1 = len_sq(n1);
+    if (l0 < 1e-20 || l1 < 1e-20) return false;
+    n0 = n0 / sqrt(l0); n1 = n1 / sqrt(l1);
+    if (!g.has_normals) return !(dot(n0, n1) >= 1 - 1e-6f);
     bool ff0 = dot(p - o0, n0) > 0.f, ff1 = dot(p - o1, n1) > 0.f;
     return (ff0 && !ff1) || (!ff0 && ff1);
 }

@@ -329,8 +329,7 @@ RDR_FN LineSetup line_setup(V3 v0o, V3 v1o) {
     s.ok = true;
     return s;
 }
-RDR_FN double edge_line_importance(const SceneD &sc, const EdgeD &e, const LtcCtx &c) {
-    V3 a = edge_v0(sc.shapes, e), b = edge_v1(sc.shapes, e);
+RDR_FN double edge_line_importance(V3 a, V3 b, const LtcCtx &c) {
     if (len_sq(b - a) > 1e-10f) {
         V3 ao = m3_apply(c.m_inv, a - c.pos), bo = m3_apply(c.m_inv, b - c.pos);
         if (ao.z > 0.f || bo.z > 0.f) {
@@ -341,22 +340,22 @@ RDR_FN double edge_line_importance(const SceneD &sc, const EdgeD &e, const LtcCt
     return 0;
 }
 RDR_FN double leaf_importance_h(const SceneD &sc, const EdgeSceneD &es, int eid, const LtcCtx &c) {
-    const EdgeD &e = es.edges[eid];
-    if (!edge_is_silhouette(sc.shapes, c.pos, e)) return 0;
-    return edge_line_importance(sc, e, c);
+    const EdgeGeom &g = es.geom[eid];
+    if (!edge_is_silhouette_g(g, c.pos)) return 0;
+    return edge_line_importance(v3_of(g.v0), v3_of(g.v1), c);
 }
 // Leaf weight for the NEE-billboard mode: the edge must be a silhouette from both ends of the NEE
 // segment and the NEE ray must pass within `edge_bounds_expand` of it.
 RDR_FN double leaf_importance_l(const SceneD &sc, const EdgeSceneD &es, int eid, const LtcCtx &c,
                                 const Ray &nee, bool nee_valid) {
-    const EdgeD &e = es.edges[eid];
-    if (!edge_is_silhouette(sc.shapes, c.pos, e)) return 0;
+    const EdgeGeom &g = es.geom[eid];
+    if (!edge_is_silhouette_g(g, c.pos)) return 0;
     if (nee_valid) {
-        if (!edge_is_silhouette(sc.shapes, nee.org + nee.tmax * nee.dir, e)) return 0;
+        if (!edge_is_silhouette_g(g, nee.org + nee.tmax * nee.dir)) return 0;
     } else {
-        if (!edge_is_silhouette(sc.shapes, nee.dir, e)) return 0;
+        if (!edge_is_silhouette_g(g, nee.dir)) return 0;
     }
-    V3 a = edge_v0(sc.shapes, e), b = edge_v1(sc.shapes, e);
+    V3 a = v3_of(g.v0), b = v3_of(g.v1);
     V3 pn = nee.dir;
     double t = -(dot(nee.org, pn) - dot(a, pn)) / dot(nee.dir, pn);
     V3 ip = nee.org + nee.dir * t;
@@ -364,7 +363,7 @@ RDR_FN double leaf_importance_l(const SceneD &sc, const EdgeSceneD &es, int eid,
     V3 ab = normalize(b - a);
     V3 ept = ip + ap - (dot(ap, ab)) * ab;
     if (len_sq(ip - ept) > sq(es.edge_bounds_expand)) return 0;
-    return edge_line_importance(sc, e, c);
+    return edge_line_importance(a, b, c);
 }
 
 // Slab test of the reference's edge-tree traversal (src/aabb.h:176-200), boxes grown by `expand`.
