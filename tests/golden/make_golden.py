@@ -102,6 +102,10 @@ CASES = {
     'bunny_box_panorama_nosec_32x32x4': ('bunny_box_panorama', 32, 4, 2, None, {'use_secondary_edge_sampling': False}),
     # environment light only: NEE / BSDF-miss lookups, envmap adjoint, edge rays that reach the environment
     'envmap_sphere_48x48x4': ('envmap_sphere', 48, 4, 2),
+    # separate uv / normal index buffers, two lights (two-sided; not directly visible), non-square image, viewport,
+    # samples at pixel centres
+    'misc_features_40x56x4': ('misc_features', (40, 56), 4, 2),
+    'misc_features_viewport_40x56x4': ('misc_features_viewport', (40, 56), 4, 2, None, {'sample_pixel_center': True}),
     # radiance after a 3-wide channel: the reference adds path contributions at the channel INDEX (src/channels.cpp:27)
     'textured_sphere_radiance_last_48x48x2': ('textured_sphere', 48, 2, 2, ['position', 'radiance']),
     'textured_sphere_generic_48x48x4': ('textured_sphere', 48, 4, 1,
@@ -127,7 +131,7 @@ def render_case(backend, builder, res, spp, mb, channels=None, opts=None, device
     """Forward + backward of one case; returns {'image': ..., 'grad_<i>_<name>': ...}."""
     import scenes
     from redner_amd.render_pytorch import RenderFunction
-    sc = getattr(scenes, builder)(device, resolution=(res, res))
+    sc = getattr(scenes, builder)(device, resolution=res if isinstance(res, tuple) else (res, res))
     for l in sc.area_lights:
         l.intensity.requires_grad_(True)
     for m in sc.materials:

@@ -209,3 +209,43 @@ def envmap_sphere(device, resolution=(48, 48)):
               [-np.sin(ang), 0.0, np.cos(ang), 0.0], [0.0, 0.0, 0.0, 1.0]], 'cpu', grad=True)
     env = EnvironmentMap(Texture(levels), env_to_world=e2w)
     return Scene(base.camera, [sphere, ground], mats, [], envmap=env)
+
+
+def misc_features(device, resolution=(40, 56), viewport=None):
+    """Odds and ends of the interface in one scene: separate uv / normal index buffers, a two-sided light, a light
+    that is not directly visible, two area lights (light CDF), a non-square image and an optional viewport
+    (pyredner/shape.py uv_indices / normal_indices, pyredner/area_light.py, pyredner/camera.py viewport)."""
+    cam = Camera(position=_t([0.0, 0.5, -6.0], 'cpu'), look_at=_t([0.0, 0.0, 0.0], 'cpu'),
+                 up=_t([0.0, 1.0, 0.0], 'cpu'), fov=_t([50.0], 'cpu'), clip_near=1e-2, resolution=resolution,
+                 viewport=viewport)
+    # a pyramid whose uv / normal buffers are indexed separately from the positions
+    verts = _t([[0.0, 1.2, 0.0], [-1.0, -0.6, -1.0], [1.0, -0.6, -1.0], [1.0, -0.6, 1.0], [-1.0, -0.6, 1.0]], device, grad=True)
+    idx = _t([[0, 2, 1], [0, 3, 2], [0, 4, 3], [0, 1, 4]], device, torch.int32)
+    uvs = _t([[0.5, 1.0], [0.0, 0.0], [1.0, 0.0], [0.25, 0.5], [0.75, 0.5], [0.5, 0.2]], device, grad=True)
+    uv_idx = _t([[0, 2, 1], [3, 5, 4], [0, 1, 2], [4, 3, 5]], device, torch.int32)
+    nrm = np.array([[0.0, 1.0, 0.0], [-0.7, 0.2, -0.7], [0.7, 0.2, -0.7], [0.7, 0.2, 0.7], [-0.7, 0.2, 0.7], [0.0, 0.4, -0.9],
+                    [0.9, 0.4, 0.0]], np.float32)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    n_idx = _t([[0, 2, 1], [0, 6, 2], [0, 4, 3], [0, 1, 5]], device, torch.int32)
+    pyramid = Shape(verts, idx, 0, uvs=uvs, normals=_t(nrm, device, grad=True), uv_indices=uv_idx, normal_indices=n_idx)
+    floor = Shape(_t([[-4.0, -0.6, -4.0], [4.0, -0.6, -4.0], [-4.0, -0.6, 4.0], [4.0, -0.6, 4.0]], device, grad=True),
+                  _t([[0, 2, 1], [1, 2, 3]], device, torch.int32), 1)
+    light_a = Shape(_t([[-2.5, 2.5, -1.0], [-1.5, 2.5, -1.0], [-2.5, 2.5, 0.0], [-1.5, 2.5, 0.0]], device),
+                    _t([[0, 1, 2], [1, 3, 2]], device, torch.int32), 2)
+    light_b = Shape(_t([[1.5, 1.0, -3.0], [2.5, 1.0, -3.0], [1.5, 2.0, -3.2], [2.5, 2.0, -3.2]], device),
+                    _t([[0, 2, 1], [1, 2, 3]], device, torch.int32), 2)
+    tex = Texture(_mip_chain(torch.from_numpy(_procedural(16, 16, 3, 0.5))), uv_scale=_t([1.0, 1.0], device))
+    for l in tex.mipmap:
+        l.data = l.data.to(device)
+    mats = [Material(diffuse_reflectance=Texture([l.to(device).requires_grad_(True) for l in tex.mipmap]),
+                     specular_reflectance=_t([0.1, 0.1, 0.1], device, grad=True), roughness=_t([0.4], device, grad=True),
+                     two_sided=True),
+            Material(diffuse_reflectance=_t([0.45, 0.5, 0.4], device, grad=True)),
+            Material(diffuse_reflectance=_t([0.0, 0.0, 0.0], device))]
+    lights = [AreaLight(2, _t([30.0, 28.0, 25.0], 'cpu'), two_sided=True),
+              AreaLight(3, _t([10.0, 14.0, 20.0], 'cpu'), two_sided=False, directly_visible=False)]
+    return Scene(cam, [pyramid, floor, light_a, light_b], mats, lights)
+
+
+def misc_features_viewport(device, resolution=(40, 56)):
+    return misc_features(device, resolution, viewport=(6, 10, 30, 44))

@@ -1,0 +1,76 @@
+"""Degenerate inputs the reference's drivers guard against (src/pathtracer.cpp:292-300: a sample with no live
+paths, a scene without lights; src/scene.cpp:197: no light tables at all): nothing may crash, hang or
+produce non-finite values, and where the oracle is available the results must equal it."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_util
+import scenes
+from redner_amd.render_pytorch import Camera, Scene, RenderFunction
+
+
+def _run(backend, device, sc, spp=2, mb=2):
+    for s in sc.shapes:
+        s.vertices.requires_grad_(True)
+    args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=backend.SamplerType.sobol, device=device,
+                                          backend=backend)
+    img = RenderFunction.apply(3, *args)
+    img.sum().backward()
+    grads = [s.vertices.grad.cpu().numpy() if s.vertices.grad is not None else None for s in sc.shapes]
+    return img.detach().cpu().numpy(), grads
+
+
+def _variants(device):
+    def no_lights():
+        sc = scenes.two_triangles(device, resolution=(24, 24))
+        return Scene(sc.camera, sc.shapes[:2], sc.materials, [])
+    def all_miss():
+        sc = scenes.two_triangles(device, resolution=(24, 24))
+        c = sc.camera
+        sc.camera = Camera(position=c.position, look_at=torch.tensor([50.0, 0.0, -5.0]), up=c.up, fov=torch.tensor([20.0]),
+                           clip_near=c.clip_near, resolution=(24, 24))
+        return sc
+    def no_bounces():
+        return scenes.two_triangles(device, resolution=(24, 24))
+    return {'no_lights': (no_lights, 2), 'all_miss': (all_miss, 2), 'no_bounces': (no_bounces, 0)}
+
+
+@pytest.mark.parametrize('name', ['no_lights', 'all_miss', 'no_bounces'])
+def test_degenerate_hostsim(hostsim_backend, name):
+    build, mb = _variants(torch.device('cpu'))[name]
+    img, grads = _run(hostsim_backend, torch.device('cpu'), build(), mb=mb)
+    assert np.isfinite(img).all()
+    if name in ('no_lights', 'all_miss'):
+        assert not img.any()
+    if oracle_util.oracle_available():
+        ref_img, ref_grads = _run(oracle_util.load_oracle(), torch.device('cpu'), build(), mb=mb)
+        assert np.array_equal(img, ref_img)
+        for g, r in zip(grads, ref_grads):
+            if r is None:
+                continue
+            n = np.linalg.norm(r)
+            assert np.linalg.norm(g - r) <= 1e-4 * n + 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['no_lights', 'all_miss', 'no_bounces'])
+def test_degenerate_gpu(gpu_backend, name):
+    dev = torch.device('cuda:0')
+    build, mb = _variants(dev)[name]
+    img, grads = _run(gpu_backend, dev, build(), mb=mb)
+    assert np.isfinite(img).all()
+    if name in ('no_lights', 'all_miss'):
+        assert not img.any()
+    for g in grads:
+        assert g is None or np.isfinite(g).all()
+
+
+def test_empty_scene_hostsim(hostsim_backend):
+    """No shapes at all: a black image and no crash (src/scene.cpp:189-195 handles an empty shape list)."""
+    sc = scenes.two_triangles(torch.device('cpu'), resolution=(16, 16))
+    empty = Scene(sc.camera, [], [], [])
+    args = RenderFunction.serialize_scene(empty, 1, 1, sampler_type=hostsim_backend.SamplerType.sobol,
+                                          device=torch.device('cpu'), backend=hostsim_backend)
+    img = RenderFunction.apply(1, *args)
+    assert img.shape == (16, 16, 3) and not img.numpy().any()

@@ -18,7 +18,7 @@ TOL = 1e-4
 
 
 def _render(backend, device, builder, res, spp, mb, channels=None, opts=None):
-    sc = getattr(scenes, builder)(device, resolution=(res, res))
+    sc = getattr(scenes, builder)(device, resolution=res if isinstance(res, tuple) else (res, res))
     ch = None if channels is None else [getattr(backend.channels, c) for c in channels]
     opts = dict(opts or {})
     sampler = getattr(backend.SamplerType, opts.pop('sampler', 'sobol'))
