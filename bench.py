@@ -139,6 +139,19 @@ def cpu_baseline(max_bounces):
                       % (res, res, spp, max_bounces, reps, dt)}
 
 
+def measured_traffic(a):
+    """HBM bytes per closest-hit launch from the PMC passes (rocprofv3 cannot run inside this process): the
+    committed measurement in profiles/r1_traffic.json, valid for the default workload only, else None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_traffic.json')
+    if a.res != 1024 or a.max_bounces != 4 or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return float(json.load(f)['hbm_bytes_per_launch'])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -229,7 +242,7 @@ def main():
                        'parallelism': 'sample-sharded x%d' % world},
             'scene_build_ms': prep.scene_build_s * 1e3,
             'roofline': {'kernel': 'trace_kernel<closest-hit>', 'bound': 'hbm', 'achieved': achieved,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(a),
                          'mean_launch_ms': mean_launch_ms, 'launches_per_step': per_step_launches,
                          'rays_per_step': rays, 'nodes_per_ray': cnt.closest_nodes / max(rays, 1),
                          'tris_per_ray': cnt.closest_tris / max(rays, 1),
