@@ -372,7 +372,7 @@ RDR_FN V3 cos_hemisphere(V2 s) {
 // Importance-sample the outgoing direction.  Returns 0 when the sample fails.  wo_rd is written
 // only on success (like the reference, which leaves it untouched on the early return).
 RDR_FN V3 bsdf_sample_dir(const MaterialD &m, const Surf &sp, V3 wi, V2 s_uv, double s_w, double min_rough,
-                          const RayDiff &wi_rd, RayDiff &wo_rd, double &next_min_rough) {
+                          const RayDiff &wi_rd, RayDiff &wo_rd, double &next_min_rough, bool diffs = true) {
     next_min_rough = min_rough;
     ShadeCtx c = shade_ctx(m, sp);
     double gwi = dot(c.gn, wi);
@@ -381,9 +381,11 @@ RDR_FN V3 bsdf_sample_dir(const MaterialD &m, const Surf &sp, V3 wi, V2 s_uv, do
     if (s_w <= p.diffuse) {
         next_min_rough = 1.0;
         V3 ld = cos_hemisphere(s_uv);
-        wo_rd.org_dx = wi_rd.org_dx; wo_rd.org_dy = wi_rd.org_dy;
-        wo_rd.dir_dx = V3{0.03f, 0.03f, 0.03f};
-        wo_rd.dir_dy = V3{0.03f, 0.03f, 0.03f};
+        if (diffs) {
+            wo_rd.org_dx = wi_rd.org_dx; wo_rd.org_dy = wi_rd.org_dy;
+            wo_rd.dir_dx = V3{0.03f, 0.03f, 0.03f};
+            wo_rd.dir_dy = V3{0.03f, 0.03f, 0.03f};
+        }
         V3 d = to_world(c.fr, ld);
         if (dot(c.gn, d) * gwi < 0) d = to_world(c.fr, -ld);
         return d;
@@ -403,6 +405,7 @@ RDR_FN V3 bsdf_sample_dir(const MaterialD &m, const Surf &sp, V3 wi, V2 s_uv, do
         h = to_world(c.fr, hl);
         d = 2.f * dot(wi, h) * h - wi;
     }
+    if (!diffs) return d;
     V3 dmdx = sp.dn_dx * hl.z, dmdy = sp.dn_dy * hl.z;
     V3 wi_dx = -wi_rd.dir_dx, wi_dy = -wi_rd.dir_dy;
     double wdm_dx = sum(wi_dx * h) + sum(wi * dmdx);

@@ -3,6 +3,9 @@
 #include "edges.h"
 #include "camera.h"
 #include "scene.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -379,7 +382,21 @@ struct TreeBuilder {
 
 void delete_edge_data(EdgeData *e) { delete e; }
 
+namespace {
+struct PhaseTimer {         // RDR_DEBUG_DUMP: wall time of the build phases on stderr
+    const bool on = std::getenv("RDR_DEBUG_DUMP") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[redner_amd] edge build: %-24s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+}
+
 EdgeData *build_edge_data(Scene &scene) {
+    PhaseTimer timer;
     std::unique_ptr<EdgeData> ed(new EdgeData());
     const int ns = (int)scene.shapes.size();
     // host views of the shapes (same records, pointers into the host mirrors)
@@ -460,6 +477,7 @@ EdgeData *build_edge_data(Scene &scene) {
 
     // ---- primary edges: PMF = clipped screen-space length of camera silhouettes (:186-214, :299-334)
     if (scene.use_primary_edges) {
+        timer.lap("edge list (sort, merge)");
         ed->primary_pmf.assign(ne, 0); ed->primary_cdf.assign(ne, 0);
         double total = 0;
         for (int i = 0; i < ne; ++i) {
@@ -516,9 +534,12 @@ EdgeData *build_edge_data(Scene &scene) {
         mad = mad / double(ne);
         ed->edge_bounds_expand = 0.01f * len(mad);
 
+        timer.lap("pmf, bounds, split");
         TreeBuilder cs(true, shapes, edges, bounds), ncs(false, shapes, edges, bounds);
         cs.build(cs_ids);
+        timer.lap("3-D tree");
         ncs.build(ncs_ids);
+        timer.lap("6-D tree");
         ed->cs_nodes.swap(cs.nodes); ed->cs_leaves = cs.n;
         ed->ncs_nodes.swap(ncs.nodes); ed->ncs_leaves = ncs.n;
         // the NEE-mode traversal keeps one pending sibling per level in a fixed 64-entry stack
@@ -598,6 +619,7 @@ EdgeData *build_edge_data(Scene &scene) {
     };
     d.cs_nodes = fatten(ed->cs_nodes, ed->cs_leaves, 0, d.cs_root);
     d.ncs_nodes = fatten(ed->ncs_nodes, ed->ncs_leaves, kEdgeTreeBit, d.ncs_root);
+    timer.lap("device copies");
     d.edge_bounds_expand = ed->edge_bounds_expand;
     d.max_stack = ed->max_stack;
     d.cam_org = cam_org;

@@ -236,6 +236,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     s.d.materials = to_device(s, s.materials.data(), s.materials.size());
     s.d.lights = to_device(s, s.lights.data(), s.lights.size());
     s.d.envmap = nullptr;
+    s.d.no_diffs = 0;
     if (envmap) {
         EnvmapD e;
         std::memset(&e, 0, sizeof(e));

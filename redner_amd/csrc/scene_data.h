@@ -82,6 +82,7 @@ struct SceneD {
     const double *light_pmf, *light_cdf, *light_areas;
     const double *area_cdf_pool;   // concatenated per-light triangle CDFs
     const int *area_cdf_offset;    // per area light: start inside the pool
+    int no_diffs;                  // ray differentials cannot influence the result (set by the lean stages only)
 };
 
 // ---- gradient accumulators --------------------------------------------------------------------

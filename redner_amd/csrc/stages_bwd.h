@@ -69,7 +69,7 @@ struct AdjBounceArgs {
 
 struct AdjBounceScatter {
     AdjBounceArgs a;
-    RDR_FN void make_lean() { lean_scene(a.sc); a.nd = 3; a.radiance_dim = 0; }
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; }
     RDR_FN void operator()(int idx) const {
         const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v, &vn = a.vn; const AdjState &adj = a.adj;
         int p = a.active[idx];
@@ -86,7 +86,7 @@ struct AdjBounceScatter {
             int btri = vn.tri[p];
             RayDiff wo_rd = load_rdiff(vn, p);
             RayDiff tmp;
-            Surf bp = surf_at(bsh, btri, load_ray(vn, p), wo_rd, tmp);
+            Surf bp = surf_at(bsh, btri, load_ray(vn, p), wo_rd, tmp, !sc.no_diffs);
             V3 next_thr_bar = ld3(adj.thr, adj.n, p, 0);
             V3 next_dir_bar = ld3(adj.ray_dir, adj.n, p, 0);
             Surf next_pt_bar = load_adj_point(adj, p);
@@ -128,7 +128,7 @@ struct AdjBounceScatter {
                 RayDiff rd_bar = raydiff_zero();
                 TriGrad tg = trigrad_zero();
                 Ray br = make_ray(pos, wo);
-                adj_surf_at(bsh, btri, br, wo_rd, bp_bar, raydiff_zero(), r_bar, rd_bar, tg);
+                adj_surf_at(bsh, btri, br, wo_rd, bp_bar, raydiff_zero(), r_bar, rd_bar, tg, !sc.no_diffs);
                 if (c.mrough > 0.01f) {
                     sp_bar.position -= dir_bar;
                     sp_bar.position += r_bar.org;
@@ -178,7 +178,7 @@ RDR_FN void adj_record_add(const AdjState &adj, int p, V3 thr_bar, V3 in_dir_bar
 
 struct AdjBounceNee {
     AdjBounceArgs a;
-    RDR_FN void make_lean() { lean_scene(a.sc); a.nd = 3; a.radiance_dim = 0; }
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; }
     // next-event estimation towards the environment light (src/path_contribution.cpp:295-338)
     RDR_FN void envmap_nee(int p, const LightDraw &ld) const {
         const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v;
@@ -322,7 +322,7 @@ struct AdjPrimary {
     SceneD sc; GScene g; SamplerD rng; int sample_center;
     VSlice v0; const float *d_image; int nd, radiance_dim; double weight;
     AdjState adj; float *screen_grad; ChannelsD ch;
-    RDR_FN void make_lean() { lean_scene(sc); lean_channels(ch); nd = 3; radiance_dim = 0; }
+    RDR_FN void make_lean() { lean_scene(sc); lean_slice(v0); lean_channels(ch); nd = 3; radiance_dim = 0; }
     RDR_FN void operator()(int p) const {
         int shape = v0.shape[p];
         Ray ray = load_ray(v0, p);
@@ -332,7 +332,7 @@ struct AdjPrimary {
             const ShapeD &sh = sc.shapes[shape];
             if (sh.light_id >= 0 && g.light_intensity) {
                 RayDiff tmp;
-                Surf sp = surf_at(sh, v0.tri[p], ray, rd, tmp);
+                Surf sp = surf_at(sh, v0.tri[p], ray, rd, tmp, !sc.no_diffs);
                 const LightD &l = sc.lights[sh.light_id];
                 if (dot(-ray.dir, sp.frame.n) > 0 && l.directly_visible) {
                     V3 e_bar = weight * ld3(v0.thr, v0.n, p, 0) * image_grad(d_image, nd, ch.radiance_off, p);
@@ -361,26 +361,29 @@ struct AdjPrimary {
             Surf pt_bar = load_adj_point(adj, p);
             if (!ch.radiance_only) {
                 RayDiff tmp;
-                Surf sp = surf_at(sc.shapes[shape], v0.tri[p], ray, rd, tmp);
+                Surf sp = surf_at(sc.shapes[shape], v0.tri[p], ray, rd, tmp, !sc.no_diffs);
                 adj_first_hit_channels(sc, g, ch, d_image, weight, p, shape, sp, ray, pt_bar, r_bar.org);
             }
             TriGrad tg = trigrad_zero();
-            adj_surf_at(sc.shapes[shape], v0.tri[p], ray, rd, pt_bar, raydiff_zero(), r_bar, prd_bar, tg);
+            adj_surf_at(sc.shapes[shape], v0.tri[p], ray, rd, pt_bar, raydiff_zero(), r_bar, prd_bar, tg, !sc.no_diffs);
             scatter_trigrad(sc.shapes[shape], g.shapes[shape], v0.tri[p], tg);
         }
         V2 s = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
         V2 screen = pixel_to_screen(sc.cam, p, s);
         double delta = 1e-3;
         double sx = 0.5 / sc.cam.width, sy = 0.5 / sc.cam.height;
-        DRay rx_bar{prd_bar.org_dx * sx / delta, prd_bar.dir_dx * sx / delta};
-        DRay ry_bar{prd_bar.org_dy * sy / delta, prd_bar.dir_dy * sy / delta};
-        r_bar.org += (prd_bar.org_dx * -sx + prd_bar.org_dy * -sy) / delta;
-        r_bar.dir += (prd_bar.dir_dx * -sx + prd_bar.dir_dy * -sy) / delta;
         V2 scr_bar = v2(0, 0);
         const bool sb = screen_grad != nullptr;
+        if (!sc.no_diffs) {
+            // the finite-difference ray differential: two more primary rays carry its adjoint
+            DRay rx_bar{prd_bar.org_dx * sx / delta, prd_bar.dir_dx * sx / delta};
+            DRay ry_bar{prd_bar.org_dy * sy / delta, prd_bar.dir_dy * sy / delta};
+            r_bar.org += (prd_bar.org_dx * -sx + prd_bar.org_dy * -sy) / delta;
+            r_bar.dir += (prd_bar.dir_dx * -sx + prd_bar.dir_dy * -sy) / delta;
+            RDR_INLINE_CALL adj_primary_ray(sc.cam, screen + v2(delta, 0), rx_bar, g.cam, sb, scr_bar);
+            RDR_INLINE_CALL adj_primary_ray(sc.cam, screen + v2(0, delta), ry_bar, g.cam, sb, scr_bar);
+        }
         RDR_INLINE_CALL adj_primary_ray(sc.cam, screen, r_bar, g.cam, sb, scr_bar);
-        RDR_INLINE_CALL adj_primary_ray(sc.cam, screen + v2(delta, 0), rx_bar, g.cam, sb, scr_bar);
-        RDR_INLINE_CALL adj_primary_ray(sc.cam, screen + v2(0, delta), ry_bar, g.cam, sb, scr_bar);
         if (screen_grad) {
             screen_grad[2 * p] += (float)scr_bar.x;
             screen_grad[2 * p + 1] += (float)scr_bar.y;

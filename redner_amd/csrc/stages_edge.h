@@ -82,7 +82,7 @@ struct RecordHits {
 // First-hit emission for lanes whose hit ids are already recorded.
 struct ShadeRecorded {
     SceneD sc; const int *active; VSlice v; Sink sink;
-    RDR_FN void make_lean() { lean_scene(sc); lean_channels(sink.ch); sink.multipliers = nullptr; }
+    RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); lean_channels(sink.ch); sink.multipliers = nullptr; }
     RDR_FN void operator()(int idx) const {
         int p = active[idx];
         shade_first_hit(sc, sink, v, p, v.shape[p], v.tri[p]);
@@ -115,7 +115,7 @@ struct SamplePrimaryEdges {
     const float *d_image; int nd, radiance_dim;
     PrimaryEdgeRec *recs; VSlice v;       // lanes 2*slot, 2*slot+1
     double *multipliers;                  // [2P x nd] per-channel weights of the two rays, or null
-    RDR_FN void make_lean() { lean_scene(sc); multipliers = nullptr; nd = 3; radiance_dim = 0; }
+    RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); multipliers = nullptr; nd = 3; radiance_dim = 0; }
     RDR_FN void operator()(int slot) const {
         int l0 = 2 * slot, l1 = 2 * slot + 1;
         if (multipliers) for (int d = 0; d < 2 * nd; ++d) multipliers[(size_t)nd * l0 + d] = 0;
@@ -136,7 +136,7 @@ struct SamplePrimaryEdges {
         V2 a_ss, b_ss;
         // both rays of a slot carry the differential of the sampled screen position; see DESIGN.md
         // "edge-ray differentials" for how this differs from the reference's slot-indexed buffer
-        RayDiff rd;
+        RayDiff rd = raydiff_zero();
         if (!project_segment(sc.cam, a, b, a_ss, b_ss) || es.primary_pmf[eid] <= 0.f) {
             store_rdiff(v, l0, raydiff_zero()); store_rdiff(v, l1, raydiff_zero());
             return;
@@ -201,7 +201,7 @@ struct SamplePrimaryEdges {
         if (!linear) { w_up = w_up * jacobian; w_lo = w_lo * jacobian; }
         st3(v.thr, v.n, l0, 0, w_up);
         st3(v.thr, v.n, l1, 0, w_lo);
-        primary_ray_with_diff(sc.cam, pt, rd);
+        if (!sc.no_diffs) primary_ray_with_diff(sc.cam, pt, rd);
         if (v.erd) st_rdiff(v.erd, v.n, slot, rd);            // [quirk] slot-indexed; lanes read theirs in LoadLaneDiff
         else { store_rdiff(v, l0, rd); store_rdiff(v, l1, rd); }
     }
@@ -624,7 +624,7 @@ struct SecEdgeArgs {          // what every stage of the sampler needs
 // mode[slot]: 0 = no sample, 1 = hierarchical pick, 2 = NEE-billboard pick.  Also resets the slot's outputs.
 struct SecEdgeSetup {
     SecEdgeArgs a; unsigned char *mode; SecondaryEdgeRec *recs; SecPick *picks; VSlice ev; double *edge_tmin;
-    RDR_FN void make_lean() { lean_scene(a.sc); }
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(ev); }
     RDR_FN void operator()(int idx) const {
         int p = a.active[idx];
         int l0 = 2 * idx, l1 = 2 * idx + 1;
@@ -653,7 +653,7 @@ struct KeepMode {
 
 struct SecEdgePickH {
     SecEdgeArgs a; const int *slots; SecPick *picks;
-    RDR_FN void make_lean() { lean_scene(a.sc); }
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
     RDR_FN void operator()(int i) const {
         int idx = slots[i];
         SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
@@ -664,7 +664,7 @@ struct SecEdgePickH {
 };
 template <int NS> struct SecEdgePickN {
     SecEdgeArgs a; const int *slots; SecPick *picks;
-    RDR_FN void make_lean() { lean_scene(a.sc); }
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
     RDR_FN void operator()(int i) const {
         int idx = slots[i];
         SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
@@ -679,7 +679,7 @@ struct SecEdgeFinish {
     SecEdgeArgs a; const unsigned char *mode; const SecPick *picks;
     const float *d_image; int nd, radiance_dim;
     SecondaryEdgeRec *recs; VSlice ev; double *edge_tmin;
-    RDR_FN void make_lean() { lean_scene(a.sc); nd = 3; radiance_dim = 0; }
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(ev); nd = 3; radiance_dim = 0; }
     RDR_FN void operator()(int idx) const {
         if (mode[idx] == 0) return;
         SecPick pkd = picks[idx];
@@ -773,7 +773,7 @@ RDR_FN V3 isect_jacobian(V3 org, V3 dir, V3 p, V3 n, V3 l) {
 
 struct SecondaryEdgeWeights {
     SceneD sc; const SecondaryEdgeRec *recs; VSlice ev; double *hit_pos;   // hit_pos: 3 x n, stride ev.n
-    RDR_FN void make_lean() { lean_scene(sc); }
+    RDR_FN void make_lean() { lean_scene(sc); lean_slice(ev); }
     RDR_FN void scale_lane(const SecondaryEdgeRec &rec, int l) const {
         if (ev.shape[l] < 0) {
             if (sc.envmap != nullptr) {
@@ -786,7 +786,7 @@ struct SecondaryEdgeWeights {
             return;
         }
         RayDiff tmp;
-        Surf hp = surf_at(sc.shapes[ev.shape[l]], ev.tri[l], load_ray(ev, l), load_rdiff(ev, l), tmp);
+        Surf hp = surf_at(sc.shapes[ev.shape[l]], ev.tri[l], load_ray(ev, l), load_rdiff(ev, l), tmp, !sc.no_diffs);
         st3(hit_pos, ev.n, l, 0, hp.position);
         V3 dir = hp.position - rec.sp_pos;
         double d2 = len_sq(dir);

@@ -50,6 +50,7 @@ RDR_FN void st3(double *b, int n, int i, int k, V3 v) { b[(size_t)(k) * n + i] =
 RDR_FN Ray load_ray(const VSlice &v, int i) { return make_ray(ld3(v.ray, v.n, i, 0), ld3(v.ray, v.n, i, 3)); }
 RDR_FN void store_ray(const VSlice &v, int i, V3 o, V3 d) { st3(v.ray, v.n, i, 0, o); st3(v.ray, v.n, i, 3, d); }
 RDR_FN RayDiff load_rdiff(const VSlice &v, int i) {
+    if (!v.rdiff) return raydiff_zero();        // lean stages: differentials are neither stored nor used
     return RayDiff{ld3(v.rdiff, v.n, i, 0), ld3(v.rdiff, v.n, i, 3), ld3(v.rdiff, v.n, i, 6), ld3(v.rdiff, v.n, i, 9)};
 }
 RDR_FN void st_rdiff(double *b, int n, int i, const RayDiff &r) {
@@ -59,7 +60,7 @@ RDR_FN void st_rdiff(double *b, int n, int i, const RayDiff &r) {
 RDR_FN RayDiff ld_rdiff(const double *b, int n, int i) {
     return RayDiff{ld3(b, n, i, 0), ld3(b, n, i, 3), ld3(b, n, i, 6), ld3(b, n, i, 9)};
 }
-RDR_FN void store_rdiff(const VSlice &v, int i, const RayDiff &r) { st_rdiff(v.rdiff, v.n, i, r); }
+RDR_FN void store_rdiff(const VSlice &v, int i, const RayDiff &r) { if (v.rdiff) st_rdiff(v.rdiff, v.n, i, r); }
 
 RDR_FN void put_ray(rt::RayRec *q, int slot, const Ray &r, bool dead) {
     rt::RayRec rec;
@@ -94,11 +95,13 @@ struct Sink {
 };
 
 // ---- lean specialisation ---------------------------------------------------------------------------
-// Most scenes have a pinhole camera without lens distortion, no environment light and render radiance only.
+// Most scenes have a pinhole camera without lens distortion, no environment light, no mip-mapped texture and
+// render radiance only (without mip levels and environment lookups ray differentials have no effect at all).
 // For them the host launches LeanStage<Stage>: the stage's scene copy gets those facts written in as constants,
 // so after inlining the compiler drops the other camera models, the environment-light estimators and the
 // G-buffer channels -- and with them the registers (and scratch) those paths would pin.
-RDR_FN void lean_scene(SceneD &sc) { sc.envmap = nullptr; sc.cam.kind = kCamPerspective; sc.cam.distortion.defined = 0; }
+RDR_FN void lean_scene(SceneD &sc) { sc.envmap = nullptr; sc.cam.kind = kCamPerspective; sc.cam.distortion.defined = 0; sc.no_diffs = 1; }
+RDR_FN void lean_slice(VSlice &v) { v.rdiff = nullptr; v.erd = nullptr; }
 RDR_FN void lean_channels(ChannelsD &ch) { ch.n = 1; ch.radiance_only = 1; ch.radiance_dim = 0; ch.radiance_off = 0; ch.nd = 3; }
 template <class Stage> struct LeanStage {
     Stage f;
@@ -114,11 +117,12 @@ RDR_FN LightDraw draw_light(const SamplerD &rng, int slot, int dim) {
 struct GenPrimary {
     SceneD sc; SamplerD rng; int sample_center;
     VSlice v0; rt::RayRec *q;
-    RDR_FN void make_lean() { lean_scene(sc); }
+    RDR_FN void make_lean() { lean_scene(sc); lean_slice(v0); }
     RDR_FN void operator()(int p) const {
         V2 s = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
-        RayDiff rd;
-        Ray r = primary_ray_with_diff(sc.cam, pixel_to_screen(sc.cam, p, s), rd);
+        RayDiff rd = raydiff_zero();
+        Ray r = sc.no_diffs ? primary_ray(sc.cam, pixel_to_screen(sc.cam, p, s))
+                            : primary_ray_with_diff(sc.cam, pixel_to_screen(sc.cam, p, s), rd);
         store_ray(v0, p, r.org, r.dir);
         store_rdiff(v0, p, rd);
         st3(v0.thr, v0.n, p, 0, v3(1));
@@ -141,7 +145,7 @@ RDR_FN V3 direct_emission(const SceneD &sc, int shape, int tri, const Ray &ray, 
             bool facing = true;
             if (!l.two_sided) {
                 RayDiff tmp;
-                Surf sp = surf_at(sh, tri, ray, rd, tmp);
+                Surf sp = surf_at(sh, tri, ray, rd, tmp, !sc.no_diffs);
                 facing = dot(-ray.dir, sp.frame.n) > 0;
             }
             if (facing) e += v3f(l.intensity);
@@ -210,7 +214,7 @@ RDR_FN void shade_first_hit(const SceneD &sc, const Sink &sink, const VSlice &v,
         return;
     }
     Surf sp = surf_zero();
-    if (shape >= 0) { RayDiff tmp; sp = surf_at(sc.shapes[shape], tri, ray, rd, tmp); }
+    if (shape >= 0) { RayDiff tmp; sp = surf_at(sc.shapes[shape], tri, ray, rd, tmp, !sc.no_diffs); }
     int d = 0;
     for (int k = 0; k < sink.ch.n; ++k) {
         int id = sink.ch.id[k];
@@ -248,7 +252,7 @@ RDR_FN void shade_first_hit(const SceneD &sc, const Sink &sink, const VSlice &v,
 
 struct ShadePrimary {
     SceneD sc; const int *active; VSlice v; const rt::HitRec *hits; Sink sink;
-    RDR_FN void make_lean() { lean_scene(sc); lean_channels(sink.ch); sink.multipliers = nullptr; }
+    RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); lean_channels(sink.ch); sink.multipliers = nullptr; }
     RDR_FN void operator()(int idx) const {
         int p = active ? active[idx] : idx;
         rt::HitRec h = hits[idx];
@@ -268,7 +272,7 @@ RDR_FN VertexCtx load_vertex(const SceneD &sc, const VSlice &v, int p) {
     c.rd_in = load_rdiff(v, p);
     c.shape = &sc.shapes[v.shape[p]];
     c.mat = &sc.materials[c.shape->material_id];
-    c.sp = surf_at(*c.shape, v.tri[p], c.ray, c.rd_in, c.rd_surf);
+    c.sp = surf_at(*c.shape, v.tri[p], c.ray, c.rd_in, c.rd_surf, !sc.no_diffs);
     c.wi = -c.ray.dir;
     c.mrough = v.mrough[p];
     return c;
@@ -277,7 +281,7 @@ RDR_FN VertexCtx load_vertex(const SceneD &sc, const VSlice &v, int p) {
 // ---- stage: draw the NEE point and the BSDF direction, emit both rays ---------------------------
 struct BounceSample {
     SceneD sc; SamplerD rng; int dim, rng_shift;
-    RDR_FN void make_lean() { lean_scene(sc); }
+    RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); lean_slice(vn); }
     const int *active; VSlice v, vn;
     rt::RayRec *q_nee, *q_bsdf;
     RDR_FN void operator()(int idx) const {
@@ -303,7 +307,7 @@ struct BounceSample {
         // a sampler that bails out (one-sided surface seen from behind) leaves the differential untouched
         RayDiff wo_rd = vn.erd ? ld_rdiff(vn.erd, vn.n, p) : raydiff_zero();
         double next_mr;
-        V3 dir = bsdf_sample_dir(*c.mat, c.sp, c.wi, buv, bw, c.mrough, c.rd_surf, wo_rd, next_mr);
+        V3 dir = bsdf_sample_dir(*c.mat, c.sp, c.wi, buv, bw, c.mrough, c.rd_surf, wo_rd, next_mr, !sc.no_diffs);
         store_ray(vn, p, c.sp.position, dir);
         store_rdiff(vn, p, wo_rd);
         if (vn.erd) st_rdiff(vn.erd, vn.n, p, wo_rd);
@@ -399,7 +403,7 @@ struct BounceContrib {
     const int *active; VSlice v, vn;
     const rt::HitRec *h_nee, *h_bsdf;
     Sink sink;
-    RDR_FN void make_lean() { lean_scene(sc); lean_channels(sink.ch); }
+    RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); lean_slice(vn); lean_channels(sink.ch); }
     RDR_FN void operator()(int idx) const {
         int p = active[idx];
         int slot = p >> rng_shift;
@@ -415,7 +419,7 @@ struct BounceContrib {
         Surf bp = surf_zero();
         if (hb.shape >= 0) {
             RayDiff tmp;
-            bp = surf_at(sc.shapes[hb.shape], hb.prim, load_ray(vn, p), load_rdiff(vn, p), tmp);
+            bp = surf_at(sc.shapes[hb.shape], hb.prim, load_ray(vn, p), load_rdiff(vn, p), tmp, !sc.no_diffs);
             if (vn.erd) st_rdiff(vn.erd, vn.n, p, tmp);
         }
         V3 thr = ld3(v.thr, v.n, p, 0);

@@ -54,7 +54,23 @@ RDR_FN double clamp_divisor(double d) {
     return d;
 }
 
-RDR_FN TriHit tri_hit(V3 p0, V3 p1, V3 p2, const Ray &ray, const RayDiff &rd) {
+// `diffs` = false: the caller knows that ray differentials cannot influence anything (no mip-mapped texture, no
+// environment light; see LeanStage) -- the screen-space derivatives are then not computed and come back as zero.
+RDR_FN TriHit tri_hit(V3 p0, V3 p1, V3 p2, const Ray &ray, const RayDiff &rd, bool diffs = true) {
+    if (!diffs) {
+        V3 e1 = p1 - p0, e2 = p2 - p0;
+        V3 pv = cross(ray.dir, e2);
+        double div = clamp_divisor(dot(pv, e1));
+        V3 s = ray.org - p0;
+        double a = dot(s, pv);
+        V3 qv = cross(s, e1);
+        double b = dot(ray.dir, qv);
+        double c = dot(e2, qv);
+        TriHit h;
+        h.u = a / div; h.v = b / div; h.t = c / div;
+        h.u_dxy = h.v_dxy = h.t_dxy = v2(0, 0);
+        return h;
+    }
     V3 e1 = p1 - p0, e2 = p2 - p0;
     V3 pv = cross(ray.dir, e2), pv_x = cross(rd.dir_dx, e2), pv_y = cross(rd.dir_dy, e2);
     double div = clamp_divisor(dot(pv, e1));
@@ -76,6 +92,43 @@ RDR_FN TriHit tri_hit(V3 p0, V3 p1, V3 p2, const Ray &ray, const RayDiff &rd) {
 }
 
 // Adjoint of tri_hit.  uvt_bar = adjoint of (u, v, t).
+// Adjoint of tri_hit(..., diffs = false): only (u, v, t) carry adjoints.  Same expressions in the same order as the
+// general version below with every differential term dropped (those terms are exact zeros there).
+RDR_FN void adj_tri_hit_nodiff(V3 p0, V3 p1, V3 p2, const Ray &ray, V3 uvt_bar,
+                               V3 &p0_bar, V3 &p1_bar, V3 &p2_bar, DRay &ray_bar) {
+    RDR_CONTRACT_FAST
+    V3 e1 = p1 - p0, e2 = p2 - p0;
+    V3 pv = cross(ray.dir, e2);
+    double div = clamp_divisor(dot(pv, e1));
+    V3 s = ray.org - p0;
+    double a = dot(s, pv);
+    V3 qv = cross(s, e1);
+    double b = dot(ray.dir, qv);
+    double c = dot(e2, qv);
+    double div_bar = 0, n_bar;
+    // t
+    n_bar = uvt_bar.z / div;
+    div_bar += -uvt_bar.z * (c / div) / div;
+    V3 e2_bar = n_bar * qv;
+    V3 qv_bar = n_bar * e2;
+    // v
+    n_bar = uvt_bar.y / div;
+    div_bar += -uvt_bar.y * (b / div) / div;
+    ray_bar.dir += n_bar * qv; qv_bar += n_bar * ray.dir;
+    V3 s_bar = v3(0), e1_bar = v3(0);
+    adj_cross(s, e1, qv_bar, s_bar, e1_bar);
+    // u
+    n_bar = uvt_bar.x / div;
+    div_bar += -uvt_bar.x * (a / div) / div;
+    s_bar += n_bar * pv; V3 pv_bar = n_bar * s;
+    ray_bar.org += s_bar;
+    p0_bar -= s_bar;
+    pv_bar += div_bar * e1; e1_bar += div_bar * pv;
+    adj_cross(ray.dir, e2, pv_bar, ray_bar.dir, e2_bar);
+    p2_bar += e2_bar; p0_bar -= e2_bar;
+    p1_bar += e1_bar; p0_bar -= e1_bar;
+}
+
 RDR_FN void adj_tri_hit(V3 p0, V3 p1, V3 p2, const Ray &ray, const RayDiff &rd,
                         V3 uvt_bar, V2 udxy_bar, V2 vdxy_bar, V2 tdxy_bar,
                         V3 &p0_bar, V3 &p1_bar, V3 &p2_bar, DRay &ray_bar, RayDiff &rd_bar) {
@@ -162,10 +215,10 @@ RDR_FN TriAttr load_attr(const ShapeD &sh, int tri, const TriVerts &tv) {
 
 // Shading point of `ray` on triangle `tri` of `sh`; also transfers the ray differential onto the
 // surface (new_rd).
-RDR_FN Surf surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff &rd, RayDiff &new_rd) {
+RDR_FN Surf surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff &rd, RayDiff &new_rd, bool diffs = true) {
     TriVerts tv = load_tri(sh, tri);
     TriAttr at = load_attr(sh, tri, tv);
-    TriHit h = tri_hit(tv.p0, tv.p1, tv.p2, ray, rd);
+    TriHit h = tri_hit(tv.p0, tv.p1, tv.p2, ray, rd, diffs);
     double u = h.u, v = h.v, w = 1.f - (u + v), t = h.t;
     Surf sp;
     sp.uv = w * at.uv0 + u * at.uv1 + v * at.uv2;
@@ -182,20 +235,26 @@ RDR_FN Surf surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff &rd
         V3 p02 = tv.p0 - tv.p2, p12 = tv.p1 - tv.p2;
         dpdu = (uv12.y * p02 - uv02.y * p12) * inv;
     }
-    sp.du_dxy = (-h.u_dxy - h.v_dxy) * at.uv0.x + h.u_dxy * at.uv1.x + h.v_dxy * at.uv2.x;
-    sp.dv_dxy = (-h.u_dxy - h.v_dxy) * at.uv0.y + h.u_dxy * at.uv1.y + h.v_dxy * at.uv2.y;
-    V3 dpdx = rd.org_dx + ray.dir * h.t_dxy.x + rd.dir_dx * t;
-    V3 dpdy = rd.org_dy + ray.dir * h.t_dxy.y + rd.dir_dy * t;
+    sp.du_dxy = sp.dv_dxy = v2(0, 0);
+    V3 dpdx = v3(0), dpdy = v3(0);
+    if (diffs) {
+        sp.du_dxy = (-h.u_dxy - h.v_dxy) * at.uv0.x + h.u_dxy * at.uv1.x + h.v_dxy * at.uv2.x;
+        sp.dv_dxy = (-h.u_dxy - h.v_dxy) * at.uv0.y + h.u_dxy * at.uv1.y + h.v_dxy * at.uv2.y;
+        dpdx = rd.org_dx + ray.dir * h.t_dxy.x + rd.dir_dx * t;
+        dpdy = rd.org_dy + ray.dir * h.t_dxy.y + rd.dir_dy * t;
+    }
     V3 sn = gn;
     sp.dn_dx = sp.dn_dy = v3(0);
     if (sh.normals) {
         V3 n0 = v3f(sh.normals + 3 * at.ni0), n1 = v3f(sh.normals + 3 * at.ni1), n2 = v3f(sh.normals + 3 * at.ni2);
         V3 nn = w * n0 + u * n1 + v * n2;
-        V3 dnn_dx = (-h.u_dxy.x - h.v_dxy.x) * n0 + h.u_dxy.x * n1 + h.v_dxy.x * n2;
-        V3 dnn_dy = (-h.u_dxy.y - h.v_dxy.y) * n0 + h.u_dxy.y * n1 + h.v_dxy.y * n2;
-        double l2 = dot(nn, nn), l = sqrt(l2);
-        sp.dn_dx = (l2 * dnn_dx - dot(nn, dnn_dx) * nn) / (l2 * l);
-        sp.dn_dy = (l2 * dnn_dy - dot(nn, dnn_dy) * nn) / (l2 * l);
+        if (diffs) {
+            V3 dnn_dx = (-h.u_dxy.x - h.v_dxy.x) * n0 + h.u_dxy.x * n1 + h.v_dxy.x * n2;
+            V3 dnn_dy = (-h.u_dxy.y - h.v_dxy.y) * n0 + h.u_dxy.y * n1 + h.v_dxy.y * n2;
+            double l2 = dot(nn, nn), l = sqrt(l2);
+            sp.dn_dx = (l2 * dnn_dx - dot(nn, dnn_dx) * nn) / (l2 * l);
+            sp.dn_dy = (l2 * dnn_dy - dot(nn, dnn_dy) * nn) / (l2 * l);
+        }
         sn = normalize(nn);
         if (dot(gn, sn) < 0.f) gn = -gn;
     }
@@ -211,7 +270,7 @@ RDR_FN Surf surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff &rd
     sp.geom_normal = gn;
     sp.dpdu = dpdu;
     new_rd.org_dx = dpdx; new_rd.org_dy = dpdy;
-    new_rd.dir_dx = rd.dir_dx; new_rd.dir_dy = rd.dir_dy;
+    new_rd.dir_dx = diffs ? rd.dir_dx : v3(0); new_rd.dir_dy = diffs ? rd.dir_dy : v3(0);
     sp.color = v3(0);
     if (sh.colors) {
         V3 c0 = v3f(sh.colors + 3 * tv.i0), c1 = v3f(sh.colors + 3 * tv.i1), c2 = v3f(sh.colors + 3 * tv.i2);
@@ -231,11 +290,11 @@ RDR_FN TriGrad trigrad_zero() {
 
 RDR_FN void adj_surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff &rd,
                         const Surf &sp_bar, const RayDiff &new_rd_bar,
-                        DRay &ray_bar, RayDiff &rd_bar, TriGrad &g) {
+                        DRay &ray_bar, RayDiff &rd_bar, TriGrad &g, bool diffs = true) {
     RDR_CONTRACT_FAST
     TriVerts tv = load_tri(sh, tri);
     TriAttr at = load_attr(sh, tri, tv);
-    TriHit h = tri_hit(tv.p0, tv.p1, tv.p2, ray, rd);
+    TriHit h = tri_hit(tv.p0, tv.p1, tv.p2, ray, rd, diffs);
     double u = h.u, v = h.v, w = 1.f - (u + v), t = h.t;
     V3 gn_raw = cross(tv.p1 - tv.p0, tv.p2 - tv.p0);
     V3 gn = normalize(gn_raw);
@@ -257,11 +316,13 @@ RDR_FN void adj_surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff
     if (sh.normals) {
         n0 = v3f(sh.normals + 3 * at.ni0); n1 = v3f(sh.normals + 3 * at.ni1); n2 = v3f(sh.normals + 3 * at.ni2);
         nn = w * n0 + u * n1 + v * n2;
-        dnn_dx = (-h.u_dxy.x - h.v_dxy.x) * n0 + h.u_dxy.x * n1 + h.v_dxy.x * n2;
-        dnn_dy = (-h.u_dxy.y - h.v_dxy.y) * n0 + h.u_dxy.y * n1 + h.v_dxy.y * n2;
         l2 = dot(nn, nn); l = sqrt(l2);
-        dn_dx = (l2 * dnn_dx - dot(nn, dnn_dx) * nn) / (l2 * l);
-        dn_dy = (l2 * dnn_dy - dot(nn, dnn_dy) * nn) / (l2 * l);
+        if (diffs) {
+            dnn_dx = (-h.u_dxy.x - h.v_dxy.x) * n0 + h.u_dxy.x * n1 + h.v_dxy.x * n2;
+            dnn_dy = (-h.u_dxy.y - h.v_dxy.y) * n0 + h.u_dxy.y * n1 + h.v_dxy.y * n2;
+            dn_dx = (l2 * dnn_dx - dot(nn, dnn_dx) * nn) / (l2 * l);
+            dn_dy = (l2 * dnn_dy - dot(nn, dnn_dy) * nn) / (l2 * l);
+        }
         sn = normalize(nn);
         if (dot(gn, sn) < 0.f) { gn = -gn; flipped = true; }
     }
@@ -299,7 +360,11 @@ RDR_FN void adj_surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff
         if (flipped) gn_bar = -gn_bar;
         // the reference additionally pushes the frame tangents through an onb() adjoint here
         adj_onb(sn, sp_bar.frame.x, sp_bar.frame.y, sn_bar);
-        if (l2 > 0) {
+        if (l2 > 0 && !diffs) {
+            V3 nn_bar = adj_normalize(nn, sn_bar);
+            w_bar += sum(nn_bar * n0); u_bar += sum(nn_bar * n1); v_bar += sum(nn_bar * n2);
+            g.n[0] += nn_bar * w; g.n[1] += nn_bar * u; g.n[2] += nn_bar * v;
+        } else if (l2 > 0) {
             V3 nn_bar = adj_normalize(nn, sn_bar);
             double den = l2 * l;
             V3 a_bar = sp_bar.dn_dx, b_bar = sp_bar.dn_dy;
@@ -328,16 +393,19 @@ RDR_FN void adj_surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff
         adj_onb(sn, sp_bar.frame.x, sp_bar.frame.y, gn_bar);
     }
     V2 tdxy_bar = v2(0, 0);
-    rd_bar.org_dx += dpdx_bar;
-    ray_bar.dir += dpdx_bar * h.t_dxy.x;
-    tdxy_bar.x += sum(dpdx_bar * ray.dir);
-    rd_bar.dir_dx += dpdx_bar * t;
-    double t_bar = sum(dpdx_bar * rd.dir_dx);
-    rd_bar.org_dy += dpdy_bar;
-    ray_bar.dir += dpdy_bar * h.t_dxy.y;
-    tdxy_bar.y += sum(dpdy_bar * ray.dir);
-    rd_bar.dir_dy += dpdy_bar * t;
-    t_bar += sum(dpdy_bar * rd.dir_dy);
+    double t_bar = 0;
+    if (diffs) {
+        rd_bar.org_dx += dpdx_bar;
+        ray_bar.dir += dpdx_bar * h.t_dxy.x;
+        tdxy_bar.x += sum(dpdx_bar * ray.dir);
+        rd_bar.dir_dx += dpdx_bar * t;
+        t_bar = sum(dpdx_bar * rd.dir_dx);
+        rd_bar.org_dy += dpdy_bar;
+        ray_bar.dir += dpdy_bar * h.t_dxy.y;
+        tdxy_bar.y += sum(dpdy_bar * ray.dir);
+        rd_bar.dir_dy += dpdy_bar * t;
+        t_bar += sum(dpdy_bar * rd.dir_dy);
+    }
 
     V2 uv0_bar = v2(0, 0), uv1_bar = v2(0, 0), uv2_bar = v2(0, 0);
     if (uv_det == 0) {
@@ -359,12 +427,14 @@ RDR_FN void adj_surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff
         uv0_bar += uv02_bar; uv1_bar += uv12_bar; uv2_bar -= (uv02_bar + uv12_bar);
         p0_bar += p02_bar; p1_bar += p12_bar; p2_bar -= (p02_bar + p12_bar);
     }
-    V2 du_bar = sp_bar.du_dxy, dv_bar = sp_bar.dv_dxy;
-    udxy_bar += du_bar * (at.uv1.x - at.uv0.x) + dv_bar * (at.uv1.y - at.uv0.y);
-    vdxy_bar += du_bar * (at.uv2.x - at.uv0.x) + dv_bar * (at.uv2.y - at.uv0.y);
-    uv0_bar.x += sum(du_bar * (-h.u_dxy - h.v_dxy)); uv0_bar.y += sum(dv_bar * (-h.u_dxy - h.v_dxy));
-    uv1_bar.x += sum(du_bar * h.u_dxy); uv1_bar.y += sum(dv_bar * h.u_dxy);
-    uv2_bar.x += sum(du_bar * h.v_dxy); uv2_bar.y += sum(dv_bar * h.v_dxy);
+    if (diffs) {
+        V2 du_bar = sp_bar.du_dxy, dv_bar = sp_bar.dv_dxy;
+        udxy_bar += du_bar * (at.uv1.x - at.uv0.x) + dv_bar * (at.uv1.y - at.uv0.y);
+        vdxy_bar += du_bar * (at.uv2.x - at.uv0.x) + dv_bar * (at.uv2.y - at.uv0.y);
+        uv0_bar.x += sum(du_bar * (-h.u_dxy - h.v_dxy)); uv0_bar.y += sum(dv_bar * (-h.u_dxy - h.v_dxy));
+        uv1_bar.x += sum(du_bar * h.u_dxy); uv1_bar.y += sum(dv_bar * h.u_dxy);
+        uv2_bar.x += sum(du_bar * h.v_dxy); uv2_bar.y += sum(dv_bar * h.v_dxy);
+    }
 
     V3 gnraw_bar = adj_normalize(gn_raw, gn_bar);
     V3 e1_bar = v3(0), e2_bar = v3(0);
@@ -378,8 +448,9 @@ RDR_FN void adj_surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff
     w_bar += sum(uv_bar * at.uv0); u_bar += sum(uv_bar * at.uv1); v_bar += sum(uv_bar * at.uv2);
     uv0_bar += uv_bar * w; uv1_bar += uv_bar * u; uv2_bar += uv_bar * v;
     u_bar -= w_bar; v_bar -= w_bar;
-    adj_tri_hit(tv.p0, tv.p1, tv.p2, ray, rd, v3(u_bar, v_bar, t_bar), udxy_bar, vdxy_bar, tdxy_bar,
-                p0_bar, p1_bar, p2_bar, ray_bar, rd_bar);
+    if (diffs) adj_tri_hit(tv.p0, tv.p1, tv.p2, ray, rd, v3(u_bar, v_bar, t_bar), udxy_bar, vdxy_bar, tdxy_bar,
+                           p0_bar, p1_bar, p2_bar, ray_bar, rd_bar);
+    else adj_tri_hit_nodiff(tv.p0, tv.p1, tv.p2, ray, v3(u_bar, v_bar, t_bar), p0_bar, p1_bar, p2_bar, ray_bar);
     if (sh.uvs) { g.uv[0] += uv0_bar; g.uv[1] += uv1_bar; g.uv[2] += uv2_bar; }
     g.p[0] += p0_bar; g.p[1] += p1_bar; g.p[2] += p2_bar;
 }
