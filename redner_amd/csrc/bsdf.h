@@ -133,17 +133,26 @@ RDR_FN void adj_tex_fetch(const TexD &tex, V2 uv_, V2 du_, V2 dv_, const double 
     }
 }
 
+// sp.plain (lean stages): the texture is known to be a constant, so the lookup machinery -- and the registers it
+// would pin -- is compiled out; the values are what tex_fetch's own constant branch returns.
 RDR_FN V3 tex3(const TexD &tex, const Surf &sp) {
+    if (sp.plain) return V3{(double)tex.texels[0][0], (double)tex.texels[0][1], (double)tex.texels[0][2]};
     double o[3]; tex_fetch(tex, sp.uv, sp.du_dxy, sp.dv_dxy, o); return V3{o[0], o[1], o[2]};
 }
 RDR_FN double tex1(const TexD &tex, const Surf &sp) {
+    if (sp.plain) return tex.texels[0][0];
     double o; tex_fetch(tex, sp.uv, sp.du_dxy, sp.dv_dxy, &o); return o;
 }
 RDR_FN void adj_tex3(const TexD &tex, const Surf &sp, V3 o_bar, const GTex &g, Surf &sp_bar) {
+    if (sp.plain) {
+        if (g.texels[0]) { accum(g.texels[0] + 0, o_bar.x); accum(g.texels[0] + 1, o_bar.y); accum(g.texels[0] + 2, o_bar.z); }
+        return;
+    }
     double ob[3] = {o_bar.x, o_bar.y, o_bar.z};
     adj_tex_fetch(tex, sp.uv, sp.du_dxy, sp.dv_dxy, ob, g, sp_bar.uv, sp_bar.du_dxy, sp_bar.dv_dxy);
 }
 RDR_FN void adj_tex1(const TexD &tex, const Surf &sp, double o_bar, const GTex &g, Surf &sp_bar) {
+    if (sp.plain) { if (g.texels[0]) accum(g.texels[0], o_bar); return; }
     adj_tex_fetch(tex, sp.uv, sp.du_dxy, sp.dv_dxy, &o_bar, g, sp_bar.uv, sp_bar.du_dxy, sp_bar.dv_dxy);
 }
 
@@ -178,7 +187,7 @@ struct ShadeCtx {      // the side/frame bookkeeping all four BSDF entry points 
 RDR_FN ShadeCtx shade_ctx(const MaterialD &m, const Surf &sp) {
     ShadeCtx c;
     c.fr = sp.frame;
-    if (has_normal_map(m)) c.fr = perturbed_frame(m, sp);
+    if (!sp.plain && has_normal_map(m)) c.fr = perturbed_frame(m, sp);
     c.gn = sp.geom_normal;
     if (dot(c.gn, c.fr.n) < 0) c.gn = -c.gn;
     return c;

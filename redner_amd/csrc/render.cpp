@@ -97,7 +97,7 @@ uint64_t pcg_stream_seed(const rdr_render_options &o) {
 bool scene_is_lean(const Scene &scene, const ChannelsD &ch) {
     const CameraD &c = scene.d.cam;
     return scene.d.envmap == nullptr && c.kind == kCamPerspective && !c.distortion.defined && ch.radiance_only &&
-           !scene.has_mipmaps;
+           !scene.has_mipmaps && !scene.has_textures;
 }
 
 // Launch `f`, or its lean specialisation when the scene allows it (see LeanStage in stages_fwd.h).

@@ -149,6 +149,9 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         o.use_vertex_color = in.use_vertex_color;
         for (const TexD *t : {&o.diffuse, &o.specular, &o.roughness, &o.generic, &o.normal_map})
             if (t->num_levels > 1) s.has_mipmaps = true;
+        for (const TexD *t : {&o.diffuse, &o.specular, &o.roughness})
+            if (t->width[0] > 0 || t->height[0] > 0) s.has_textures = true;
+        if (o.normal_map.num_levels > 0) s.has_textures = true;
         if (o.generic.num_levels > 0)
             s.max_generic_texture_dimension = std::max(s.max_generic_texture_dimension, o.generic.channels);
     }
@@ -237,6 +240,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     s.d.lights = to_device(s, s.lights.data(), s.lights.size());
     s.d.envmap = nullptr;
     s.d.no_diffs = 0;
+    s.d.plain_materials = 0;
     if (envmap) {
         EnvmapD e;
         std::memset(&e, 0, sizeof(e));

@@ -83,6 +83,7 @@ struct SceneD {
     const double *area_cdf_pool;   // concatenated per-light triangle CDFs
     const int *area_cdf_offset;    // per area light: start inside the pool
     int no_diffs;                  // ray differentials cannot influence the result (set by the lean stages only)
+    int plain_materials;           // every texture is a constant, no normal maps (set by the lean stages only)
 };
 
 // ---- gradient accumulators --------------------------------------------------------------------

@@ -95,12 +95,13 @@ struct Sink {
 };
 
 // ---- lean specialisation ---------------------------------------------------------------------------
-// Most scenes have a pinhole camera without lens distortion, no environment light, no mip-mapped texture and
-// render radiance only (without mip levels and environment lookups ray differentials have no effect at all).
+// Plain scenes -- pinhole camera without lens distortion, no environment light, constant reflectances (no image
+// textures, no normal maps), radiance only -- are what optimisation loops over geometry mostly render.  Without
+// mip levels and environment lookups ray differentials have no effect at all.
 // For them the host launches LeanStage<Stage>: the stage's scene copy gets those facts written in as constants,
 // so after inlining the compiler drops the other camera models, the environment-light estimators and the
 // G-buffer channels -- and with them the registers (and scratch) those paths would pin.
-RDR_FN void lean_scene(SceneD &sc) { sc.envmap = nullptr; sc.cam.kind = kCamPerspective; sc.cam.distortion.defined = 0; sc.no_diffs = 1; }
+RDR_FN void lean_scene(SceneD &sc) { sc.envmap = nullptr; sc.cam.kind = kCamPerspective; sc.cam.distortion.defined = 0; sc.no_diffs = 1; sc.plain_materials = 1; }
 RDR_FN void lean_slice(VSlice &v) { v.rdiff = nullptr; v.erd = nullptr; }
 RDR_FN void lean_channels(ChannelsD &ch) { ch.n = 1; ch.radiance_only = 1; ch.radiance_dim = 0; ch.radiance_off = 0; ch.nd = 3; }
 template <class Stage> struct LeanStage {
@@ -273,6 +274,7 @@ RDR_FN VertexCtx load_vertex(const SceneD &sc, const VSlice &v, int p) {
     c.shape = &sc.shapes[v.shape[p]];
     c.mat = &sc.materials[c.shape->material_id];
     c.sp = surf_at(*c.shape, v.tri[p], c.ray, c.rd_in, c.rd_surf, !sc.no_diffs);
+    c.sp.plain = sc.plain_materials;
     c.wi = -c.ray.dir;
     c.mrough = v.mrough[p];
     return c;

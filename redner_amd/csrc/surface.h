@@ -29,6 +29,7 @@ struct Surf {
     V3 dn_dx, dn_dy;
     V3 color;
     V2 bary;
+    int plain = 0;     // set by the lean stages: every texture of the scene is a constant and there is no normal map
 };
 RDR_FN Surf surf_zero() {
     Surf s;
