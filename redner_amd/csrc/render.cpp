@@ -97,7 +97,7 @@ uint64_t pcg_stream_seed(const rdr_render_options &o) {
 bool scene_is_lean(const Scene &scene, const ChannelsD &ch) {
     const CameraD &c = scene.d.cam;
     return scene.d.envmap == nullptr && c.kind == kCamPerspective && !c.distortion.defined && ch.radiance_only &&
-           !scene.has_mipmaps && !scene.has_textures;
+           !scene.has_mipmaps && !scene.has_textures && !scene.has_vertex_colors;
 }
 
 // Launch `f`, or its lean specialisation when the scene allows it (see LeanStage in stages_fwd.h).
@@ -252,7 +252,7 @@ struct Backward {
         : scene(scene_), opt(opt_), P(P_), B(B_), d_image(d_image_), screen_grad(screen_grad_), weight(weight_),
           nd(nd_), radiance_dim(radiance_dim_), grads(scene_, ds), ch(ch_) {
         lean = scene_is_lean(scene, ch);
-        adj.n = P;
+        adj.n = P; adj.plain = 0;
         adj.thr = arena.get<double>((size_t)3 * P);
         adj.ray_dir = arena.get<double>((size_t)3 * P);
         adj.point = arena.get<double>((size_t)kAdjPointDoubles * P);

@@ -122,6 +122,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         ShapeD &o = s.shapes[i];
         o.vertices = in.vertices; o.indices = in.indices; o.uvs = in.uvs; o.normals = in.normals;
         o.uv_indices = in.uv_indices; o.normal_indices = in.normal_indices; o.colors = in.colors;
+        if (in.colors) s.has_vertex_colors = true;
         o.num_vertices = in.num_vertices; o.num_uv_vertices = in.num_uv_vertices;
         o.num_normal_vertices = in.num_normal_vertices; o.num_triangles = in.num_triangles;
         o.material_id = in.material_id; o.light_id = in.light_id;

@@ -23,6 +23,7 @@ struct Scene {
     bool use_primary_edges = false, use_secondary_edges = false;
     int max_generic_texture_dimension = 0;
     bool has_textures = false;     // some reflectance / roughness is an image, or a normal map is present
+    bool has_vertex_colors = false;
     bool has_mipmaps = false;
     EnvmapD h_envmap;              // valid when d.envmap != nullptr      // some texture has > 1 level, i.e. ray differentials influence results
 

@@ -25,6 +25,7 @@ struct AdjState {      // SoA, stride n, indexed by lane id
     double *ray_dir;   // 3 x n   (adjoint of the incoming ray's direction; the origin's is always 0)
     double *point;     // 24 x n  (non-zero part of the shading point adjoint)
     int n;
+    int plain;         // lean stages: uv / uv-derivative / colour adjoints are identically zero and not kept
 };
 
 RDR_FN Surf load_adj_point(const AdjState &a, int p) {
@@ -32,6 +33,7 @@ RDR_FN Surf load_adj_point(const AdjState &a, int p) {
     s.position = ld3(a.point, a.n, p, 0);
     s.frame.x = ld3(a.point, a.n, p, 3); s.frame.y = ld3(a.point, a.n, p, 6); s.frame.n = ld3(a.point, a.n, p, 9);
     s.dpdu = ld3(a.point, a.n, p, 12);
+    if (a.plain) return s;
     s.uv = v2(a.point[(size_t)15 * a.n + p], a.point[(size_t)16 * a.n + p]);
     s.du_dxy = v2(a.point[(size_t)17 * a.n + p], a.point[(size_t)18 * a.n + p]);
     s.dv_dxy = v2(a.point[(size_t)19 * a.n + p], a.point[(size_t)20 * a.n + p]);
@@ -42,6 +44,7 @@ RDR_FN void store_adj_point(const AdjState &a, int p, const Surf &s) {
     st3(a.point, a.n, p, 0, s.position);
     st3(a.point, a.n, p, 3, s.frame.x); st3(a.point, a.n, p, 6, s.frame.y); st3(a.point, a.n, p, 9, s.frame.n);
     st3(a.point, a.n, p, 12, s.dpdu);
+    if (a.plain) return;
     a.point[(size_t)15 * a.n + p] = s.uv.x; a.point[(size_t)16 * a.n + p] = s.uv.y;
     a.point[(size_t)17 * a.n + p] = s.du_dxy.x; a.point[(size_t)18 * a.n + p] = s.du_dxy.y;
     a.point[(size_t)19 * a.n + p] = s.dv_dxy.x; a.point[(size_t)20 * a.n + p] = s.dv_dxy.y;
@@ -69,7 +72,7 @@ struct AdjBounceArgs {
 
 struct AdjBounceScatter {
     AdjBounceArgs a;
-    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; }
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; a.adj.plain = 1; }
     RDR_FN void operator()(int idx) const {
         const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v, &vn = a.vn; const AdjState &adj = a.adj;
         int p = a.active[idx];
@@ -128,13 +131,13 @@ struct AdjBounceScatter {
                 RayDiff rd_bar = raydiff_zero();
                 TriGrad tg = trigrad_zero();
                 Ray br = make_ray(pos, wo);
-                adj_surf_at(bsh, btri, br, wo_rd, bp_bar, raydiff_zero(), r_bar, rd_bar, tg, !sc.no_diffs);
+                adj_surf_at(bsh, btri, br, wo_rd, bp_bar, raydiff_zero(), r_bar, rd_bar, tg, !sc.no_diffs, sc.plain_materials != 0);
                 if (c.mrough > 0.01f) {
                     sp_bar.position -= dir_bar;
                     sp_bar.position += r_bar.org;
                 }
                 in_dir_bar -= wi_bar;
-                scatter_trigrad(bsh, g.shapes[bshape], btri, tg);
+                scatter_trigrad(bsh, g.shapes[bshape], btri, tg, sc.plain_materials != 0);
             }
         } else if (sc.envmap != nullptr) {
             // the BSDF ray reached the environment light (src/path_contribution.cpp:520-600); MIS weight and
@@ -178,7 +181,7 @@ RDR_FN void adj_record_add(const AdjState &adj, int p, V3 thr_bar, V3 in_dir_bar
 
 struct AdjBounceNee {
     AdjBounceArgs a;
-    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; }
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; a.adj.plain = 1; }
     // next-event estimation towards the environment light (src/path_contribution.cpp:295-338)
     RDR_FN void envmap_nee(int p, const LightDraw &ld) const {
         const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v;
@@ -322,7 +325,7 @@ struct AdjPrimary {
     SceneD sc; GScene g; SamplerD rng; int sample_center;
     VSlice v0; const float *d_image; int nd, radiance_dim; double weight;
     AdjState adj; float *screen_grad; ChannelsD ch;
-    RDR_FN void make_lean() { lean_scene(sc); lean_slice(v0); lean_channels(ch); nd = 3; radiance_dim = 0; }
+    RDR_FN void make_lean() { lean_scene(sc); lean_slice(v0); lean_channels(ch); nd = 3; radiance_dim = 0; adj.plain = 1; }
     RDR_FN void operator()(int p) const {
         int shape = v0.shape[p];
         Ray ray = load_ray(v0, p);
@@ -365,8 +368,8 @@ struct AdjPrimary {
                 adj_first_hit_channels(sc, g, ch, d_image, weight, p, shape, sp, ray, pt_bar, r_bar.org);
             }
             TriGrad tg = trigrad_zero();
-            adj_surf_at(sc.shapes[shape], v0.tri[p], ray, rd, pt_bar, raydiff_zero(), r_bar, prd_bar, tg, !sc.no_diffs);
-            scatter_trigrad(sc.shapes[shape], g.shapes[shape], v0.tri[p], tg);
+            adj_surf_at(sc.shapes[shape], v0.tri[p], ray, rd, pt_bar, raydiff_zero(), r_bar, prd_bar, tg, !sc.no_diffs, sc.plain_materials != 0);
+            scatter_trigrad(sc.shapes[shape], g.shapes[shape], v0.tri[p], tg, sc.plain_materials != 0);
         }
         V2 s = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
         V2 screen = pixel_to_screen(sc.cam, p, s);

@@ -291,7 +291,8 @@ RDR_FN TriGrad trigrad_zero() {
 
 RDR_FN void adj_surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff &rd,
                         const Surf &sp_bar, const RayDiff &new_rd_bar,
-                        DRay &ray_bar, RayDiff &rd_bar, TriGrad &g, bool diffs = true) {
+                        DRay &ray_bar, RayDiff &rd_bar, TriGrad &g, bool diffs = true, bool plain = false) {
+    // plain: no texture coordinate or vertex colour can carry an adjoint (constant materials, no vertex colours)
     RDR_CONTRACT_FAST
     TriVerts tv = load_tri(sh, tri);
     TriAttr at = load_attr(sh, tri, tv);
@@ -335,7 +336,7 @@ RDR_FN void adj_surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff
 
     // ---- reverse sweep ----
     double u_bar = sp_bar.bary.x, v_bar = sp_bar.bary.y, w_bar = 0;
-    if (sh.colors) {
+    if (!plain && sh.colors) {
         V3 c0 = v3f(sh.colors + 3 * tv.i0), c1 = v3f(sh.colors + 3 * tv.i1), c2 = v3f(sh.colors + 3 * tv.i2);
         g.c[0] += sp_bar.color * w; g.c[1] += sp_bar.color * u; g.c[2] += sp_bar.color * v;
         w_bar += sum(sp_bar.color * c0); u_bar += sum(sp_bar.color * c1); v_bar += sum(sp_bar.color * c2);
@@ -445,20 +446,22 @@ RDR_FN void adj_surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff
     ray_bar.org += pos_bar;
     ray_bar.dir += pos_bar * t;
     t_bar += sum(pos_bar * ray.dir);
-    V2 uv_bar = sp_bar.uv;
-    w_bar += sum(uv_bar * at.uv0); u_bar += sum(uv_bar * at.uv1); v_bar += sum(uv_bar * at.uv2);
-    uv0_bar += uv_bar * w; uv1_bar += uv_bar * u; uv2_bar += uv_bar * v;
+    if (!plain) {
+        V2 uv_bar = sp_bar.uv;
+        w_bar += sum(uv_bar * at.uv0); u_bar += sum(uv_bar * at.uv1); v_bar += sum(uv_bar * at.uv2);
+        uv0_bar += uv_bar * w; uv1_bar += uv_bar * u; uv2_bar += uv_bar * v;
+    }
     u_bar -= w_bar; v_bar -= w_bar;
     if (diffs) adj_tri_hit(tv.p0, tv.p1, tv.p2, ray, rd, v3(u_bar, v_bar, t_bar), udxy_bar, vdxy_bar, tdxy_bar,
                            p0_bar, p1_bar, p2_bar, ray_bar, rd_bar);
     else adj_tri_hit_nodiff(tv.p0, tv.p1, tv.p2, ray, v3(u_bar, v_bar, t_bar), p0_bar, p1_bar, p2_bar, ray_bar);
-    if (sh.uvs) { g.uv[0] += uv0_bar; g.uv[1] += uv1_bar; g.uv[2] += uv2_bar; }
+    if (!plain && sh.uvs) { g.uv[0] += uv0_bar; g.uv[1] += uv1_bar; g.uv[2] += uv2_bar; }
     g.p[0] += p0_bar; g.p[1] += p1_bar; g.p[2] += p2_bar;
 }
 
 // Scatter a TriGrad into the fp64 accumulators of shape `sid` (same targets as the reference's
 // atomic_add calls, e.g. src/path_contribution.cpp:477-520).
-RDR_FN void scatter_trigrad(const ShapeD &sh, const GShape &gs, int tri, const TriGrad &g) {
+RDR_FN void scatter_trigrad(const ShapeD &sh, const GShape &gs, int tri, const TriGrad &g, bool plain = false) {
     TriVerts tv = load_tri(sh, tri);
     TriAttr at = load_attr(sh, tri, tv);
     int vi[3] = {tv.i0, tv.i1, tv.i2};
@@ -467,9 +470,9 @@ RDR_FN void scatter_trigrad(const ShapeD &sh, const GShape &gs, int tri, const T
 #pragma unroll
     for (int k = 0; k < 3; ++k) {       // must unroll: dynamic indexing would push the TriGrad into scratch
         accum3(gs.vertices + 3 * vi[k], g.p[k]);
-        if (sh.uvs && gs.uvs) { accum(gs.uvs + 2 * ui[k], g.uv[k].x); accum(gs.uvs + 2 * ui[k] + 1, g.uv[k].y); }
+        if (!plain && sh.uvs && gs.uvs) { accum(gs.uvs + 2 * ui[k], g.uv[k].x); accum(gs.uvs + 2 * ui[k] + 1, g.uv[k].y); }
         if (sh.normals && gs.normals) accum3(gs.normals + 3 * ni[k], g.n[k]);
-        if (sh.colors && gs.colors) accum3(gs.colors + 3 * vi[k], g.c[k]);
+        if (!plain && sh.colors && gs.colors) accum3(gs.colors + 3 * vi[k], g.c[k]);
     }
 }
 
