@@ -4,6 +4,7 @@
 #include "bvh.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <stdexcept>
 
@@ -27,7 +28,9 @@ struct Box {
 struct Builder {
     std::vector<Prim> prims;
     BvhHost out;
-    static constexpr int kBins = 16, kLeafMax = 4;
+    static constexpr int kMaxBins = 64, kLeafMax = 4;
+    int kBins = 64;            // tuning knobs (RDR_BVH_BINS / RDR_BVH_TCOST); defaults from a sweep on bunny_box (profiles/r1_notes.md)
+    float kTravCost = 0.3f;
 
     void set_bounds(int node, const Box &b) {
         Node &n = out.nodes[node];
@@ -57,13 +60,13 @@ struct Builder {
             for (int axis = 0; axis < 3; ++axis) {
                 float ext = cb.hi[axis] - cb.lo[axis];
                 if (!(ext > 0)) continue;
-                Box bins[kBins]; int cnt[kBins] = {0};
+                Box bins[kMaxBins]; int cnt[kMaxBins] = {0};
                 float scale = kBins / ext;
                 for (int i = first; i < first + count; ++i) {
                     int bi = std::min(kBins - 1, std::max(0, (int)((prims[i].c[axis] - cb.lo[axis]) * scale)));
                     bins[bi].grow(prims[i].lo, prims[i].hi); cnt[bi]++;
                 }
-                float ra[kBins]; int rc[kBins];
+                float ra[kMaxBins]; int rc[kMaxBins];
                 Box acc; int c = 0;
                 for (int k = kBins - 1; k > 0; --k) { acc.grow(bins[k].lo, bins[k].hi); c += cnt[k]; ra[k] = acc.half_area(); rc[k] = c; }
                 Box l; int lc = 0;
@@ -76,7 +79,7 @@ struct Builder {
             }
         }
         float leaf_cost = b.half_area() * count;
-        bool split = best_axis >= 0 && (count > kLeafMax || best_cost + 1.0f * b.half_area() < leaf_cost);
+        bool split = best_axis >= 0 && (count > kLeafMax || best_cost + kTravCost * b.half_area() < leaf_cost);
         int mid = first + count / 2;
         if (split) {
             float ext = cb.hi[best_axis] - cb.lo[best_axis];
@@ -108,6 +111,8 @@ struct Builder {
 
 BvhHost build_bvh(const std::vector<MeshView> &meshes) {
     Builder bd;
+    if (const char *e = std::getenv("RDR_BVH_BINS")) bd.kBins = std::min(64, std::max(2, std::atoi(e)));
+    if (const char *e = std::getenv("RDR_BVH_TCOST")) bd.kTravCost = (float)std::atof(e);
     for (size_t s = 0; s < meshes.size(); ++s) {
         const MeshView &m = meshes[s];
         for (int t = 0; t < m.num_triangles; ++t) {

@@ -25,8 +25,19 @@
 #define RDR_DEV_FN __device__ inline
 #define RDR_STACK_DECL(T, name, N) __shared__ T name##_lds[(N) * 256]; T *name = name##_lds + threadIdx.x
 #define RDR_STACK_AT(name, k) name[(k) * 256]
+// Stack of a resumable walk (persistent kernels): an LDS column on the GPU, a member of the walk state on the host.
+#define RDR_WALK_STACK_MEMBER(T, name, N)
+#define RDR_WALK_STACK(st, T, name, N, TAG) (rdr::lds_column<T, N, TAG>())
+#define RDR_WALK_AT(stk, k) stk[(k) * 256]
 
 namespace rdr {
+template <class T, int N, int TAG>
+__device__ inline T *lds_column() {
+    __shared__ T tile[N * 256];
+    return tile + threadIdx.x;
+}
+__host__ inline void *lds_column_host_stub() { return nullptr; }
+
 // Gradient scatter.  Many lanes of a wave usually add to the SAME address (all pixels of a wall
 // hit the same 4 vertices / the same constant albedo; every pixel adds to the camera), which would
 // serialise 64 fp64 atomics on one L2 line.  So: if every active lane of the wave targets one
@@ -113,6 +124,52 @@ __global__ void __launch_bounds__(256) stage_kernel(F f, int n) {
     // a stage body that is instantiated twice (plain + LeanStage) must still be inlined into each kernel:
     // an out-of-line call would pass the whole functor through scratch
     if (i < n) { RDR_INLINE_CALL f(i); }
+}
+
+// Persistent waves with lane refill, for walks whose length varies wildly from lane to lane (the NEE-mode edge pick:
+// median 20 steps, 95th percentile 640 -- a one-item-per-lane kernel keeps 25 % of the SIMD busy).  W provides
+//   State; bool begin(int item, State&)   set up the walk; false = nothing to walk (finish is still called)
+//          bool step(State&)              one step; true when the walk is complete
+//          void finish(State&)            write the result
+// A wave keeps running: whenever >= kRefillIdle lanes are idle they take the next items off a global counter
+// (one atomic per refill), then every busy lane advances kWalkSteps steps.
+constexpr int kRefillIdle = 16;
+constexpr int kWalkSteps = 16;
+template <class W>
+__global__ void __launch_bounds__(256) persistent_kernel(W w, int n, int *next_item) {
+    typename W::State st;
+    bool busy = false;
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        const unsigned long long idle = __ballot(!busy);
+        const int nidle = __popcll(idle);
+        if (nidle >= kRefillIdle) {
+            const int leader = __ffsll((long long)idle) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(next_item, nidle);
+            base = __shfl(base, leader);
+            if (!busy) {
+                const int item = base + __popcll(idle & ((1ull << lane) - 1ull));
+                if (item < n) {
+                    if (w.begin(item, st)) busy = true;
+                    else w.finish(st);
+                }
+            }
+            if (__ballot(busy) == 0ull && base + nidle >= n) break;
+        }
+#pragma unroll 1
+        for (int it = 0; it < kWalkSteps; ++it) {
+            if (busy && w.step(st)) { w.finish(st); busy = false; }
+        }
+    }
+}
+int *persistent_counter();          // trace.hip: ring of zeroed ints, one per launch
+template <class W>
+inline void launch_persistent(int n, const W &w) {
+    if (n <= 0) return;
+    int blocks = std::min((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(persistent_kernel<W>, dim3(blocks), dim3(256), 0, ctx().stream, w, n, persistent_counter());
+    check(hipGetLastError(), "persistent launch");
 }
 
 template <class F>

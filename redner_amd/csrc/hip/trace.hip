@@ -73,6 +73,17 @@ __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayR
     hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};
 }
 
+int *persistent_counter() {
+    static int *ring = nullptr;
+    static int slot = 0;
+    constexpr int kRing = 4096;
+    if (!ring) ring = (int *)dmalloc(sizeof(int) * kRing);
+    if (slot == 0) zero(ring, sizeof(int) * kRing);        // stream-ordered: re-zeroed once per lap
+    int *p = ring + slot;
+    slot = (slot + 1) % kRing;
+    return p;
+}
+
 namespace {
 struct Pending { hipEvent_t a, b; bool any; };
 std::vector<Pending> g_pending;

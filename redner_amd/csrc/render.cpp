@@ -302,6 +302,17 @@ struct Backward {
     }
     SamplerD edge_rng_at(const SamplerD &rng_edge, int edim) const { SamplerD r = rng_edge; r.pcg_base = edim; return r; }
 
+    template <bool LEAN> void launch_pick_n(int need, int nN, const SecEdgeArgs &sa) {
+        auto go = [&](auto walk) {
+            if (LEAN) exec::launch_persistent(nN, LeanWalk<decltype(walk)>{walk});
+            else exec::launch_persistent(nN, walk);
+        };
+        if (need <= 24) go(SecEdgePickNWalk<24>{sa, elist[0], sec_picks});
+        else if (need <= 32) go(SecEdgePickNWalk<32>{sa, elist[0], sec_picks});
+        else if (need <= 48) go(SecEdgePickNWalk<48>{sa, elist[0], sec_picks});
+        else go(SecEdgePickNWalk<64>{sa, elist[0], sec_picks});
+    }
+
     int trace_edge_paths(const SamplerD &rng_edge, int edim, int n_act, int n_slots, int first_depth, const Queues &q,
                          const Sink &sink, bool need_lights) {
         int used = 0;
@@ -348,10 +359,9 @@ struct Backward {
                 launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
                 int nN = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 2});
                 const int need = es.max_stack;
-                if (need <= 24) launch_v(lean, nN, SecEdgePickN<24>{sa, elist[0], sec_picks});
-                else if (need <= 32) launch_v(lean, nN, SecEdgePickN<32>{sa, elist[0], sec_picks});
-                else if (need <= 48) launch_v(lean, nN, SecEdgePickN<48>{sa, elist[0], sec_picks});
-                else launch_v(lean, nN, SecEdgePickN<64>{sa, elist[0], sec_picks});
+                // NEE-mode pick: persistent waves (walk lengths: median 20, p95 640 steps)
+                if (lean) launch_pick_n<true>(need, nN, sa);
+                else launch_pick_n<false>(need, nN, sa);
                 if (nH == 0 && nN == 0) {
                     // no slot samples an edge here (typically: every path already passed a diffuse vertex,
                     // src/edge.cpp:1396-1401); only the sampler bookkeeping of the skipped stages remains

@@ -463,6 +463,38 @@ RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, co
 #undef RDR_H_PUSH
 }
 
+// Tail of the NEE-mode pick: pmf of the selected edge, Jacobian of the NEE-ray / billboard intersection, point on the edge.
+RDR_FN int finish_edge_nee(const SceneD &sc, const EdgeSceneD &es, const Ray &nee, bool nee_valid, const Surf &nee_pt, int nee_shape,
+                           int selected, double edge_w, double wsum, double &weight, V3 &edge_pt, V3 &mwt) {
+    double pmf = edge_w / wsum;
+    const EdgeD &e = es.edges[selected];
+    V3 a = edge_v0(sc.shapes, e), b = edge_v1(sc.shapes, e);
+    V3 pn = nee.dir;
+    double t = -(dot(nee.org, pn) - dot(a, pn)) / dot(nee.dir, pn);
+    if (t < nee.tmin || t > nee.tmax) return -1;
+    V3 ip = nee.org + nee.dir * t;
+    double jac = 0, pdf_nee = 0;
+    if (nee_valid) {
+        V3 ln = nee_pt.geom_normal, lpos = nee_pt.position;
+        double tau = dot(lpos - nee.org, ln) / dot(ip - nee.org, ln);
+        V3 omega = ip - nee.org;
+        jac = len(tau * ((b - a) - omega * (dot(b - a, ln) / dot(omega, ln))));
+        const ShapeD &lsh = sc.shapes[nee_shape];
+        pdf_nee = sc.light_pmf[lsh.light_id] / sc.light_areas[lsh.light_id];
+    } else {
+        // environment light (:1349-1353)
+        jac = 1 / len_sq(ip - nee.org);
+        pdf_nee = envmap_pdf(*sc.envmap, nee.dir);
+    }
+    if (pmf <= 0 || jac <= 0 || pdf_nee <= 0) return -1;
+    weight = 1 / (2 * es.edge_bounds_expand * pmf * jac * pdf_nee);
+    V3 ap = a - ip;
+    V3 ab = normalize(b - a);
+    edge_pt = ip + ap - (dot(ap, ab)) * ab - nee.org;
+    mwt = b - a;
+    return selected;
+}
+
 // NEE-billboard pick: gather every edge whose billboard the NEE ray crosses, keep one.
 template <int NS>
 RDR_DEV_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c, const Ray &nee, bool nee_valid,
@@ -499,33 +531,7 @@ RDR_DEV_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCt
         }
     }
     if (selected == -1) return -1;
-    double pmf = edge_w / wsum;
-    const EdgeD &e = es.edges[selected];
-    V3 a = edge_v0(sc.shapes, e), b = edge_v1(sc.shapes, e);
-    V3 pn = nee.dir;
-    double t = -(dot(nee.org, pn) - dot(a, pn)) / dot(nee.dir, pn);
-    if (t < nee.tmin || t > nee.tmax) return -1;
-    V3 ip = nee.org + nee.dir * t;
-    double jac = 0, pdf_nee = 0;
-    if (nee_valid) {
-        V3 ln = nee_pt.geom_normal, lpos = nee_pt.position;
-        double tau = dot(lpos - nee.org, ln) / dot(ip - nee.org, ln);
-        V3 omega = ip - nee.org;
-        jac = len(tau * ((b - a) - omega * (dot(b - a, ln) / dot(omega, ln))));
-        const ShapeD &lsh = sc.shapes[nee_shape];
-        pdf_nee = sc.light_pmf[lsh.light_id] / sc.light_areas[lsh.light_id];
-    } else {
-        // environment light (:1349-1353)
-        jac = 1 / len_sq(ip - nee.org);
-        pdf_nee = envmap_pdf(*sc.envmap, nee.dir);
-    }
-    if (pmf <= 0 || jac <= 0 || pdf_nee <= 0) return -1;
-    weight = 1 / (2 * es.edge_bounds_expand * pmf * jac * pdf_nee);
-    V3 ap = a - ip;
-    V3 ab = normalize(b - a);
-    edge_pt = ip + ap - (dot(ap, ab)) * ab - nee.org;
-    mwt = b - a;
-    return selected;
+    return finish_edge_nee(sc, es, nee, nee_valid, nee_pt, nee_shape, selected, edge_w, wsum, weight, edge_pt, mwt);
 }
 
 RDR_FN M3 ltc_matrix(const float *tab, const Surf &sp, V3 wi, double roughness) {
@@ -662,6 +668,72 @@ struct SecEdgePickH {
         picks[idx] = SecPick{eid, ew, v3(0), v3(0)};
     }
 };
+// The NEE-mode pick as a resumable walk for exec::launch_persistent: same tests in the same order as
+// pick_edge_nee<>, one popped reference per step.
+template <int NS> struct SecEdgePickNWalk {
+    SecEdgeArgs a; const int *slots; SecPick *picks;
+    struct State {
+        int idx, sp, selected;
+        double edge_w, wsum, resample;
+        LtcCtx c;
+        Ray nee; bool nee_valid; V3 nee_pos;
+        RDR_WALK_STACK_MEMBER(int, stack, NS)
+    };
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_DEV_FN bool begin(int i, State &st) const {
+        st.idx = slots[i];
+        SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[st.idx], st.idx);
+        st.sp = 0; st.selected = -1; st.edge_w = 0; st.wsum = 0; st.resample = s.resample_sel;
+        st.c = s.lc; st.nee = s.nee; st.nee_valid = s.nee_valid; st.nee_pos = s.nee_pt.position;
+        auto stack = RDR_WALK_STACK(st, int, stack, NS, 1);
+        if (a.es.cs_root != kNoEdgeTree) { RDR_WALK_AT(stack, st.sp) = a.es.cs_root; st.sp++; }
+        if (a.es.ncs_root != kNoEdgeTree) { RDR_WALK_AT(stack, st.sp) = a.es.ncs_root; st.sp++; }
+        return st.sp > 0;
+    }
+    RDR_DEV_FN bool step(State &st) const {
+        const SceneD &sc = a.sc; const EdgeSceneD &es = a.es;
+        auto stack = RDR_WALK_STACK(st, int, stack, NS, 1);
+        --st.sp;
+        int ref = RDR_WALK_AT(stack, st.sp);
+        if (ref < 0) {
+            const int leaf_edge = ~ref;
+            double w = leaf_importance_l(sc, es, leaf_edge, st.c, st.nee, st.nee_valid);
+            if (w > 0) {
+                double prev = st.wsum;
+                st.wsum += w;
+                double nw = w / st.wsum;
+                if (st.resample <= nw || prev == 0) { st.selected = leaf_edge; st.edge_w = w; st.resample /= nw; }
+                else st.resample = (st.resample - nw) / (1 - nw);
+            }
+        } else {
+            const EdgeNodeP &nd = edge_node(es, ref);
+            const int tree = ref & kEdgeTreeBit;
+            const bool tree3d = tree == 0;
+            for (int k = 0; k < 2; ++k) {
+                bool ok = may_hold_silhouette(es, tree3d, nd.c_dx_min[k], nd.c_dx_max[k], st.c.pos);
+                if (ok && st.nee_valid) ok = may_hold_silhouette(es, tree3d, nd.c_dx_min[k], nd.c_dx_max[k], st.nee_pos);
+                if (ok) ok = ray_box_expand(v3_of(nd.c_pmin[k]), v3_of(nd.c_pmax[k]), st.nee, es.edge_bounds_expand);
+                if (ok && st.sp < NS) { RDR_WALK_AT(stack, st.sp) = nd.c_ref[k] < 0 ? nd.c_ref[k] : (nd.c_ref[k] | tree); st.sp++; }
+            }
+        }
+        return st.sp == 0;
+    }
+    // weight, point on the edge and edge vector of the selected edge (the tail of pick_edge_nee); the NEE segment
+    // is rebuilt from the slot rather than carried through the walk
+    RDR_DEV_FN void finish(State &st) const {
+        const SceneD &sc = a.sc; const EdgeSceneD &es = a.es;
+        SecPick out{-1, 0.0, v3(0), v3(0)};
+        if (st.selected != -1) {
+            SecPre s = sec_prepare(sc, es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[st.idx], st.idx);
+            double ew = 0;
+            V3 sample_p = v3(0), mwt = v3(0);
+            int eid = finish_edge_nee(sc, es, s.nee, s.nee_valid, s.nee_pt, s.nee_shape, st.selected, st.edge_w, st.wsum, ew, sample_p, mwt);
+            out = SecPick{eid, ew, sample_p, mwt};
+        }
+        picks[st.idx] = out;
+    }
+};
+
 template <int NS> struct SecEdgePickN {
     SecEdgeArgs a; const int *slots; SecPick *picks;
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }

@@ -108,6 +108,14 @@ template <class Stage> struct LeanStage {
     Stage f;
     RDR_FN void operator()(int i) const { Stage g = f; g.make_lean(); RDR_INLINE_CALL g(i); }
 };
+// The same for resumable walks (exec::launch_persistent).
+template <class Walk> struct LeanWalk {
+    Walk w;
+    using State = typename Walk::State;
+    RDR_DEV_FN bool begin(int i, State &st) const { Walk g = w; g.make_lean(); return g.begin(i, st); }
+    RDR_DEV_FN bool step(State &st) const { Walk g = w; g.make_lean(); return g.step(st); }
+    RDR_DEV_FN void finish(State &st) const { Walk g = w; g.make_lean(); g.finish(st); }
+};
 
 struct LightDraw { double light_sel, tri_sel; V2 uv; };
 RDR_FN LightDraw draw_light(const SamplerD &rng, int slot, int dim) {

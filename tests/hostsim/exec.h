@@ -17,6 +17,9 @@
 #define RDR_DEV_FN inline
 #define RDR_STACK_DECL(T, name, N) T name[N]
 #define RDR_STACK_AT(name, k) name[k]
+#define RDR_WALK_STACK_MEMBER(T, name, N) T name[N];
+#define RDR_WALK_STACK(st, T, name, N, TAG) ((st).name)
+#define RDR_WALK_AT(stk, k) stk[k]
 #define RDR_HOSTSIM 1
 
 namespace rdr {
@@ -32,6 +35,14 @@ inline void download(void *dst, const void *src, size_t bytes) { memcpy(dst, src
 inline void sync() {}
 template <class F>
 inline void launch(int n, const F &f) { for (int i = 0; i < n; ++i) f(i); }
+template <class W>
+inline void launch_persistent(int n, const W &w) {          // see hip/exec.h: begin / step... / finish per item
+    for (int i = 0; i < n; ++i) {
+        typename W::State st;
+        if (w.begin(i, st)) { while (!w.step(st)) {} }
+        w.finish(st);
+    }
+}
 } // namespace exec
 
 // ---- host stand-ins for the hand-written kernels (compact.hip / trace.hip) ----------------------
