@@ -286,6 +286,18 @@ RDR_FN double ltc_bound(V3 lo, V3 hi, const LtcCtx &c) {
 }
 // Sphere/box overlap (Arvo), early-out form of src/aabb.h:158-174.
 // Only the x axis can decide (see EdgeNodeC): the first partial sum is the smallest one.
+// Silhouette query of one point p against Hough intervals: centre x and squared radius of the sphere
+// (0.5 (p - cam), 0.5 |cam - p|), computed once per walk instead of at every node.
+struct SilQuery { double cx, r2; };
+RDR_FN SilQuery sil_query(const EdgeSceneD &es, V3 p) {
+    return SilQuery{(0.5f * (p - es.cam_org)).x, sq(0.5f * len(es.cam_org - p))};
+}
+RDR_FN bool sphere_box_x(const SilQuery &q, double lo_x, double hi_x) {
+    double dmin_ = 0;
+    if (q.cx < lo_x) dmin_ += sq(q.cx - lo_x);
+    else if (q.cx > hi_x) dmin_ += sq(q.cx - hi_x);
+    return dmin_ <= q.r2;
+}
 RDR_FN bool sphere_box_x(double cx, double radius, double lo_x, double hi_x) {
     double dmin_ = 0, r2 = sq(radius);
     if (cx < lo_x) dmin_ += sq(cx - lo_x);
@@ -294,14 +306,14 @@ RDR_FN bool sphere_box_x(double cx, double radius, double lo_x, double hi_x) {
 }
 // Can the subtree with Hough x-interval [dx_min, dx_max] hold an edge that is a silhouette seen from p?
 // (3-D tree: always; src/edge.cpp contains_silhouette)
-RDR_FN bool may_hold_silhouette(const EdgeSceneD &es, bool tree3d, double dx_min, double dx_max, V3 p) {
+RDR_FN bool may_hold_silhouette(bool tree3d, double dx_min, double dx_max, const SilQuery &q) {
     if (tree3d) return true;
-    return sphere_box_x((0.5f * (p - es.cam_org)).x, 0.5f * len(es.cam_org - p), dx_min, dx_max);
+    return sphere_box_x(q, dx_min, dx_max);
 }
 // Importance of child k of `nd` (src/edge.cpp:885-928).
-RDR_FN double node_importance(const EdgeSceneD &es, const EdgeNodeP &nd, int k, bool tree3d, const LtcCtx &c) {
+RDR_FN double node_importance(const EdgeNodeP &nd, int k, bool tree3d, const LtcCtx &c, const SilQuery &q) {
     if (!tree3d) {
-        if (!sphere_box_x((0.5f * (c.pos - es.cam_org)).x, 0.5f * len(es.cam_org - c.pos), nd.c_dx_min[k], nd.c_dx_max[k])) return 0;
+        if (!sphere_box_x(q, nd.c_dx_min[k], nd.c_dx_max[k])) return 0;
     }
     V3 lo = v3_of(nd.c_pmin[k]), hi = v3_of(nd.c_pmax[k]);
     double brdf = ltc_bound(lo, hi, c);
@@ -367,10 +379,11 @@ RDR_FN double leaf_importance_l(const SceneD &sc, const EdgeSceneD &es, int eid,
 }
 
 // Slab test of the reference's edge-tree traversal (src/aabb.h:176-200), boxes grown by `expand`.
-RDR_FN bool ray_box_expand(V3 lo, V3 hi, const Ray &r, double expand) {
+// `inv_dir` = 1 / r.dir per axis, computed once per walk (the reference divides at every node; same values).
+RDR_FN bool ray_box_expand(V3 lo, V3 hi, const Ray &r, V3 inv_dir, double expand) {
     double t0 = r.tmin, t1 = r.tmax;
     for (int i = 0; i < 3; ++i) {
-        double inv = 1 / comp(r.dir, i);
+        double inv = comp(inv_dir, i);
         double tn = (comp(lo, i) - expand - comp(r.org, i)) * inv;
         double tf = (comp(hi, i) + expand - comp(r.org, i)) * inv;
         if (tn > tf) { double t = tn; tn = tf; tf = t; }
@@ -396,6 +409,7 @@ struct HItem { int ref, num; double pmf; };
 // and keeping one leaf by reservoir sampling.  Returns the edge id or -1; weight = 1/pmf.
 RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c,
                                       double sample, double resample, double &weight) {
+    const SilQuery q_pos = sil_query(es, c.pos);
     RDR_STACK_DECL(int, st_ref, kHStack);
     RDR_STACK_DECL(unsigned char, st_num, kHStack);
     RDR_STACK_DECL(double, st_pmf, kHStack);
@@ -441,7 +455,7 @@ RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, co
             int c1 = nd.c_ref[1] < 0 ? nd.c_ref[1] : (nd.c_ref[1] | tree);
             double i0, i1;
             if (box_contains(v3_of(nd.p_min), v3_of(nd.p_max), c.pos)) { i0 = i1 = 1; }
-            else { i0 = node_importance(es, nd, 0, tree3d, c); i1 = node_importance(es, nd, 1, tree3d, c); }
+            else { i0 = node_importance(nd, 0, tree3d, c, q_pos); i1 = node_importance(nd, 1, tree3d, c, q_pos); }
             if (i0 > 0 || i1 > 0) {
                 double p0 = i0 / (i0 + i1), p1 = 1 - p0;
                 double e0 = it.num * p0, e1 = it.num * p1;
@@ -495,44 +509,6 @@ RDR_FN int finish_edge_nee(const SceneD &sc, const EdgeSceneD &es, const Ray &ne
     return selected;
 }
 
-// NEE-billboard pick: gather every edge whose billboard the NEE ray crosses, keep one.
-template <int NS>
-RDR_DEV_FN int pick_edge_nee(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c, const Ray &nee, bool nee_valid,
-                             const Surf &nee_pt, int nee_shape, double resample, double &weight, V3 &edge_pt, V3 &mwt) {
-    RDR_STACK_DECL(int, stack, NS);
-    int sp = 0;
-    int selected = -1;
-    double edge_w = 0, wsum = 0;
-    if (es.cs_root != kNoEdgeTree) { RDR_STACK_AT(stack, sp) = es.cs_root; sp++; }
-    if (es.ncs_root != kNoEdgeTree) { RDR_STACK_AT(stack, sp) = es.ncs_root; sp++; }
-    while (sp > 0) {
-        --sp;
-        int ref = RDR_STACK_AT(stack, sp);
-        if (ref < 0) {
-            const int leaf_edge = ~ref;
-            double w = leaf_importance_l(sc, es, leaf_edge, c, nee, nee_valid);
-            if (w > 0) {
-                double prev = wsum;
-                wsum += w;
-                double nw = w / wsum;
-                if (resample <= nw || prev == 0) { selected = leaf_edge; edge_w = w; resample /= nw; }
-                else resample = (resample - nw) / (1 - nw);
-            }
-        } else {
-            const EdgeNodeP &nd = edge_node(es, ref);
-            const int tree = ref & kEdgeTreeBit;
-            const bool tree3d = tree == 0;
-            for (int k = 0; k < 2; ++k) {
-                bool ok = may_hold_silhouette(es, tree3d, nd.c_dx_min[k], nd.c_dx_max[k], c.pos);
-                if (ok && nee_valid) ok = may_hold_silhouette(es, tree3d, nd.c_dx_min[k], nd.c_dx_max[k], nee_pt.position);
-                if (ok) ok = ray_box_expand(v3_of(nd.c_pmin[k]), v3_of(nd.c_pmax[k]), nee, es.edge_bounds_expand);
-                if (ok && sp < NS) { RDR_STACK_AT(stack, sp) = nd.c_ref[k] < 0 ? nd.c_ref[k] : (nd.c_ref[k] | tree); sp++; }
-            }
-        }
-    }
-    if (selected == -1) return -1;
-    return finish_edge_nee(sc, es, nee, nee_valid, nee_pt, nee_shape, selected, edge_w, wsum, weight, edge_pt, mwt);
-}
 
 RDR_FN M3 ltc_matrix(const float *tab, const Surf &sp, V3 wi, double roughness) {
     double ct = dot(wi, sp.frame.n);
@@ -669,14 +645,16 @@ struct SecEdgePickH {
     }
 };
 // The NEE-mode pick as a resumable walk for exec::launch_persistent: same tests in the same order as
-// pick_edge_nee<>, one popped reference per step.
+// the reference's sample_edge_l (src/edge.cpp:1239-1364), one popped reference per step.
 template <int NS> struct SecEdgePickNWalk {
     SecEdgeArgs a; const int *slots; SecPick *picks;
     struct State {
         int idx, sp, selected;
         double edge_w, wsum, resample;
         LtcCtx c;
-        Ray nee; bool nee_valid; V3 nee_pos;
+        Ray nee; bool nee_valid;
+        V3 inv_dir;                 // 1 / nee.dir
+        SilQuery q_pos, q_nee;      // silhouette queries of the shading point and of the light point
         RDR_WALK_STACK_MEMBER(int, stack, NS)
     };
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
@@ -684,7 +662,9 @@ template <int NS> struct SecEdgePickNWalk {
         st.idx = slots[i];
         SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[st.idx], st.idx);
         st.sp = 0; st.selected = -1; st.edge_w = 0; st.wsum = 0; st.resample = s.resample_sel;
-        st.c = s.lc; st.nee = s.nee; st.nee_valid = s.nee_valid; st.nee_pos = s.nee_pt.position;
+        st.c = s.lc; st.nee = s.nee; st.nee_valid = s.nee_valid;
+        st.inv_dir = V3{1 / s.nee.dir.x, 1 / s.nee.dir.y, 1 / s.nee.dir.z};
+        st.q_pos = sil_query(a.es, s.lc.pos); st.q_nee = sil_query(a.es, s.nee_pt.position);
         auto stack = RDR_WALK_STACK(st, int, stack, NS, 1);
         if (a.es.cs_root != kNoEdgeTree) { RDR_WALK_AT(stack, st.sp) = a.es.cs_root; st.sp++; }
         if (a.es.ncs_root != kNoEdgeTree) { RDR_WALK_AT(stack, st.sp) = a.es.ncs_root; st.sp++; }
@@ -710,15 +690,15 @@ template <int NS> struct SecEdgePickNWalk {
             const int tree = ref & kEdgeTreeBit;
             const bool tree3d = tree == 0;
             for (int k = 0; k < 2; ++k) {
-                bool ok = may_hold_silhouette(es, tree3d, nd.c_dx_min[k], nd.c_dx_max[k], st.c.pos);
-                if (ok && st.nee_valid) ok = may_hold_silhouette(es, tree3d, nd.c_dx_min[k], nd.c_dx_max[k], st.nee_pos);
-                if (ok) ok = ray_box_expand(v3_of(nd.c_pmin[k]), v3_of(nd.c_pmax[k]), st.nee, es.edge_bounds_expand);
+                bool ok = may_hold_silhouette(tree3d, nd.c_dx_min[k], nd.c_dx_max[k], st.q_pos);
+                if (ok && st.nee_valid) ok = may_hold_silhouette(tree3d, nd.c_dx_min[k], nd.c_dx_max[k], st.q_nee);
+                if (ok) ok = ray_box_expand(v3_of(nd.c_pmin[k]), v3_of(nd.c_pmax[k]), st.nee, st.inv_dir, es.edge_bounds_expand);
                 if (ok && st.sp < NS) { RDR_WALK_AT(stack, st.sp) = nd.c_ref[k] < 0 ? nd.c_ref[k] : (nd.c_ref[k] | tree); st.sp++; }
             }
         }
         return st.sp == 0;
     }
-    // weight, point on the edge and edge vector of the selected edge (the tail of pick_edge_nee); the NEE segment
+    // weight, point on the edge and edge vector of the selected edge (src/edge.cpp:1319-1363); the NEE segment
     // is rebuilt from the slot rather than carried through the walk
     RDR_DEV_FN void finish(State &st) const {
         const SceneD &sc = a.sc; const EdgeSceneD &es = a.es;
@@ -731,19 +711,6 @@ template <int NS> struct SecEdgePickNWalk {
             out = SecPick{eid, ew, sample_p, mwt};
         }
         picks[st.idx] = out;
-    }
-};
-
-template <int NS> struct SecEdgePickN {
-    SecEdgeArgs a; const int *slots; SecPick *picks;
-    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
-    RDR_FN void operator()(int i) const {
-        int idx = slots[i];
-        SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
-        double ew = 0;
-        V3 sample_p = v3(0), mwt = v3(0);
-        int eid = pick_edge_nee<NS>(a.sc, a.es, s.lc, s.nee, s.nee_valid, s.nee_pt, s.nee_shape, s.resample_sel, ew, sample_p, mwt);
-        picks[idx] = SecPick{eid, ew, sample_p, mwt};
     }
 };
 
