@@ -43,9 +43,10 @@ static_assert(sizeof(RayRec) == 32 && sizeof(HitRec) == 8, "queue record sizes")
 // `stack` holds kTraverseStack ints spaced `stride` apart (a private array on the host, a column of
 // an LDS tile on the GPU); the builder rejects hierarchies deeper than that.
 constexpr int kTraverseStack = 40;
-template <bool ANY>
+// IDX: the stack's element type -- unsigned short when the hierarchy has < 65536 nodes (halves the LDS column).
+template <bool ANY, class IDX = int>
 RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], float tnear, float tfar,
-                          int *stack, int stride, Counters *cnt = nullptr) {
+                          IDX *stack, int stride, Counters *cnt = nullptr) {
     Hit best{tfar, -1, -1};
     if (bvh.num_nodes == 0) return best;
     const float inv[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};
@@ -80,7 +81,7 @@ RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], f
             if (hl && hr) {
                 int near = n.a, far = n.a + 1;
                 if (tr < tl) { near = n.a + 1; far = n.a; }
-                stack[sp * stride] = far; ++sp;
+                stack[sp * stride] = (IDX)far; ++sp;
                 cur = near;
                 continue;
             } else if (hl) { cur = n.a; continue; }
@@ -90,7 +91,7 @@ RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], f
         // children's box tests (lim shrinks), which keeps the stack to one int per entry.
         if (sp == 0) break;
         --sp;
-        cur = stack[sp * stride];
+        cur = (int)stack[sp * stride];
     }
     if (cnt) { cnt->nodes += nn; cnt->tris += nt; }
     return best;

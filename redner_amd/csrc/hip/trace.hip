@@ -49,12 +49,12 @@ CompactScratch &compact_scratch(int nblocks) {
 // STACK: entries of the per-lane LDS stack column.  The kernel waits on node fetches about two thirds of the
 // time (profiles/r1_notes.md), so waves per SIMD matter: 40 entries allow 4, 24 allow 6, 16 allow 8.  The host
 // picks the smallest instantiation that covers the scene's hierarchy depth.
-template <bool ANY, bool COUNT, int STACK>
+template <bool ANY, bool COUNT, int STACK, class IDX>
 __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays,
                                                     rt::HitRec *__restrict__ hits, int n,
                                                     unsigned long long *counters) {
-    __shared__ int stack_tile[STACK * 256];                   // per-lane stack columns
-    int *stack = stack_tile + threadIdx.x;
+    __shared__ IDX stack_tile[STACK * 256];                   // per-lane stack columns (16-bit when the node count allows)
+    IDX *stack = stack_tile + threadIdx.x;
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     rt::RayRec r = rays[i];
@@ -63,11 +63,11 @@ __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayR
         float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
         if (COUNT) {
             rt::Counters c{0, 0};
-            h = rt::traverse<ANY>(bvh, o, d, r.tmin, r.tmax, stack, 256, &c);
+            h = rt::traverse<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, &c);
             atomicAdd(&counters[0], c.nodes);
             atomicAdd(&counters[1], c.tris);
         } else {
-            h = rt::traverse<ANY>(bvh, o, d, r.tmin, r.tmax, stack, 256, nullptr);
+            h = rt::traverse<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, nullptr);
         }
     }
     hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};
@@ -131,8 +131,13 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n,
         p.a = get_event(); p.b = get_event(); p.any = any;
         check(hipEventRecord(p.a, s), "hipEventRecord");
     }
-#define RDR_TRACE_LAUNCH(ANY_, COUNT_, STACK_, ctr) \
-    hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr)
+#define RDR_TRACE_LAUNCH(ANY_, COUNT_, STACK_, ctr)                                                                          \
+    do {                                                                                                                     \
+        if (bvh.num_nodes < 65536)                                                                                           \
+            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, unsigned short>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr); \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, int>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr);            \
+    } while (0)
 #define RDR_TRACE_BY_STACK(ANY_, COUNT_, ctr)                                  \
     do {                                                                       \
         if (bvh.stack_need <= 16) RDR_TRACE_LAUNCH(ANY_, COUNT_, 16, ctr);      \
