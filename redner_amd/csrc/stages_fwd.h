@@ -302,8 +302,29 @@ struct BounceSample {
         LightDraw ld = draw_light(rng, slot, dim);
         LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
         if (pk.shape_id >= 0) {
-            Surf lp = sample_tri(sc.shapes[pk.shape_id], pk.tri_id, ld.uv);
-            put_ray(q_nee, idx, shadow_ray_to(c.sp.position, lp.position), false);
+            const ShapeD &lsh = sc.shapes[pk.shape_id];
+            Surf lp = sample_tri(lsh, pk.tri_id, ld.uv);
+            // A shadow ray whose answer cannot matter is not traced: when the light faces away, or the direction
+            // fails one of bsdf_eval's geometric early-outs, the estimator and its adjoint are exactly zero whether
+            // the segment is blocked or not (eval_bounce / AdjBounceNee / adj_bsdf_eval test the same conditions on
+            // the same values).  About a third of the shadow rays of the Cornell-box benchmark are of this kind.
+            bool moot = false;
+            {
+                V3 dir = lp.position - c.sp.position;
+                double d2 = len_sq(dir);
+                if (d2 > 1e-20f && lsh.light_id >= 0) {
+                    V3 wo = dir / sqrt(d2);
+                    const LightD &l = sc.lights[lsh.light_id];
+                    if (!(l.two_sided || dot(-wo, lp.frame.n) > 0)) moot = true;
+                    ShadeCtx sx = shade_ctx(*c.mat, c.sp);
+                    double gwi = dot(sx.gn, c.wi), gwo = dot(sx.gn, wo);
+                    double swi = fabs(dot(sx.fr.n, c.wi)), swo = fabs(dot(sx.fr.n, wo));
+                    if (gwi * gwo < 0) moot = true;
+                    if (!c.mat->two_sided && gwi < 0 && gwo < 0) moot = true;
+                    if (swi == 0 || swo <= 1e-3f || fabs(gwo) <= 1e-3f) moot = true;
+                }
+            }
+            put_ray(q_nee, idx, shadow_ray_to(c.sp.position, lp.position), moot);
         } else if (sc.envmap != nullptr) {
             Ray er = make_ray(c.sp.position, envmap_sample(*sc.envmap, ld.uv));      // tmin 1e-3f, tmax inf (:709-711)
             put_ray(q_nee, idx, er, false);
