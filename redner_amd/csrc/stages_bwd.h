@@ -228,6 +228,14 @@ struct AdjBounceNee {
         V3 wo = dir / sqrt(d2);
         const LightD &l = sc.lights[lsh.light_id];
         if (!(l.two_sided || dot(-wo, lp.frame.n) > 0)) return;
+        {   // bsdf_eval's geometric early-outs: value and every adjoint below are exactly zero then
+            ShadeCtx sx = shade_ctx(*c.mat, c.sp);
+            double gwi = dot(sx.gn, c.wi), gwo = dot(sx.gn, wo);
+            double swi = fabs(dot(sx.fr.n, c.wi)), swo = fabs(dot(sx.fr.n, wo));
+            if (gwi * gwo < 0) return;
+            if (!c.mat->two_sided && gwi < 0 && gwo < 0) return;
+            if (swi == 0 || swo <= 1e-3f || fabs(gwo) <= 1e-3f) return;
+        }
         const GMaterial &gm = g.materials[c.shape->material_id];
         V3 thr = ld3(v.thr, v.n, p, 0);
         V3 pc_bar = a.weight * image_grad(a.d_image, a.nd, a.radiance_dim, p);
