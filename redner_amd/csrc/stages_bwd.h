@@ -84,6 +84,8 @@ struct AdjBounceScatter {
         Surf sp_bar = surf_zero();
         V3 pos = c.sp.position;
         int bshape = vn.shape[p];
+        TriGrad tg = trigrad_zero();          // gradient of the triangle hit by the continuation, scattered at the end
+        int tg_shape = -1, tg_tri = -1;
         if (bshape >= 0) {
             const ShapeD &bsh = sc.shapes[bshape];
             int btri = vn.tri[p];
@@ -129,15 +131,14 @@ struct AdjBounceScatter {
                 bp_bar.position += dir_bar;
                 DRay r_bar = dray_zero();
                 RayDiff rd_bar = raydiff_zero();
-                TriGrad tg = trigrad_zero();
                 Ray br = make_ray(pos, wo);
                 adj_surf_at(bsh, btri, br, wo_rd, bp_bar, raydiff_zero(), r_bar, rd_bar, tg, !sc.no_diffs, sc.plain_materials != 0);
+                tg_shape = bshape; tg_tri = btri;
                 if (c.mrough > 0.01f) {
                     sp_bar.position -= dir_bar;
                     sp_bar.position += r_bar.org;
                 }
                 in_dir_bar -= wi_bar;
-                scatter_trigrad(bsh, g.shapes[bshape], btri, tg, sc.plain_materials != 0);
             }
         } else if (sc.envmap != nullptr) {
             // the BSDF ray reached the environment light (src/path_contribution.cpp:520-600); MIS weight and
@@ -164,6 +165,7 @@ struct AdjBounceScatter {
         st3(adj.thr, adj.n, p, 0, thr_bar);
         st3(adj.ray_dir, adj.n, p, 0, in_dir_bar);
         store_adj_point(adj, p, sp_bar);
+        scatter_trigrad_wave(sc.shapes, g.shapes, tg_shape, tg_tri, tg, sc.plain_materials != 0);   // every lane gets here
     }
 };
 
@@ -335,6 +337,12 @@ struct AdjPrimary {
     AdjState adj; float *screen_grad; ChannelsD ch;
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v0); lean_channels(ch); nd = 3; radiance_dim = 0; adj.plain = 1; }
     RDR_FN void operator()(int p) const {
+        TriGrad tg = trigrad_zero();          // gradient of the first-hit triangle, scattered by the whole wave at the end
+        int tg_shape = -1, tg_tri = -1;
+        RDR_INLINE_CALL camera_vertex(p, tg, tg_shape, tg_tri);
+        scatter_trigrad_wave(sc.shapes, g.shapes, tg_shape, tg_tri, tg, sc.plain_materials != 0);
+    }
+    RDR_FN void camera_vertex(int p, TriGrad &tg, int &tg_shape, int &tg_tri) const {
         int shape = v0.shape[p];
         Ray ray = load_ray(v0, p);
         RayDiff rd = load_rdiff(v0, p);
@@ -375,9 +383,8 @@ struct AdjPrimary {
                 Surf sp = surf_at(sc.shapes[shape], v0.tri[p], ray, rd, tmp, !sc.no_diffs);
                 adj_first_hit_channels(sc, g, ch, d_image, weight, p, shape, sp, ray, pt_bar, r_bar.org);
             }
-            TriGrad tg = trigrad_zero();
             adj_surf_at(sc.shapes[shape], v0.tri[p], ray, rd, pt_bar, raydiff_zero(), r_bar, prd_bar, tg, !sc.no_diffs, sc.plain_materials != 0);
-            scatter_trigrad(sc.shapes[shape], g.shapes[shape], v0.tri[p], tg, sc.plain_materials != 0);
+            tg_shape = shape; tg_tri = v0.tri[p];
         }
         V2 s = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
         V2 screen = pixel_to_screen(sc.cam, p, s);

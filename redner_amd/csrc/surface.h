@@ -476,6 +476,75 @@ RDR_FN void scatter_trigrad(const ShapeD &sh, const GShape &gs, int tri, const T
     }
 }
 
+// Wave-cooperative version for the adjoint kernels, called by EVERY lane of the stage at a convergent point
+// (shape < 0: nothing to add).  Lanes of a wave often hit the same triangle -- neighbouring pixels, the two triangles
+// of a wall -- and then add to the same 9..18 addresses; the three biggest same-triangle groups (>= 4 lanes) are
+// summed across the wave first (xor butterfly) and only their first lane issues the atomics.  Measured on the
+// benchmark: AdjPrimary 0.90 -> 0.43 ms, AdjBounceScatter 0.94 -> 0.73 ms per launch.
+RDR_FN void scatter_trigrad_wave(const ShapeD *shapes, const GShape *gshapes, int shape, int tri, const TriGrad &g, bool plain) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__ballot(1) == ~0ull) {              // the butterfly needs every lane; the ragged last wave takes the plain path
+        const bool valid = shape >= 0;
+        const unsigned long long key = valid ? (((unsigned long long)(unsigned)shape << 32) | (unsigned)tri) : ~0ull;
+        unsigned long long rem = __ballot(valid);
+        bool handled = !valid;
+        const int lane = threadIdx.x & 63;
+        for (int it = 0; it < 3 && rem != 0; ++it) {
+            const int l = __ffsll((long long)rem) - 1;
+            const unsigned klo = __builtin_amdgcn_readlane((unsigned)key, l);
+            const unsigned khi = __builtin_amdgcn_readlane((unsigned)(key >> 32), l);
+            const bool in = key == (((unsigned long long)khi << 32) | klo);
+            const unsigned long long m = __ballot(in);
+            rem &= ~m;
+            if (__popcll(m) < 4) continue;
+            handled = handled || in;
+            const bool lead = lane == l;
+            TriVerts tv; TriAttr at;
+            bool has_n = false, has_uv = false, has_c = false;
+            double *gv = nullptr, *gn = nullptr, *gu = nullptr, *gc = nullptr;
+            tv.i0 = tv.i1 = tv.i2 = 0; at.ui0 = at.ui1 = at.ui2 = at.ni0 = at.ni1 = at.ni2 = 0;
+            if (lead) {
+                const ShapeD &sh = shapes[shape];
+                const GShape &gs = gshapes[shape];
+                tv = load_tri(sh, tri); at = load_attr(sh, tri, tv);
+                gv = gs.vertices;
+                has_n = sh.normals && gs.normals; gn = gs.normals;
+                has_uv = !plain && sh.uvs && gs.uvs; gu = gs.uvs;
+                has_c = !plain && sh.colors && gs.colors; gc = gs.colors;
+            }
+            const bool any_n = __ballot(has_n) != 0, any_uv = __ballot(has_uv) != 0, any_c = __ballot(has_c) != 0;
+            const int vi[3] = {tv.i0, tv.i1, tv.i2}, ui[3] = {at.ui0, at.ui1, at.ui2}, ni[3] = {at.ni0, at.ni1, at.ni2};
+#define RDR_WSUM(x) { double s_ = in ? (x) : 0.0; for (int sh_ = 32; sh_ >= 1; sh_ >>= 1) s_ += __shfl_xor(s_, sh_, 64); (x) = s_; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                V3 p = g.p[k];
+                RDR_WSUM(p.x) RDR_WSUM(p.y) RDR_WSUM(p.z)
+                if (lead) accum3(gv + 3 * vi[k], p);
+                if (any_n) {
+                    V3 n = g.n[k];
+                    RDR_WSUM(n.x) RDR_WSUM(n.y) RDR_WSUM(n.z)
+                    if (lead && has_n) accum3(gn + 3 * ni[k], n);
+                }
+                if (any_uv) {
+                    V2 t = g.uv[k];
+                    RDR_WSUM(t.x) RDR_WSUM(t.y)
+                    if (lead && has_uv) { accum(gu + 2 * ui[k], t.x); accum(gu + 2 * ui[k] + 1, t.y); }
+                }
+                if (any_c) {
+                    V3 c = g.c[k];
+                    RDR_WSUM(c.x) RDR_WSUM(c.y) RDR_WSUM(c.z)
+                    if (lead && has_c) accum3(gc + 3 * vi[k], c);
+                }
+            }
+#undef RDR_WSUM
+        }
+        if (!handled) scatter_trigrad(shapes[shape], gshapes[shape], tri, g, plain);
+        return;
+    }
+#endif
+    if (shape >= 0) scatter_trigrad(shapes[shape], gshapes[shape], tri, g, plain);
+}
+
 RDR_FN double tri_area(const ShapeD &sh, int tri) {
     TriVerts tv = load_tri(sh, tri);
     return 0.5f * len(cross(tv.p1 - tv.p0, tv.p2 - tv.p0));

@@ -1,0 +1,5 @@
+set -x
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_ws -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --spp 8 --no-cpu-baseline 2>&1 | tail -1
