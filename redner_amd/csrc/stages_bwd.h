@@ -211,6 +211,12 @@ struct AdjBounceNee {
         adj_record_add(a.adj, p, thr_bar, -wi_bar, sp_bar);
     }
     RDR_FN void operator()(int idx) const {
+        V3 lv_bar[3] = {v3(0), v3(0), v3(0)};      // gradient of the sampled light triangle, scattered by the whole wave
+        int l_shape = -1, l_tri = -1;
+        RDR_INLINE_CALL light_vertex(idx, lv_bar, l_shape, l_tri);
+        scatter_positions_wave(a.sc.shapes, a.g.shapes, l_shape, l_tri, lv_bar);
+    }
+    RDR_FN void light_vertex(int idx, V3 (&lv_bar)[3], int &l_shape, int &l_tri) const {
         const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v; const AdjState &adj = a.adj;
         int p = a.active[idx];
         if (v.occl[p]) return;
@@ -243,7 +249,6 @@ struct AdjBounceNee {
         V3 pc_bar = a.weight * image_grad(a.d_image, a.nd, a.radiance_dim, p);
         V3 thr_bar = v3(0), in_dir_bar = v3(0);
         Surf sp_bar = surf_zero();
-        V3 lv_bar[3] = {v3(0), v3(0), v3(0)};
         V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
         double cl = dot(wo, lp.geom_normal);
         double geo = fabs(cl) / d2;
@@ -279,9 +284,7 @@ struct AdjBounceNee {
         sp_bar.position -= dir_bar;
         in_dir_bar -= wi_bar;
         adj_sample_tri(lsh, pk.tri_id, ld.uv, lp_bar, lv_bar);
-        TriVerts tv = load_tri(lsh, pk.tri_id);
-        double *gv = g.shapes[pk.shape_id].vertices;
-        accum3(gv + 3 * tv.i0, lv_bar[0]); accum3(gv + 3 * tv.i1, lv_bar[1]); accum3(gv + 3 * tv.i2, lv_bar[2]);
+        l_shape = pk.shape_id; l_tri = pk.tri_id;
         adj_record_add(adj, p, thr_bar, in_dir_bar, sp_bar);
     }
 };

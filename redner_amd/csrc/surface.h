@@ -545,6 +545,49 @@ RDR_FN void scatter_trigrad_wave(const ShapeD *shapes, const GShape *gshapes, in
     if (shape >= 0) scatter_trigrad(shapes[shape], gshapes[shape], tri, g, plain);
 }
 
+// Same for the three vertex positions of a sampled light triangle (AdjBounceNee): an area light is a handful of
+// triangles, so nearly every lane of the wave falls into one of the groups.
+RDR_FN void scatter_positions_wave(const ShapeD *shapes, const GShape *gshapes, int shape, int tri, const V3 (&pb)[3]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__ballot(1) == ~0ull) {
+        const bool valid = shape >= 0;
+        const unsigned long long key = valid ? (((unsigned long long)(unsigned)shape << 32) | (unsigned)tri) : ~0ull;
+        unsigned long long rem = __ballot(valid);
+        bool handled = !valid;
+        const int lane = threadIdx.x & 63;
+        for (int it = 0; it < 3 && rem != 0; ++it) {
+            const int l = __ffsll((long long)rem) - 1;
+            const unsigned klo = __builtin_amdgcn_readlane((unsigned)key, l);
+            const unsigned khi = __builtin_amdgcn_readlane((unsigned)(key >> 32), l);
+            const bool in = key == (((unsigned long long)khi << 32) | klo);
+            const unsigned long long m = __ballot(in);
+            rem &= ~m;
+            if (__popcll(m) < 4) continue;
+            handled = handled || in;
+            const bool lead = lane == l;
+            TriVerts tv; tv.i0 = tv.i1 = tv.i2 = 0;
+            double *gv = nullptr;
+            if (lead) { tv = load_tri(shapes[shape], tri); gv = gshapes[shape].vertices; }
+            const int vi[3] = {tv.i0, tv.i1, tv.i2};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                V3 p = in ? pb[k] : V3{0.0, 0.0, 0.0};
+                for (int sh_ = 32; sh_ >= 1; sh_ >>= 1) {
+                    p.x += __shfl_xor(p.x, sh_, 64); p.y += __shfl_xor(p.y, sh_, 64); p.z += __shfl_xor(p.z, sh_, 64);
+                }
+                if (lead) accum3(gv + 3 * vi[k], p);
+            }
+        }
+        if (handled) return;
+    } else if (shape < 0) return;
+#else
+    if (shape < 0) return;
+#endif
+    TriVerts tv = load_tri(shapes[shape], tri);
+    double *gv = gshapes[shape].vertices;
+    accum3(gv + 3 * tv.i0, pb[0]); accum3(gv + 3 * tv.i1, pb[1]); accum3(gv + 3 * tv.i2, pb[2]);
+}
+
 RDR_FN double tri_area(const ShapeD &sh, int tri) {
     TriVerts tv = load_tri(sh, tri);
     return 0.5f * len(cross(tv.p1 - tv.p0, tv.p2 - tv.p0));
