@@ -89,7 +89,7 @@ RDR_FN void adj_distort(const DistortD &d, V2 pos, V2 out_bar, double *g_dist, V
     pos_bar.x += x_bar * 2;
     pos_bar.y += y_bar * 2;
     if (g_dist) {
-        for (int i = 0; i < 6; ++i) accum(g_dist + i, k_bar[i]);
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) accum(g_dist + i, k_bar[i]);
         accum(g_dist + 6, p_bar[0]);
         accum(g_dist + 7, p_bar[1]);
     }
@@ -203,13 +203,13 @@ RDR_FN void scatter_cam_to_world(const CameraD &cam, const M4 &c2w_bar, const GC
         if (g.look) accum3(g.look, lb);
         if (g.up) accum3(g.up, ub);
     } else if (g.cam_to_world) {
-        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) accum(g.cam_to_world + 4 * r + c, c2w_bar.m[r][c]);
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) { _Pragma("unroll") for (int c = 0; c < 4; ++c) accum(g.cam_to_world + 4 * r + c, c2w_bar.m[r][c]); }
     }
 }
 RDR_FN void accum_outer3(double *g, V3 a, V3 b, int rows) {          // g[r][c] += a[r] * b[c]
     if (!g) return;
     double av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
-    for (int r = 0; r < rows; ++r) for (int c = 0; c < 3; ++c) accum(g + 3 * r + c, av[r] * bv[c]);
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) { if (r < rows) { _Pragma("unroll") for (int c = 0; c < 3; ++c) accum(g + 3 * r + c, av[r] * bv[c]); } }
 }
 // Tail shared by every camera model: undo the lens distortion on the way back to the screen position.
 RDR_FN void adj_screen_tail(const CameraD &cam, V2 screen, V2 distorted_bar, const GCamera &g, bool want, V2 &screen_bar) {

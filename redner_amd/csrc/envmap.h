@@ -82,7 +82,7 @@ RDR_FN void adj_envmap_eval(const EnvmapD &env, V3 dir, const RayDiff &rd, V3 o_
     V3 nl_bar = adj_normalize(n_local, ld_bar);
     adj_xfm_vector(env.world_to_env, dir, nl_bar, w2e_bar, dir_bar);
     if (g && g->world_to_env)
-        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) accum(g->world_to_env + 4 * r + c, w2e_bar.m[r][c]);
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) { _Pragma("unroll") for (int c = 0; c < 4; ++c) accum(g->world_to_env + 4 * r + c, w2e_bar.m[r][c]); }
 }
 
 RDR_FN double tent_inv_cdf(double x) {

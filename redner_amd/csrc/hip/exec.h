@@ -40,37 +40,47 @@ __host__ inline void *lds_column_host_stub() { return nullptr; }
 
 // Gradient scatter.  Many lanes of a wave usually add to the SAME address (all pixels of a wall
 // hit the same 4 vertices / the same constant albedo; every pixel adds to the camera), which would
-// serialise 64 fp64 atomics on one L2 line.  So: if every active lane of the wave targets one
-// address, the wave sums its values first (xor-butterfly when all 64 lanes are active, otherwise a
-// scalar loop over the active lanes in lane order) and issues ONE atomic; mixed addresses fall
-// back to one hardware fp64 atomic per lane.
+// serialise 64 fp64 atomics on one L2 line.  So: the lanes that target the first lane's address sum
+// their values first (xor-butterfly when all 64 lanes are active, otherwise a scalar loop over
+// those lanes in lane order) and issue ONE atomic; that is repeated for up to kAccumRounds distinct
+// addresses (lanes on different materials / walls), whoever is left issues its own hardware fp64 atomic.
 static __device__ unsigned long long g_replica_stride = 0;   // doubles between replicas (0 = none)
 static __device__ unsigned g_replica_mask = 0;               // replicas - 1 (power of two)
+constexpr int kAccumRounds = 3;                              // distinct addresses summed across the wave per call
 
 __device__ inline void accum(double *p, double v) {
     p += (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & g_replica_mask) * g_replica_stride;
     const unsigned long long act = __ballot(1);
     const unsigned long long addr = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)addr);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(addr >> 32));
-    const bool same = addr == (((unsigned long long)hi << 32) | lo);
-    if (__ballot(same) != act || __popcll(act) == 1) { unsafeAtomicAdd(p, v); return; }
-    double s;
-    if (act == ~0ull) {
-        s = v;
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-    } else {
-        s = 0;
-        const int vlo = __double2loint(v), vhi = __double2hiint(v);
-        unsigned long long m = act;
-        while (m) {
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            s += __hiloint2double(__builtin_amdgcn_readlane(vhi, l), __builtin_amdgcn_readlane(vlo, l));
+    const int lane = threadIdx.x & 63;
+    const int vlo = __double2loint(v), vhi = __double2hiint(v);
+    unsigned long long rem = act;
+    bool mine = true;                         // this lane's value has not been added yet
+    for (int round = 0; round < kAccumRounds && rem != 0; ++round) {      // wave-uniform trip count
+        const int l = __ffsll((long long)rem) - 1;
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)addr, l);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(addr >> 32), l);
+        const bool same = addr == (((unsigned long long)hi << 32) | lo);
+        const unsigned long long m = __ballot(same) & rem;
+        rem &= ~m;
+        if (__popcll(m) < 2) continue;        // a lone lane adds for itself below
+        double s;
+        if (act == ~0ull) {
+            s = same ? v : 0.0;
+            for (int x = 32; x >= 1; x >>= 1) s += __shfl_xor(s, x, 64);
+        } else {
+            s = 0;
+            unsigned long long mm = m;
+            while (mm) {
+                const int k = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                s += __hiloint2double(__builtin_amdgcn_readlane(vhi, k), __builtin_amdgcn_readlane(vlo, k));
+            }
         }
+        if (lane == l) unsafeAtomicAdd(p, s);
+        if (same) mine = false;
     }
-    const int first = __ffsll((long long)act) - 1;
-    if ((int)(threadIdx.x & 63) == first) unsafeAtomicAdd(p, s);
+    if (mine) unsafeAtomicAdd(p, v);
 }
 __host__ inline void accum(double *p, double v) { *p += v; }   // host instantiation is never executed
 }
