@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <future>
 #include <limits>
 #include <stdexcept>
 
@@ -25,8 +26,11 @@ struct Box {
     }
 };
 
+// Builds the subtree over prims[first, first+count) of a shared primitive array into its own node / triangle
+// arrays (root = node 0).  Disjoint ranges can be built by different threads; the splice below puts them
+// together in a fixed order, so the layout does not depend on thread timing.
 struct Builder {
-    std::vector<Prim> prims;
+    Prim *prims = nullptr;
     BvhHost out;
     static constexpr int kMaxBins = 64, kLeafMax = 4;
     int kBins = 64;            // tuning knobs (RDR_BVH_BINS / RDR_BVH_TCOST); defaults from a sweep on bunny_box (profiles/r1_notes.md)
@@ -49,11 +53,10 @@ struct Builder {
         out.nodes[node].b = count;
     }
 
-    void build(int node, int first, int count, int depth) {
-        out.depth = std::max(out.depth, depth);
-        Box b, cb;
+    // Bounds of the range and its SAH split (partitions the range in place).  False: the range becomes a leaf.
+    bool split_range(int first, int count, Box &b, int &mid) {
+        Box cb;
         for (int i = first; i < first + count; ++i) { b.grow(prims[i].lo, prims[i].hi); cb.grow_pt(prims[i].c); }
-        set_bounds(node, b);
         int best_axis = -1, best_bin = -1;
         float best_cost = std::numeric_limits<float>::infinity();
         if (count > 1) {
@@ -80,23 +83,32 @@ struct Builder {
         }
         float leaf_cost = b.half_area() * count;
         bool split = best_axis >= 0 && (count > kLeafMax || best_cost + kTravCost * b.half_area() < leaf_cost);
-        int mid = first + count / 2;
+        mid = first + count / 2;
         if (split) {
             float ext = cb.hi[best_axis] - cb.lo[best_axis];
             float scale = kBins / ext;
             float lo = cb.lo[best_axis];
-            auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim &p) {
+            Prim *it = std::partition(prims + first, prims + first + count, [&](const Prim &p) {
                 int bi = std::min(kBins - 1, std::max(0, (int)((p.c[best_axis] - lo) * scale)));
                 return bi <= best_bin;
             });
-            mid = (int)(it - prims.begin());
+            mid = (int)(it - prims);
             if (mid == first || mid == first + count) split = false;
         }
         if (!split) {
-            if (count <= kLeafMax) { make_leaf(node, first, count); return; }
+            if (count <= kLeafMax) return false;
             // degenerate (coincident centroids): median split by index keeps the tree finite
             mid = first + count / 2;
         }
+        return true;
+    }
+
+    void build(int node, int first, int count, int depth) {
+        out.depth = std::max(out.depth, depth);
+        Box b; int mid;
+        bool inner = split_range(first, count, b, mid);
+        set_bounds(node, b);
+        if (!inner) { make_leaf(node, first, count); return; }
         int left = (int)out.nodes.size();
         out.nodes.push_back(Node{});
         out.nodes.push_back(Node{});
@@ -105,12 +117,48 @@ struct Builder {
         build(left, first, mid - first, depth + 1);
         build(left + 1, mid, first + count - mid, depth + 1);
     }
+
+    // Top of the tree: the two halves of a large range are built concurrently and spliced as
+    // [root, left root, right root, rest of left, rest of right].
+    static constexpr int kTaskMin = 1024, kTaskDepth = 5;
+    void build_top(int first, int count, int depth) {
+        out.nodes.assign(1, Node{});
+        if (count < kTaskMin || depth >= kTaskDepth) { build(0, first, count, depth); return; }
+        out.depth = depth;
+        Box b; int mid;
+        bool inner = split_range(first, count, b, mid);
+        set_bounds(0, b);
+        if (!inner) { make_leaf(0, first, count); return; }
+        Builder L, R;
+        L.prims = R.prims = prims; L.kBins = R.kBins = kBins; L.kTravCost = R.kTravCost = kTravCost;
+        auto left_job = std::async(std::launch::async, [&] { L.build_top(first, mid - first, depth + 1); });
+        R.build_top(mid, first + count - mid, depth + 1);
+        left_job.get();
+        const int nl = (int)L.out.nodes.size(), nr = (int)R.out.nodes.size();
+        const int tl = (int)L.out.ids.size() / 2;
+        out.nodes.resize(1 + nl + nr);
+        out.nodes[0].a = 1; out.nodes[0].b = 0;
+        auto place = [&](const Node &src, int child_shift, int slot_shift) {
+            Node n = src;
+            if (n.b > 0) n.a += slot_shift; else n.a += child_shift;
+            return n;
+        };
+        // local index i >= 1 of the left subtree lands at i + 2, of the right subtree at i + 1 + nl
+        out.nodes[1] = place(L.out.nodes[0], 2, 0);
+        out.nodes[2] = place(R.out.nodes[0], 1 + nl, tl);
+        for (int i = 1; i < nl; ++i) out.nodes[i + 2] = place(L.out.nodes[i], 2, 0);
+        for (int i = 1; i < nr; ++i) out.nodes[i + 1 + nl] = place(R.out.nodes[i], 1 + nl, tl);
+        out.tris = std::move(L.out.tris); out.tris.insert(out.tris.end(), R.out.tris.begin(), R.out.tris.end());
+        out.ids = std::move(L.out.ids); out.ids.insert(out.ids.end(), R.out.ids.begin(), R.out.ids.end());
+        out.depth = std::max(L.out.depth, R.out.depth);
+    }
 };
 
 } // namespace
 
 BvhHost build_bvh(const std::vector<MeshView> &meshes) {
     Builder bd;
+    std::vector<Prim> prims;
     if (const char *e = std::getenv("RDR_BVH_BINS")) bd.kBins = std::min(64, std::max(2, std::atoi(e)));
     if (const char *e = std::getenv("RDR_BVH_TCOST")) bd.kTravCost = (float)std::atof(e);
     for (size_t s = 0; s < meshes.size(); ++s) {
@@ -126,12 +174,12 @@ BvhHost build_bvh(const std::vector<MeshView> &meshes) {
                 p.hi[a] = std::max(p.v[a], std::max(p.v[3 + a], p.v[6 + a]));
                 p.c[a] = 0.5f * (p.lo[a] + p.hi[a]);
             }
-            bd.prims.push_back(p);
+            prims.push_back(p);
         }
     }
-    if (bd.prims.empty()) return bd.out;
-    bd.out.nodes.push_back(Node{});
-    bd.build(0, 0, (int)bd.prims.size(), 0);
+    if (prims.empty()) return bd.out;
+    bd.prims = prims.data();
+    bd.build_top(0, (int)prims.size(), 0);
     if (bd.out.depth + 2 > kTraverseStack) throw std::runtime_error("triangle hierarchy deeper than the traversal stack");
     return bd.out;
 }

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <limits>
 #include <memory>
 
@@ -35,21 +36,37 @@ void insertion_sort_seq(T *first, T *last, Cmp comp) {
         }
     }
 }
+// `scratch` holds at least (last - first) / 2 + 1 elements.  The halves of the top `par_levels` levels are sorted
+// on two threads: the algorithm is deterministic and the halves are disjoint, so the outcome is the same.
 template <class T, class Cmp>
-void merge_sort_seq(T *first, T *last, Cmp comp) {
+void merge_sort_rec(T *first, T *last, T *scratch, Cmp comp, int par_levels) {
     ptrdiff_t n = last - first;
     if (n <= 32) { insertion_sort_seq(first, last, comp); return; }
     T *mid = first + n / 2;
-    merge_sort_seq(first, mid, comp);
-    merge_sort_seq(mid, last, comp);
-    std::vector<T> a(first, mid), b(mid, last);
-    size_t i = 0, j = 0;
-    T *out = first;
-    while (i < a.size() && j < b.size()) {
-        if (comp(b[j], a[i])) *out++ = b[j++]; else *out++ = a[i++];
+    if (par_levels > 0 && n >= 4096) {
+        std::vector<T> other((size_t)(n / 2 / 2 + 2));
+        auto job = std::async(std::launch::async, [&] { merge_sort_rec(first, mid, other.data(), comp, par_levels - 1); });
+        merge_sort_rec(mid, last, scratch, comp, par_levels - 1);
+        job.get();
+    } else {
+        merge_sort_rec(first, mid, scratch, comp, 0);
+        merge_sort_rec(mid, last, scratch, comp, 0);
     }
-    while (i < a.size()) *out++ = a[i++];
-    while (j < b.size()) *out++ = b[j++];
+    const ptrdiff_t na = mid - first;
+    for (ptrdiff_t k = 0; k < na; ++k) scratch[k] = first[k];
+    const T *a = scratch, *a_end = scratch + na;
+    const T *b = mid;
+    T *out = first;
+    while (a < a_end && b < last) {
+        if (comp(*b, *a)) *out++ = *b++; else *out++ = *a++;
+    }
+    while (a < a_end) *out++ = *a++;
+    // what is left of the right run is already in place
+}
+template <class T, class Cmp>
+void merge_sort_seq(T *first, T *last, Cmp comp) {
+    std::vector<T> scratch((size_t)((last - first) / 2 + 2));
+    merge_sort_rec(first, last, scratch.data(), comp, 3);
 }
 
 bool f3_less_eq(F3 a, F3 b) {      // "less_than" of src/edge.cpp:93-102: true on equality
@@ -122,6 +139,20 @@ double unit_coord(double v, double lo, double hi) {
 
 int clz64(uint64_t x) { return x == 0 ? 64 : __builtin_clzll(x); }
 
+// f(begin, end) over [0, n) in up to 16 contiguous chunks on separate threads (iterations must be independent).
+template <class F>
+void parallel_chunks(int n, int grain, F f) {
+    int chunks = std::min(16, (n + grain - 1) / grain);
+    if (chunks <= 1) { f(0, n); return; }
+    std::vector<std::future<void>> jobs;
+    for (int c = 1; c < chunks; ++c) {
+        int b = (int)((long long)n * c / chunks), e = (int)((long long)n * (c + 1) / chunks);
+        jobs.push_back(std::async(std::launch::async, [=] { f(b, e); }));
+    }
+    f(0, (int)((long long)n / chunks));
+    for (auto &j : jobs) j.get();
+}
+
 // ---- one hierarchy ------------------------------------------------------------------------------
 struct TreeBuilder {
     bool is3d;
@@ -157,6 +188,7 @@ struct TreeBuilder {
     }
 
     void build(const std::vector<int> &edge_ids) {
+        PhaseTimer timer(is3d ? "3-D tree" : "6-D tree");
         ids = edge_ids;
         n = (int)ids.size();
         if (n == 0) return;
@@ -164,7 +196,8 @@ struct TreeBuilder {
         Box6 sb = empty_box6();
         for (int id : ids) sb = merge6(sb, bounds[id]);
         codes.resize(n);
-        for (int i = 0; i < n; ++i) {
+        parallel_chunks(n, 4096, [&](int i_begin, int i_end) {
+        for (int i = i_begin; i < i_end; ++i) {
             const Box6 &b = bounds[ids[i]];
             V3 pc = 0.5f * (b.p_min + b.p_max);
             if (is3d) {
@@ -185,6 +218,8 @@ struct TreeBuilder {
                            (expand6(dx) << 2u) | (expand6(dy) << 1u) | expand6(dz);
             }
         }
+        });
+        timer.lap("codes");
         // stable sort of (code, id) by code
         std::vector<int> order(n);
         for (int i = 0; i < n; ++i) order[i] = i;
@@ -193,6 +228,7 @@ struct TreeBuilder {
         for (int i = 0; i < n; ++i) { sid[i] = ids[order[i]]; scode[i] = codes[order[i]]; }
         ids.swap(sid); codes.swap(scode);
 
+        timer.lap("sort");
         n_internal = std::max(n - 1, 1);
         EdgeNode init;
         double inf = std::numeric_limits<double>::infinity();
@@ -200,8 +236,9 @@ struct TreeBuilder {
         init.wlen = 0; init.cost = 0; init.parent = -1; init.child0 = init.child1 = -1; init.edge_id = -1;
         nodes.assign(n_internal + n, init);
 
-        // Karras radix tree over the sorted codes (ties broken by edge id)
-        for (int idx = 0; idx < n - 1; ++idx) {
+        // Karras radix tree over the sorted codes (ties broken by edge id); every internal node is independent
+        parallel_chunks(n - 1, 2048, [&](int idx_begin, int idx_end) {
+        for (int idx = idx_begin; idx < idx_end; ++idx) {
             int d = (lcp(idx, idx + 1) - lcp(idx, idx - 1) >= 0) ? 1 : -1;
             int dmin = lcp(idx, idx - d);
             int lmax = 2;
@@ -230,9 +267,12 @@ struct TreeBuilder {
             if (std::max(idx, j) == gamma + 1) { nd.child1 = leaf_ref(gamma + 1); nodes[leaf_ref(gamma + 1)].parent = idx; }
             else { nd.child1 = gamma + 1; nodes[gamma + 1].parent = idx; }
         }
+        });
 
+        timer.lap("radix tree");
         // leaves + bottom-up bounds / weighted length
         std::vector<int> counter(n_internal + n, 0);
+        std::vector<int> leaves_below(n_internal + n, 1);
         for (int i = 0; i < n; ++i) {
             EdgeNode &lf = nodes[leaf_ref(i)];
             const Box6 &b = bounds[ids[i]];
@@ -247,22 +287,50 @@ struct TreeBuilder {
                 EdgeNode &nd = nodes[cur];
                 merge_children(nd, nodes[nd.child0], nodes[nd.child1]);
                 nd.wlen = nodes[nd.child0].wlen + nodes[nd.child1].wlen;
+                leaves_below[cur] = leaves_below[nd.child0] + leaves_below[nd.child1];
                 cur = nd.parent;
             }
         }
         if (n == 1) { nodes[0] = nodes[leaf_ref(0)]; }     // single primitive: the root is a copy of the leaf
 
-        // treelet optimisation, bottom-up
-        std::fill(counter.begin(), counter.end(), 0);
-        for (int i = 0; i < n; ++i) {
-            EdgeNode &lf = nodes[leaf_ref(i)];
-            lf.cost = area(lf);
-            int cur = lf.parent;
-            while (cur >= 0) {
-                if (++counter[cur] == 1) break;
-                treelet_optimize(cur);
-                if (cur == 0) break;
-                cur = nodes[cur].parent;
+        // treelet optimisation, bottom-up: a node is restructured once both child subtrees are done
+        // (src/edge_tree.cpp:724-790 climbs from the leaves with arrival counters).  A restructuring only touches
+        // nodes below its root, so any schedule that respects that dependency gives the same tree; the subtrees
+        // below the top levels are independent jobs.
+        timer.lap("bounds");
+        for (int i = 0; i < n; ++i) nodes[leaf_ref(i)].cost = area(nodes[leaf_ref(i)]);
+        if (n > 1) optimize_subtree(0, 0, leaves_below);
+        timer.lap("treelets");
+    }
+
+    void optimize_subtree(int node, int depth, const std::vector<int> &leaves_below) {
+        if (nodes[node].edge_id != -1) return;
+        const int c0 = nodes[node].child0, c1 = nodes[node].child1;
+        if (depth < 6 && leaves_below[node] >= 2048) {
+            auto job = std::async(std::launch::async, [&] { optimize_subtree(c0, depth + 1, leaves_below); });
+            optimize_subtree(c1, depth + 1, leaves_below);
+            job.get();
+        } else {
+            optimize_sequential(c0);
+            optimize_sequential(c1);
+        }
+        treelet_optimize(node);
+    }
+    void optimize_sequential(int top) {          // post-order walk without recursion (radix trees can be deep)
+        if (nodes[top].edge_id != -1) return;
+        std::vector<std::pair<int, int>> stack;   // (node, children pushed?)
+        stack.emplace_back(top, 0);
+        while (!stack.empty()) {
+            auto &e = stack.back();
+            const int node = e.first;
+            if (e.second == 0) {
+                e.second = 1;
+                const int c0 = nodes[node].child0, c1 = nodes[node].child1;
+                if (nodes[c1].edge_id == -1) stack.emplace_back(c1, 0);
+                if (nodes[c0].edge_id == -1) stack.emplace_back(c0, 0);
+            } else {
+                stack.pop_back();
+                treelet_optimize(node);
             }
         }
     }
@@ -382,21 +450,8 @@ struct TreeBuilder {
 
 void delete_edge_data(EdgeData *e) { delete e; }
 
-namespace {
-struct PhaseTimer {         // RDR_DEBUG_DUMP: wall time of the build phases on stderr
-    const bool on = std::getenv("RDR_DEBUG_DUMP") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void lap(const char *what) {
-        if (!on) return;
-        auto n = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[redner_amd] edge build: %-24s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
-        t = n;
-    }
-};
-}
-
 EdgeData *build_edge_data(Scene &scene) {
-    PhaseTimer timer;
+    PhaseTimer timer("edge build");
     std::unique_ptr<EdgeData> ed(new EdgeData());
     const int ns = (int)scene.shapes.size();
     // host views of the shapes (same records, pointers into the host mirrors)
@@ -433,12 +488,17 @@ EdgeData *build_edge_data(Scene &scene) {
             i = j;
         }
         // sort by endpoint positions so duplicated (e.g. UV-seam) edges become neighbours
-        merge_sort_seq(merged.data(), merged.data() + merged.size(), [&](const EdgeD &a, const EdgeD &b) {
-            SortedEnds ea = sorted_ends(sh, a), eb = sorted_ends(sh, b);
-            if (f3_ne(ea.lo, eb.lo)) return f3_less_eq(ea.lo, eb.lo);
-            if (f3_ne(ea.hi, eb.hi)) return f3_less_eq(ea.hi, eb.hi);
-            return true;
-        });
+        {
+            struct Keyed { SortedEnds ends; EdgeD e; };
+            std::vector<Keyed> keyed(merged.size());
+            for (size_t i = 0; i < merged.size(); ++i) keyed[i] = Keyed{sorted_ends(sh, merged[i]), merged[i]};
+            merge_sort_seq(keyed.data(), keyed.data() + keyed.size(), [](const Keyed &a, const Keyed &b) {
+                if (f3_ne(a.ends.lo, b.ends.lo)) return f3_less_eq(a.ends.lo, b.ends.lo);
+                if (f3_ne(a.ends.hi, b.ends.hi)) return f3_less_eq(a.ends.hi, b.ends.hi);
+                return true;
+            });
+            for (size_t i = 0; i < merged.size(); ++i) merged[i] = keyed[i].e;
+        }
         const int ne = (int)merged.size();
         std::vector<int> f1(ne);
         for (int i = 0; i < ne; ++i) {
@@ -536,10 +596,12 @@ EdgeData *build_edge_data(Scene &scene) {
 
         timer.lap("pmf, bounds, split");
         TreeBuilder cs(true, shapes, edges, bounds), ncs(false, shapes, edges, bounds);
-        cs.build(cs_ids);
-        timer.lap("3-D tree");
-        ncs.build(ncs_ids);
-        timer.lap("6-D tree");
+        {   // the two hierarchies are independent
+            auto cs_job = std::async(std::launch::async, [&] { cs.build(cs_ids); });
+            ncs.build(ncs_ids);
+            cs_job.get();
+        }
+        timer.lap("3-D and 6-D trees");
         ed->cs_nodes.swap(cs.nodes); ed->cs_leaves = cs.n;
         ed->ncs_nodes.swap(ncs.nodes); ed->ncs_leaves = ncs.n;
         // the NEE-mode traversal keeps one pending sibling per level in a fixed 64-entry stack

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <limits>
 #include <stdexcept>
 
@@ -83,6 +84,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
 
     std::unique_ptr<Scene> sp(new Scene());
     Scene &s = *sp;
+    PhaseTimer timer("scene build");
     s.gpu_index = gpu_index;
     s.use_primary_edges = primary_edges != 0;
     s.use_secondary_edges = secondary_edges != 0;
@@ -165,6 +167,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         for (int k = 0; k < 3; ++k) o.intensity[k] = in.intensity[k];
     }
 
+    timer.lap("tables, host mirrors");
     // ---- light PMF / CDF, per-light area CDF (src/scene.cpp:38-61, 197-253) ----
     int num_lights = num_area_lights + (envmap ? 1 : 0);       // the environment light is the last entry (:197-202)
     s.light_pmf.assign(num_lights, 0); s.light_cdf.assign(num_lights, 0); s.light_areas.assign(num_area_lights, 0);
@@ -221,19 +224,13 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         }
     }
 
-    // ---- triangle hierarchy ----
-    {
-        std::vector<rt::MeshView> meshes(num_shapes);
-        for (int i = 0; i < num_shapes; ++i)
-            meshes[i] = rt::MeshView{s.h_vertices[i].data(), s.h_indices[i].data(), s.shapes[i].num_triangles};
-        s.bvh_host = rt::build_bvh(meshes);
-        s.bvh.num_nodes = (int)s.bvh_host.nodes.size();
-        s.bvh.num_tris = (int)s.bvh_host.ids.size() / 2;
-        s.bvh.stack_need = s.bvh_host.depth + 2;
-        s.bvh.nodes = to_device(s, s.bvh_host.nodes.data(), s.bvh_host.nodes.size());
-        s.bvh.tris = to_device(s, s.bvh_host.tris.data(), s.bvh_host.tris.size());
-        s.bvh.ids = to_device(s, s.bvh_host.ids.data(), s.bvh_host.ids.size());
-    }
+    timer.lap("light tables");
+    // ---- triangle hierarchy: built on other threads while this one prepares the tables and the edge list ----
+    std::vector<rt::MeshView> meshes(num_shapes);
+    for (int i = 0; i < num_shapes; ++i)
+        meshes[i] = rt::MeshView{s.h_vertices[i].data(), s.h_indices[i].data(), s.shapes[i].num_triangles};
+    std::future<rt::BvhHost> bvh_job = std::async(std::launch::async, [&meshes] { return rt::build_bvh(meshes); });
+    struct JoinOnExit { std::future<rt::BvhHost> &f; ~JoinOnExit() { if (f.valid()) f.wait(); } } join_bvh{bvh_job};
 
     // ---- device copies of the flat tables ----
     s.d.shapes = to_device(s, s.shapes.data(), s.shapes.size());
@@ -270,8 +267,20 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     s.sobol_table = to_device(s, rdr_sobol_table, (size_t)kSobolTableWords);
     s.ltc_table = to_device(s, rdr_ltc_table, (size_t)128 * 128 * 9);
 
+    timer.lap("device copies");
     // ---- edge sampling structures ----
     if (s.use_primary_edges || s.use_secondary_edges) s.edges = build_edge_data(s);
+    timer.lap("edge structures");
+    {
+        s.bvh_host = bvh_job.get();
+        s.bvh.num_nodes = (int)s.bvh_host.nodes.size();
+        s.bvh.num_tris = (int)s.bvh_host.ids.size() / 2;
+        s.bvh.stack_need = s.bvh_host.depth + 2;
+        s.bvh.nodes = to_device(s, s.bvh_host.nodes.data(), s.bvh_host.nodes.size());
+        s.bvh.tris = to_device(s, s.bvh_host.tris.data(), s.bvh_host.tris.size());
+        s.bvh.ids = to_device(s, s.bvh_host.ids.data(), s.bvh_host.ids.size());
+        timer.lap("triangle hierarchy (wait)");
+    }
     return sp.release();
 }
 

@@ -14,6 +14,25 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+namespace rdr {
+struct PhaseTimer {         // RDR_DEBUG_DUMP: wall time of the scene-build phases on stderr
+    const char *group;
+    const bool on = std::getenv("RDR_DEBUG_DUMP") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    explicit PhaseTimer(const char *g) : group(g) {}
+    void lap(const char *what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[redner_amd] %s: %-24s %7.2f ms\n", group, what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+}
+
 namespace rdr {
 
 struct EdgeData;   // edges.h
