@@ -47,6 +47,7 @@ inline void launch_persistent(int n, const W &w) {          // see hip/exec.h: b
 
 // ---- host stand-ins for the hand-written kernels (compact.hip / trace.hip) ----------------------
 #include "bvh.h"
+#include "trace_sim.h"
 namespace exec {
 inline void select_device(int /*use_gpu*/, int /*gpu_index*/) {}
 template <class P>
@@ -60,6 +61,8 @@ inline TraceStats &trace_stats() { static TraceStats s; return s; }
 inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n, bool any) {
     TraceStats &st = trace_stats();
     rt::Counters cnt{0, 0};
+    static const bool sim = std::getenv("RDR_TRACE_SIM") != nullptr;
+    if (sim) tracesim::launch(bvh, rays, n, any);
     for (int i = 0; i < n; ++i) {
         const rt::RayRec &r = rays[i];
         rt::Hit h{0.f, -1, -1};

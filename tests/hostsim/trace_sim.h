@@ -1,0 +1,243 @@
+// trace_sim.h -- TEST INFRASTRUCTURE (debug harness only): models how the lanes of a 64-wide wave would spend
+// their vector-ALU cycles in the traversal kernel under different loop shapes / ray orders, from the real ray
+// queues of a render.  Enabled with RDR_TRACE_SIM=1; prints a summary at exit.  Costs are instruction counts read
+// off the gfx950 ISA of trace.hip: inner step ~110, triangle test ~190, ray set-up ~150.
+#pragma once
+#include "bvh.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+namespace tracesim {
+
+struct Seg { int inner; int tris; };            // inner steps, then one leaf with `tris` triangle tests (0 = none: end)
+using Path = std::vector<Seg>;
+
+template <bool ANY>
+inline Path record(const rt::BvhD &bvh, const float o[3], const float d[3], float tnear, float tfar) {
+    using namespace rt;
+    Path path;
+    Hit best{tfar, -1, -1};
+    const float inv[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};
+    int stack[kTraverseStack]; int sp = 0; float tn;
+    const Node &root = bvh.nodes[0];
+    if (!ray_box(o, inv, tnear, tfar, root.lo, root.hi, &tn)) return path;
+    int ca = root.a, cb = root.b;
+    for (;;) {
+        int inner = 0;
+        while (cb == 0) {
+            ++inner;
+            const Node l = bvh.nodes[ca], r = bvh.nodes[ca + 1];
+            const float lim = best.shape < 0 ? tfar : best.t * 1.0000004f + 1e-30f;
+            float tl, tr;
+            const bool hl = ray_box(o, inv, tnear, lim, l.lo, l.hi, &tl);
+            const bool hr = ray_box(o, inv, tnear, lim, r.lo, r.hi, &tr);
+            if (hl || hr) {
+                const bool lf = !hr || (hl && !(tr < tl));
+                if (hl && hr) stack[sp++] = lf ? ca + 1 : ca;
+                ca = lf ? l.a : r.a; cb = lf ? l.b : r.b;
+            } else if (sp == 0) cb = -1;
+            else { const Node &nx = bvh.nodes[stack[--sp]]; ca = nx.a; cb = nx.b; }
+        }
+        if (cb < 0) { if (inner) path.push_back(Seg{inner, 0}); break; }
+        path.push_back(Seg{inner, cb});
+        bool stop = false;
+        for (int k = 0; k < cb; ++k) {
+            const int slot = ca + k;
+            const float *t = bvh.tris + 9 * slot;
+            float th;
+            if (ray_triangle(o, d, tnear, tfar, t, t + 3, t + 6, &th)) {
+                const int s = bvh.ids[2 * slot], p = bvh.ids[2 * slot + 1];
+                if (ANY) { stop = true; break; }
+                if (closer(th, s, p, best)) best = Hit{th, s, p};
+            }
+        }
+        if (stop || sp == 0) break;
+        const Node &nx = bvh.nodes[stack[--sp]]; ca = nx.a; cb = nx.b;
+    }
+    return path;
+}
+
+constexpr double Ci = 110, Ct = 190, Cr = 150;
+
+struct Tot { double vote[4] = {0, 0, 0, 0}, vote_sorted[4] = {0, 0, 0, 0}; double useful = 0, ifif = 0, whilewhile = 0, ww_sorted = 0, refill8 = 0, refill24 = 0, refill_sorted = 0; long rays = 0, live = 0; };
+inline Tot &tot(bool any) { static Tot t[2]; return t[any ? 1 : 0]; }
+
+inline double useful_of(const Path &p) { double c = 0; for (const Seg &s : p) c += Ci * s.inner + Ct * s.tris; return c; }
+
+// one wave, one ray per lane, "if-if": every iteration each lane does its next op (inner step or whole leaf)
+inline double sim_ifif(const Path *const *lanes, int n) {
+    std::vector<size_t> seg(n, 0); std::vector<int> done_inner(n, 0);
+    double cost = 0;
+    for (;;) {
+        bool any_i = false; int max_t = 0; bool alive = false;
+        for (int l = 0; l < n; ++l) {
+            const Path &p = *lanes[l];
+            if (seg[l] >= p.size()) continue;
+            alive = true;
+            const Seg &s = p[seg[l]];
+            if (done_inner[l] < s.inner) { any_i = true; ++done_inner[l]; if (done_inner[l] == s.inner && s.tris == 0) { ++seg[l]; done_inner[l] = 0; } }
+            else { max_t = std::max(max_t, s.tris); ++seg[l]; done_inner[l] = 0; }
+        }
+        if (!alive) break;
+        cost += (any_i ? Ci : 0) + Ct * max_t;
+    }
+    return cost;
+}
+inline double sim_ww(const Path *const *lanes, int n) {
+    std::vector<size_t> seg(n, 0);
+    double cost = 0;
+    for (;;) {
+        int max_i = 0, max_t = 0; bool alive = false;
+        for (int l = 0; l < n; ++l) {
+            const Path &p = *lanes[l];
+            if (seg[l] >= p.size()) continue;
+            alive = true;
+            max_i = std::max(max_i, p[seg[l]].inner); max_t = std::max(max_t, p[seg[l]].tris);
+            ++seg[l];
+        }
+        if (!alive) break;
+        cost += Ci * max_i + Ct * max_t;
+    }
+    return cost;
+}
+// persistent wave over a whole queue, while-while, lanes refilled when >= `idle_min` of them are idle
+inline double sim_refill(const std::vector<const Path *> &q, int idle_min) {
+    size_t next = 0;
+    const Path *cur[64]; size_t seg[64];
+    for (int l = 0; l < 64; ++l) cur[l] = nullptr;
+    double cost = 0;
+    for (;;) {
+        int idle = 0;
+        for (int l = 0; l < 64; ++l) if (!cur[l]) ++idle;
+        if (idle == 64 && next >= q.size()) break;
+        if ((idle >= idle_min || idle == 64) && next < q.size()) {
+            for (int l = 0; l < 64 && next < q.size(); ++l) if (!cur[l]) { cur[l] = q[next++]; seg[l] = 0; if (cur[l]->empty()) cur[l] = nullptr; }
+            cost += Cr;
+        }
+        int max_i = 0, max_t = 0; bool alive = false;
+        for (int l = 0; l < 64; ++l) {
+            if (!cur[l]) continue;
+            alive = true;
+            const Seg &s = (*cur[l])[seg[l]];
+            max_i = std::max(max_i, s.inner); max_t = std::max(max_t, s.tris);
+            if (++seg[l] >= cur[l]->size()) cur[l] = nullptr;
+        }
+        if (alive) cost += Ci * max_i + Ct * max_t;
+    }
+    return cost;
+}
+
+// persistent wave, lanes refilled when >= idle_min are idle; inner steps run one at a time for the lanes that are
+// not parked on a leaf, and the parked leaves are tested (one triangle per lane per step) as soon as at least
+// `park_min` lanes are parked or nobody can do an inner step
+inline double sim_vote(const std::vector<const Path *> &q, int idle_min, int park_min) {
+    size_t next = 0;
+    const Path *cur[64]; size_t seg[64]; int inner_left[64], tris_left[64];
+    for (int l = 0; l < 64; ++l) cur[l] = nullptr;
+    double cost = 0;
+    auto load_seg = [&](int l) {
+        while (cur[l]) {
+            if (seg[l] >= cur[l]->size()) { cur[l] = nullptr; break; }
+            inner_left[l] = (*cur[l])[seg[l]].inner; tris_left[l] = (*cur[l])[seg[l]].tris;
+            if (inner_left[l] == 0 && tris_left[l] == 0) { ++seg[l]; continue; }
+            break;
+        }
+    };
+    for (;;) {
+        int idle = 0;
+        for (int l = 0; l < 64; ++l) if (!cur[l]) ++idle;
+        if (idle == 64 && next >= q.size()) break;
+        if ((idle >= idle_min || idle == 64) && next < q.size()) {
+            for (int l = 0; l < 64 && next < q.size(); ++l) if (!cur[l]) { cur[l] = q[next++]; seg[l] = 0; load_seg(l); }
+            cost += Cr;
+        }
+        int want_inner = 0, parked = 0;
+        for (int l = 0; l < 64; ++l) if (cur[l]) { if (inner_left[l] > 0) ++want_inner; else ++parked; }
+        if (want_inner == 0 && parked == 0) continue;
+        if (parked >= park_min || want_inner == 0) {
+            cost += Ct;
+            for (int l = 0; l < 64; ++l) if (cur[l] && inner_left[l] == 0) { if (--tris_left[l] == 0) { ++seg[l]; load_seg(l); } }
+        } else {
+            cost += Ci;
+            for (int l = 0; l < 64; ++l) if (cur[l] && inner_left[l] > 0) { --inner_left[l]; if (inner_left[l] == 0 && tris_left[l] == 0) { ++seg[l]; load_seg(l); } }
+        }
+    }
+    return cost;
+}
+
+// RDR_TRACE_SIM_KEY: "<bits per axis of the origin grid><o|n: with / without the direction octant><f|l: octant first / last>"
+inline unsigned sort_key(const rt::BvhD &bvh, const rt::RayRec &r) {
+    static const char *mode = std::getenv("RDR_TRACE_SIM_KEY") ? std::getenv("RDR_TRACE_SIM_KEY") : "4ol";
+    const int bits = mode[0] - '0';
+    const bool with_oct = mode[1] == 'o', oct_first = mode[2] == 'f';
+    const rt::Node &root = bvh.nodes[0];
+    unsigned key = 0;
+    const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+    unsigned c[3];
+    for (int k = 0; k < 3; ++k) {
+        float u = (o[k] - root.lo[k]) / (root.hi[k] - root.lo[k]);
+        c[k] = (unsigned)std::min((float)((1 << bits) - 1), std::max(0.f, u * (float)(1 << bits)));
+    }
+    unsigned oct = 0;
+    for (int k = 0; k < 3; ++k) oct = (oct << 1) | (d[k] < 0 ? 1u : 0u);
+    if (with_oct && oct_first) key = oct;
+    for (int b = bits - 1; b >= 0; --b) for (int k = 0; k < 3; ++k) key = (key << 1) | ((c[k] >> b) & 1u);
+    if (with_oct && !oct_first) key = (key << 3) | oct;
+    return key;
+}
+
+inline void report() {
+    for (int a = 0; a < 2; ++a) {
+        const Tot &t = tot(a != 0);
+        if (!t.rays) continue;
+        std::fprintf(stderr, "[trace_sim] %s: %ld rays (%ld live), useful %.0f/ray; wave cost per ray and lane efficiency:\n", a ? "any-hit" : "closest", t.rays, t.live, t.useful / t.rays);
+        auto line = [&](const char *name, double c) { std::fprintf(stderr, "[trace_sim]   %-28s %8.0f  eff %.2f\n", name, c * 64 / t.rays, t.useful / (c * 64)); };
+        line("if-if", t.ifif); line("while-while", t.whilewhile); line("while-while, sorted rays", t.ww_sorted);
+        const int parks[4] = {8, 16, 32, 48};
+        for (int i = 0; i < 4; ++i) { char nm[64]; std::snprintf(nm, sizeof nm, "vote park>=%d", parks[i]); line(nm, t.vote[i]); }
+        for (int i = 0; i < 4; ++i) { char nm[64]; std::snprintf(nm, sizeof nm, "vote park>=%d, sorted", parks[i]); line(nm, t.vote_sorted[i]); }
+        line("refill (>= 8 idle)", t.refill8); line("refill (>= 24 idle)", t.refill24); line("refill (>= 8), sorted", t.refill_sorted);
+    }
+}
+
+inline void launch(const rt::BvhD &bvh, const rt::RayRec *rays, int n, bool any) {
+    static bool registered = false;
+    if (!registered) { registered = true; std::atexit(report); }
+    std::vector<Path> paths(n);
+    Tot &t = tot(any);
+    for (int i = 0; i < n; ++i) {
+        const rt::RayRec &r = rays[i];
+        if (r.tmax < 0.f) continue;
+        float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+        paths[i] = any ? record<true>(bvh, o, d, r.tmin, r.tmax) : record<false>(bvh, o, d, r.tmin, r.tmax);
+        t.useful += useful_of(paths[i]);
+        ++t.live;
+    }
+    t.rays += n;
+    std::vector<const Path *> q(n);
+    for (int i = 0; i < n; ++i) q[i] = &paths[i];
+    for (int w = 0; w < n; w += 64) { int m = std::min(64, n - w); t.ifif += sim_ifif(q.data() + w, m); t.whilewhile += sim_ww(q.data() + w, m); }
+    t.refill8 += sim_refill(q, 8); t.refill24 += sim_refill(q, 24);
+    { const int parks[4] = {8, 16, 32, 48}; for (int i = 0; i < 4; ++i) t.vote[i] += sim_vote(q, 8, parks[i]); }
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::vector<unsigned> key(n);
+    for (int i = 0; i < n; ++i) key[i] = rays[i].tmax < 0.f ? 0xffffffffu : sort_key(bvh, rays[i]);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return key[x] < key[y]; });
+    std::vector<const Path *> qs(n);
+    for (int i = 0; i < n; ++i) qs[i] = &paths[order[i]];
+    for (int w = 0; w < n; w += 64) { int m = std::min(64, n - w); t.ww_sorted += sim_ww(qs.data() + w, m); }
+    t.refill_sorted += sim_refill(qs, 8);
+    if (std::getenv("RDR_TRACE_SIM_LAUNCHES")) {
+        double u = 0, c0 = 0, c1 = 0; long live = 0;
+        for (int i = 0; i < n; ++i) { u += useful_of(paths[i]); if (!(rays[i].tmax < 0.f)) ++live; }
+        for (int w = 0; w < n; w += 64) { int m = std::min(64, n - w); c0 += sim_ifif(q.data() + w, m); c1 += sim_ww(qs.data() + w, m); }
+        static int ordinal = 0;
+        std::fprintf(stderr, "[trace_sim] launch %3d %s n=%7d live=%7ld useful/ray=%6.0f wave-cost/ray: plain %6.0f sorted %6.0f  eff %.2f -> %.2f\n", ordinal++, any ? "any    " : "closest", n, live, u / n, c0 * 64 / n, c1 * 64 / n, u / (c0 * 64), u / (c1 * 64));
+    }
+    { const int parks[4] = {8, 16, 32, 48}; for (int i = 0; i < 4; ++i) t.vote_sorted[i] += sim_vote(qs, 8, parks[i]); }
+}
+
+} // namespace tracesim
