@@ -113,6 +113,25 @@ inline void download(void *dst, const void *src, size_t bytes) {
 }
 inline void sync() { check(hipStreamSynchronize(ctx().stream), "sync"); }
 
+// Side streams for stages that do not depend on each other (the edge-pick walks and the bounce adjoint of one path
+// depth): each of them keeps a fraction of the lanes busy and waits on dependent loads, so they fill each other's gaps.
+// StreamScope redirects every launch made inside it; Fence orders two streams (record on the producer, gate the consumer).
+hipStream_t side_stream(int k);          // trace.hip: two non-blocking streams per device, created on first use
+struct StreamScope {
+    hipStream_t saved;
+    explicit StreamScope(hipStream_t s) : saved(ctx().stream) { ctx().stream = s; }
+    ~StreamScope() { ctx().stream = saved; }
+    StreamScope(const StreamScope &) = delete;
+};
+struct Fence {
+    hipEvent_t e = nullptr;
+    Fence() { check(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"); }
+    ~Fence() { if (e) (void)hipEventDestroy(e); }
+    Fence(const Fence &) = delete;
+    void after(hipStream_t producer) { check(hipEventRecord(e, producer), "hipEventRecord"); }
+    void gate(hipStream_t consumer) { check(hipStreamWaitEvent(consumer, e, 0), "hipStreamWaitEvent"); }
+};
+
 // Replicated gradient accumulators (see GradStore in render.cpp): up to 256 replicas, as many as
 // fit in 256 MiB.  Must be called from the translation unit that instantiates the stage kernels.
 inline int choose_replicas(size_t replica_bytes) {

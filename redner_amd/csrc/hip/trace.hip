@@ -73,6 +73,15 @@ __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayR
     hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};
 }
 
+hipStream_t side_stream(int k) {
+    static thread_local hipStream_t streams[16][2] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipStream_t &s = streams[dev & 15][k & 1];
+    if (!s) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+    return s;
+}
+
 int *persistent_counter() {
     static int *ring = nullptr;
     static int slot = 0;

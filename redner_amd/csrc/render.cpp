@@ -268,6 +268,7 @@ struct Backward {
                 exec::zero(ea.erd, sizeof(double) * 12 * L);
             }
             for (int k = 0; k < 3; ++k) elist[k] = arena.get<int>(L);
+            nee_slots = arena.get<int>(P);
             edge_contrib = arena.get<double>(L);
             edge_tmin = arena.get<double>(L);
             hit_pos = arena.get<double>((size_t)3 * L);
@@ -288,6 +289,9 @@ struct Backward {
 
     VSlice ea, eb;                 // ping-pong vertex slices of the edge sub-paths (2P lanes each)
     int *elist[3] = {nullptr, nullptr, nullptr};
+    int *nee_slots = nullptr;                  // slots of the NEE-mode edge pick (its walk runs beside the hierarchical pick)
+    exec::Fence depth_begin, adjoint_done, setup_done, walk_done;
+    const bool overlap = std::getenv("RDR_NO_OVERLAP") == nullptr && std::getenv("RDR_DEBUG_DUMP") == nullptr;
     double *edge_contrib = nullptr, *edge_tmin = nullptr, *hit_pos = nullptr;
     PrimaryEdgeRec *prim_recs = nullptr;
     SecondaryEdgeRec *sec_recs = nullptr;
@@ -307,10 +311,10 @@ struct Backward {
             if (LEAN) exec::launch_persistent(nN, LeanWalk<decltype(walk)>{walk});
             else exec::launch_persistent(nN, walk);
         };
-        if (need <= 24) go(SecEdgePickNWalk<24>{sa, elist[0], sec_picks});
-        else if (need <= 32) go(SecEdgePickNWalk<32>{sa, elist[0], sec_picks});
-        else if (need <= 48) go(SecEdgePickNWalk<48>{sa, elist[0], sec_picks});
-        else go(SecEdgePickNWalk<64>{sa, elist[0], sec_picks});
+        if (need <= 24) go(SecEdgePickNWalk<24>{sa, nee_slots, sec_picks});
+        else if (need <= 32) go(SecEdgePickNWalk<32>{sa, nee_slots, sec_picks});
+        else if (need <= 48) go(SecEdgePickNWalk<48>{sa, nee_slots, sec_picks});
+        else go(SecEdgePickNWalk<64>{sa, nee_slots, sec_picks});
     }
 
     int trace_edge_paths(const SamplerD &rng_edge, int edim, int n_act, int n_slots, int first_depth, const Queues &q,
@@ -347,21 +351,42 @@ struct Backward {
             if (nA <= 0) continue;
             const int *act = active + (size_t)d * P;
             AdjBounceArgs ba{scene.d, grads.g, rng, dim0 + 7 * d, act, vs[d], vs[d + 1], d_image, nd, radiance_dim, weight, adj};
-            launch_v(lean, nA, AdjBounceScatter{ba});
-            launch_v(lean, nA, AdjBounceNee{ba});
-            if (edges_on && scene.use_secondary_edges) {
+            const bool with_edges = edges_on && scene.use_secondary_edges;
+            // The bounce adjoint of this depth, the hierarchical edge pick and the NEE-mode edge-pick walk do not depend on
+            // each other (the edge pass touches the adjoint records only in SecondaryEdgeDerivatives); each of them keeps a
+            // fraction of the lanes busy, so they run on three streams and are joined before the records are needed.
+            hipStream_t main_stream = exec::ctx().stream;
+            const bool side = overlap && with_edges;
+            if (side) {
+                depth_begin.after(main_stream);
+                exec::StreamScope on(exec::side_stream(0));
+                depth_begin.gate(exec::ctx().stream);
+                launch_v(lean, nA, AdjBounceScatter{ba});
+                launch_v(lean, nA, AdjBounceNee{ba});
+                adjoint_done.after(exec::ctx().stream);
+            } else {
+                launch_v(lean, nA, AdjBounceScatter{ba});
+                launch_v(lean, nA, AdjBounceNee{ba});
+            }
+            if (with_edges) {
                 // ---- secondary (shadow / inter-reflection) edges at this vertex, :500-706 ----
                 const EdgeSceneD &es = scene.edges->d;
                 const int lanes = 2 * nA;
                 SecEdgeArgs sa{scene.d, es, rng, dim0 + 7 * d, edge_rng_at(rng_edge, edim), edim, act, vs[d]};
                 launch_v(lean, nA, SecEdgeSetup{sa, sec_mode, sec_recs, sec_picks, ea, edge_tmin});
                 int nH = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 1});
-                launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
-                int nN = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 2});
+                int nN = exec::compact((const int *)nullptr, nA, nee_slots, KeepMode{sec_mode, 2});
                 const int need = es.max_stack;
-                // NEE-mode pick: persistent waves (walk lengths: median 20, p95 640 steps)
-                if (lean) launch_pick_n<true>(need, nN, sa);
-                else launch_pick_n<false>(need, nN, sa);
+                {   // NEE-mode pick: persistent waves (walk lengths: median 20, p95 640 steps)
+                    if (side) setup_done.after(main_stream);
+                    exec::StreamScope on(side ? exec::side_stream(1) : main_stream);
+                    if (side) setup_done.gate(exec::ctx().stream);
+                    if (lean) launch_pick_n<true>(need, nN, sa);
+                    else launch_pick_n<false>(need, nN, sa);
+                    if (side) walk_done.after(exec::ctx().stream);
+                }
+                launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
+                if (side) { walk_done.gate(main_stream); adjoint_done.gate(main_stream); }
                 if (nH == 0 && nN == 0) {
                     // no slot samples an edge here (typically: every path already passed a diffuse vertex,
                     // src/edge.cpp:1396-1401); only the sampler bookkeeping of the skipped stages remains
@@ -433,6 +458,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     const bool has_lights = scene.d.num_lights > 0;
     if (2 + 7 * B > kSamplerDims) throw std::runtime_error("render: max_bounces exceeds the Sobol' table");
 
+    PhaseTimer timer(d_image ? "render (backward)" : "render (forward)");
     Arena arena;
     {
         int *ids = arena.get<int>(kMaxChannels);
@@ -457,6 +483,8 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     }
 
     const bool lean = scene_is_lean(scene, lay.ch);
+    if (timer.on) exec::sync();
+    timer.lap("buffers, accumulators");
     for (int s = 0; s < opt.num_samples; ++s) {
         const int sample_id = opt.sample_offset + s;
         SamplerD rng{scene.sobol_table, opt.seed, sample_id, pcg_main, 0};
@@ -480,8 +508,11 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         if (bwd) bwd->run_sample(sample_id, rng, vs, active, num_active, q);
         if (pcg_main) exec::launch(P, PcgAdvance{pcg_main, dim});     // every slot drew `dim` numbers this sample
     }
+    if (timer.on) exec::sync();
+    timer.lap("samples");
     if (bwd) bwd->flush();
     exec::sync();
+    timer.lap("gradient flush");
 }
 
 } // namespace rdr

@@ -33,6 +33,14 @@ inline void zero(void *p, size_t bytes) { memset(p, 0, bytes); }
 inline void upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void download(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void sync() {}
+}
+typedef void *hipStream_t;       // the host driver names streams; the harness has one implicit stream
+namespace exec {
+struct Context { hipStream_t stream = nullptr; };
+inline Context &ctx() { static Context c; return c; }
+inline hipStream_t side_stream(int) { return nullptr; }
+struct StreamScope { explicit StreamScope(hipStream_t) {} ~StreamScope() {} };
+struct Fence { void after(hipStream_t) {} void gate(hipStream_t) {} };
 template <class F>
 inline void launch(int n, const F &f) { for (int i = 0; i < n; ++i) f(i); }
 template <class W>

@@ -1,0 +1,35 @@
+"""Wall time per optimisation-loop iteration at the sizes pyredner loops typically run (256x256, 4 spp): every
+iteration builds the Scene, renders forward and backward -- as pyredner.RenderFunction does (render_pytorch.py:609)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+from redner_amd import redner as rd
+from redner_amd.render_pytorch import RenderFunction
+import scenes
+
+dev = torch.device('cuda:0')
+res = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+sc = scenes.bunny_box(dev, resolution=(res, res))
+verts = [s.vertices for s in sc.shapes]
+for v in verts:
+    v.requires_grad_(True)
+times = []
+for it in range(12):
+    torch.cuda.synchronize()
+    t0 = time.time()
+    args = RenderFunction.serialize_scene(sc, spp, 4, sampler_type=rd.SamplerType.sobol, device=dev, backend=rd)
+    t1 = time.time()
+    img = RenderFunction.apply(it + 1, *args)
+    torch.cuda.synchronize()
+    t2 = time.time()
+    img.sum().backward()
+    torch.cuda.synchronize()
+    t3 = time.time()
+    times.append((t1 - t0, t2 - t1, t3 - t2))
+for name, k in (('serialize', 0), ('forward (Scene + render)', 1), ('backward', 2)):
+    xs = sorted(t[k] for t in times[2:])
+    print('%-26s median %.2f ms  min %.2f ms' % (name, xs[len(xs) // 2] * 1e3, xs[0] * 1e3))
+tot = sorted(sum(t) for t in times[2:])
+print('iteration                  median %.2f ms  (%dx%d, %d spp: %.2f Msamples/s)' % (tot[len(tot) // 2] * 1e3, res, res, spp, res * res * spp / tot[len(tot) // 2] / 1e6))
