@@ -11,7 +11,7 @@
 
 namespace exec {
 
-Context &ctx() { static Context c; return c; }
+Context &ctx() { static thread_local Context c; return c; }
 
 void select_device(int use_gpu, int gpu_index) {
     if (!use_gpu)
@@ -83,8 +83,8 @@ hipStream_t side_stream(int k) {
 }
 
 int *persistent_counter() {
-    static int *ring = nullptr;
-    static int slot = 0;
+    static thread_local int *ring = nullptr;        // per host thread: its launches are ordered on its own streams
+    static thread_local int slot = 0;
     constexpr int kRing = 4096;
     if (!ring) ring = (int *)dmalloc(sizeof(int) * kRing);
     if (slot == 0) zero(ring, sizeof(int) * kRing);        // stream-ordered: re-zeroed once per lap

@@ -7,6 +7,7 @@
 // the reference's, because sample-exact parity depends on it; how a bounce is cut into kernels
 // and what is kept in HBM is ours (stages_fwd.h / stages_bwd.h / stages_edge.h).
 #include "render.h"
+#include <exception>
 #include <cstdio>
 #include <cstdlib>
 #include "stages_fwd.h"
@@ -238,7 +239,7 @@ struct GradStore {
 struct Backward {
     const Scene &scene; const rdr_render_options &opt;
     int P, B; const float *d_image; float *screen_grad; double weight; int nd, radiance_dim;
-    GradStore grads;
+    GradStore &grads;              // shared by the sample workers: every add is an atomic
     Arena arena;
     AdjState adj;
 
@@ -247,10 +248,10 @@ struct Backward {
     uint64_t *pcg_edge = nullptr;      // PCG edge sampler: one state per slot (src/pathtracer.cpp:221-222)
     double *multipliers = nullptr;     // [2P x nd], primary-edge channel weights (non-radiance channels only)
 
-    Backward(const Scene &scene_, const rdr_render_options &opt_, const rdr_dscene_desc &ds, int P_, int B_,
+    Backward(const Scene &scene_, const rdr_render_options &opt_, GradStore &grads_, int P_, int B_,
              const float *d_image_, float *screen_grad_, double weight_, int nd_, int radiance_dim_, const ChannelsD &ch_)
         : scene(scene_), opt(opt_), P(P_), B(B_), d_image(d_image_), screen_grad(screen_grad_), weight(weight_),
-          nd(nd_), radiance_dim(radiance_dim_), grads(scene_, ds), ch(ch_) {
+          nd(nd_), radiance_dim(radiance_dim_), grads(grads_), ch(ch_) {
         lean = scene_is_lean(scene, ch);
         adj.n = P; adj.plain = 0;
         adj.thr = arena.get<double>((size_t)3 * P);
@@ -434,7 +435,6 @@ struct Backward {
             launch_v(lean, P, PrimaryEdgeDerivatives{scene.d, grads.g, prim_recs, edge_contrib, screen_grad});
         }
     }
-    void flush() { grads.flush(); }
 };
 
 } // namespace
@@ -465,52 +465,98 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         exec::upload(ids, opt.channels, sizeof(int) * opt.num_channels);
         lay.ch.id = ids;
     }
-    std::vector<VSlice> vs(B + 1);
-    for (int d = 0; d <= B; ++d) vs[d] = make_slice(arena, P, d < B);
-    int *active = arena.get<int>((size_t)(B + 1) * P);
-    Queues q;
-    q.nee = arena.get<rt::RayRec>((size_t)2 * P); q.bsdf = arena.get<rt::RayRec>((size_t)2 * P);
-    q.h_nee = arena.get<rt::HitRec>((size_t)2 * P); q.h_bsdf = arena.get<rt::HitRec>((size_t)2 * P);
-    std::vector<int> num_active(B + 2, 0);
-
-    std::unique_ptr<Backward> bwd;
-    if (d_image) bwd.reset(new Backward(scene, opt, *d_scene, P, B, d_image, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch));
+    std::unique_ptr<GradStore> grads;
+    if (d_image) grads.reset(new GradStore(scene, *d_scene));
 
     uint64_t *pcg_main = nullptr;
     if (opt.sampler_type == RDR_SAMPLER_INDEPENDENT) {
         pcg_main = arena.get<uint64_t>(P);
         exec::launch(P, PcgInit{pcg_main, pcg_stream_seed(opt)});
     }
-
     const bool lean = scene_is_lean(scene, lay.ch);
+
+    // Everything one sample needs between its camera rays and its last gradient add.
+    struct Worker {
+        Arena arena;
+        std::vector<VSlice> vs;
+        int *active = nullptr;
+        Queues q;
+        std::vector<int> num_active;
+        std::unique_ptr<Backward> bwd;
+    };
+    auto make_worker = [&](Worker &w) {
+        w.vs.resize(B + 1);
+        for (int d = 0; d <= B; ++d) w.vs[d] = make_slice(w.arena, P, d < B);
+        w.active = w.arena.get<int>((size_t)(B + 1) * P);
+        w.q.nee = w.arena.get<rt::RayRec>((size_t)2 * P); w.q.bsdf = w.arena.get<rt::RayRec>((size_t)2 * P);
+        w.q.h_nee = w.arena.get<rt::HitRec>((size_t)2 * P); w.q.h_bsdf = w.arena.get<rt::HitRec>((size_t)2 * P);
+        w.num_active.assign(B + 2, 0);
+        if (d_image) w.bwd.reset(new Backward(scene, opt, *grads, P, B, d_image, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch));
+    };
+    // samples first, first + stride, ... on the calling thread's stream
+    auto run_samples = [&](Worker &w, int first, int stride) {
+        std::vector<VSlice> &vs = w.vs;
+        int *active = w.active;
+        const Queues &q = w.q;
+        std::vector<int> &num_active = w.num_active;
+        for (int s = first; s < opt.num_samples; s += stride) {
+            const int sample_id = opt.sample_offset + s;
+            SamplerD rng{scene.sobol_table, opt.seed, sample_id, pcg_main, 0};
+            Sink sink{image, nullptr, lay.nd, lay.radiance_dim, weight, lay.ch, nullptr};
+
+            // ---- camera vertex ----
+            launch_v(lean, P, GenPrimary{scene.d, rng, opt.sample_pixel_center, vs[0], q.bsdf});
+            exec::trace(scene.bvh, q.bsdf, q.h_bsdf, P, false);
+            launch_v(lean, P, ShadePrimary{scene.d, nullptr, vs[0], q.h_bsdf, sink});
+            std::fill(num_active.begin(), num_active.end(), 0);
+            num_active[0] = exec::compact((const int *)nullptr, P, active, KeepHit{vs[0].shape});
+
+            // ---- bounces (src/pathtracer.cpp:292-390) ----
+            int dim = opt.sample_pixel_center ? 0 : 2;
+            for (int d = 0; d < B && num_active[d] > 0 && has_lights; ++d) {
+                num_active[d + 1] = run_bounce(scene, rng, dim, 0, active + (size_t)d * P, num_active[d],
+                                               vs[d], vs[d + 1], q, sink, active + (size_t)(d + 1) * P);
+                dim += 7;
+            }
+
+            if (w.bwd) w.bwd->run_sample(sample_id, rng, vs, active, num_active, q);
+            if (pcg_main) exec::launch(P, PcgAdvance{pcg_main, dim});     // every slot drew `dim` numbers this sample
+        }
+    };
+
+    // Several samples in flight (backward pass, lean scenes, Sobol' sampler): the samples of a gradient render are
+    // independent -- no image is written, the sampler is stateless, gradient adds are atomics -- and at the sizes
+    // optimisation loops run at (256x256, a few spp) one sample is a chain of short, latency-bound launches, so helper
+    // host threads drive samples k, k + workers, ... on their own streams with their own buffers.  The forward image
+    // needs its fp32 adds in sample order and stays on one stream.
+    int workers = 1;
+    if (d_image != nullptr && image == nullptr && lean && opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on)
+        workers = std::max(1, std::min(exec::sample_workers(P), opt.num_samples));
+    Worker w0;
+    make_worker(w0);
     if (timer.on) exec::sync();
     timer.lap("buffers, accumulators");
-    for (int s = 0; s < opt.num_samples; ++s) {
-        const int sample_id = opt.sample_offset + s;
-        SamplerD rng{scene.sobol_table, opt.seed, sample_id, pcg_main, 0};
-        Sink sink{image, nullptr, lay.nd, lay.radiance_dim, weight, lay.ch, nullptr};
-
-        // ---- camera vertex ----
-        launch_v(lean, P, GenPrimary{scene.d, rng, opt.sample_pixel_center, vs[0], q.bsdf});
-        exec::trace(scene.bvh, q.bsdf, q.h_bsdf, P, false);
-        launch_v(lean, P, ShadePrimary{scene.d, nullptr, vs[0], q.h_bsdf, sink});
-        std::fill(num_active.begin(), num_active.end(), 0);
-        num_active[0] = exec::compact((const int *)nullptr, P, active, KeepHit{vs[0].shape});
-
-        // ---- bounces (src/pathtracer.cpp:292-390) ----
-        int dim = opt.sample_pixel_center ? 0 : 2;
-        for (int d = 0; d < B && num_active[d] > 0 && has_lights; ++d) {
-            num_active[d + 1] = run_bounce(scene, rng, dim, 0, active + (size_t)d * P, num_active[d],
-                                           vs[d], vs[d + 1], q, sink, active + (size_t)(d + 1) * P);
-            dim += 7;
+    if (workers == 1) {
+        run_samples(w0, 0, 1);
+    } else {
+        exec::sync();                          // accumulators zeroed, tables uploaded: visible to the other streams
+        for (int k = 1; k < workers; ++k)
+            exec::SecondThread::get(k - 1).start([&, k] {
+                Worker w;
+                make_worker(w);
+                run_samples(w, k, workers);
+                exec::sync();
+            });
+        std::exception_ptr failure;
+        try { run_samples(w0, 0, workers); } catch (...) { failure = std::current_exception(); }
+        for (int k = 1; k < workers; ++k) {
+            try { exec::SecondThread::get(k - 1).wait(); } catch (...) { if (!failure) failure = std::current_exception(); }
         }
-
-        if (bwd) bwd->run_sample(sample_id, rng, vs, active, num_active, q);
-        if (pcg_main) exec::launch(P, PcgAdvance{pcg_main, dim});     // every slot drew `dim` numbers this sample
+        if (failure) std::rethrow_exception(failure);
     }
     if (timer.on) exec::sync();
     timer.lap("samples");
-    if (bwd) bwd->flush();
+    if (grads) grads->flush();
     exec::sync();
     timer.lap("gradient flush");
 }
