@@ -112,8 +112,25 @@ int run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng_shift,
                const Queues &q, const Sink &sink, int *next_active) {
     const bool lean = scene_is_lean(scene, sink.ch);
     launch_v(lean, num_active, BounceSample{scene.d, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
-    exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true);
-    exec::trace(scene.bvh, q.bsdf, q.h_bsdf, num_active, false);
+    // the shadow-ray and the continuation-ray queue are traced side by side: both kernels wait on dependent loads
+    // with a fraction of their lanes active (profiles/r1_notes.md), so they fill each other's gaps
+    static const bool side = std::getenv("RDR_NO_OVERLAP") == nullptr;
+    if (side) {
+        static thread_local exec::Fence *queued = new exec::Fence(), *shadow_done = new exec::Fence();   // per host thread
+        hipStream_t main_stream = exec::ctx().stream;
+        queued->after(main_stream);
+        {
+            exec::StreamScope on(exec::side_stream(1));
+            queued->gate(exec::ctx().stream);
+            exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true);
+            shadow_done->after(exec::ctx().stream);
+        }
+        exec::trace(scene.bvh, q.bsdf, q.h_bsdf, num_active, false);
+        shadow_done->gate(main_stream);
+    } else {
+        exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true);
+        exec::trace(scene.bvh, q.bsdf, q.h_bsdf, num_active, false);
+    }
     launch_v(lean, num_active, BounceContrib{scene.d, rng, dim, rng_shift, active, v, vn, q.h_nee, q.h_bsdf, sink});
     return exec::compact(active, num_active, next_active, KeepHit{vn.shape});
 }
