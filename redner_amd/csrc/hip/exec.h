@@ -376,14 +376,13 @@ struct TraceStats {
 TraceStats &trace_stats();
 void trace_stats_collect();     // folds pending hipEvent pairs / device counters into trace_stats()
 void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n, bool any);
-// Host threads render() may drive samples from (RDR_WORKERS=1 turns the second one off; the traversal statistics are
-// kept by one thread only).
+// Host threads render() may drive samples from (RDR_WORKERS=1 turns the second one off).
 inline int sample_workers(int lanes) {
     static const int forced = [] { const char *e = std::getenv("RDR_WORKERS"); return e ? std::min(1 + kMaxHelpers, std::max(1, std::atoi(e))) : 0; }();
-    if (trace_stats().timing || trace_stats().counting) return 1;
     if (forced) return forced;
-    (void)lanes;
-    return 2;      // measured (bunny_box backward): 256x256x16 spp 123 -> 87 ms, 512x512x8 spp 92 -> 83 ms, no change at 1024x1024; four workers are slower than two
+    // measured (bunny_box backward): 256x256x16 spp 123 -> 87 ms, 512x512x8 spp 92 -> 83 ms with a second worker, four are
+    // slower than two; at 1024x1024 the second worker adds 2 % and stretches every kernel it shares the GPU with
+    return lanes >= (1 << 19) ? 1 : 2;
 }
 void select_device(int use_gpu, int gpu_index);
 

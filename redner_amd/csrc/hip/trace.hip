@@ -95,6 +95,7 @@ int *persistent_counter() {
 
 namespace {
 struct Pending { hipEvent_t a, b; bool any; };
+std::mutex g_stats_lock;                 // launches come from every sample worker's host thread
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_free_events;
 unsigned long long *g_counters = nullptr;
@@ -109,10 +110,11 @@ hipEvent_t get_event() {
 
 TraceStats &trace_stats() { static TraceStats s; return s; }
 
-void trace_stats_collect() {
+void trace_stats_collect() {           // call between render() calls: every worker's stream has been joined by then
     TraceStats &st = trace_stats();
+    std::lock_guard<std::mutex> lk(g_stats_lock);
     if (!g_pending.empty()) {
-        check(hipStreamSynchronize(ctx().stream), "stats sync");
+        check(hipDeviceSynchronize(), "stats sync");
         for (Pending &p : g_pending) {
             float ms = 0;
             check(hipEventElapsedTime(&ms, p.a, p.b), "hipEventElapsedTime");
@@ -137,7 +139,8 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n,
     int blocks = (n + 255) / 256;
     Pending p{};
     if (st.timing) {
-        p.a = get_event(); p.b = get_event(); p.any = any;
+        { std::lock_guard<std::mutex> lk(g_stats_lock); p.a = get_event(); p.b = get_event(); }
+        p.any = any;
         check(hipEventRecord(p.a, s), "hipEventRecord");
     }
 #define RDR_TRACE_LAUNCH(ANY_, COUNT_, STACK_, ctr)                                                                          \
@@ -155,7 +158,13 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n,
         else RDR_TRACE_LAUNCH(ANY_, COUNT_, rt::kTraverseStack, ctr);          \
     } while (0)
     if (st.counting) {
-        if (!g_counters) { g_counters = (unsigned long long *)dmalloc(32); zero(g_counters, 32); }
+        {
+            std::lock_guard<std::mutex> lk(g_stats_lock);
+            if (!g_counters) {
+                g_counters = (unsigned long long *)dmalloc(32);
+                check(hipMemset(g_counters, 0, 32), "hipMemset");        // synchronous: another worker's launch may be next
+            }
+        }
         if (any) RDR_TRACE_BY_STACK(true, true, g_counters + 2);
         else RDR_TRACE_BY_STACK(false, true, g_counters);
     } else {
@@ -167,9 +176,9 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n,
     check(hipGetLastError(), "trace launch");
     if (st.timing) {
         check(hipEventRecord(p.b, s), "hipEventRecord");
-        g_pending.push_back(p);
-        if (g_pending.size() > 4096) trace_stats_collect();
     }
+    std::lock_guard<std::mutex> lk(g_stats_lock);
+    if (st.timing) g_pending.push_back(p);
     (any ? st.any_launches : st.closest_launches)++;
     (any ? st.any_rays : st.closest_rays) += (uint64_t)n;
 }
