@@ -404,12 +404,13 @@ struct Backward {
                     if (side) walk_done.after(exec::ctx().stream);
                 }
                 launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
-                if (side) { walk_done.gate(main_stream); adjoint_done.gate(main_stream); }
+                if (side) walk_done.gate(main_stream);
                 if (nH == 0 && nN == 0) {
                     // no slot samples an edge here (typically: every path already passed a diffuse vertex,
                     // src/edge.cpp:1396-1401); only the sampler bookkeeping of the skipped stages remains
                     edim += 4;
                     edge_rng_consumed(nA, 4);
+                    if (side) adjoint_done.gate(main_stream);
                     continue;
                 }
                 debug_dump("sec_mode", sample_id, d, sec_mode, (size_t)nA);
@@ -428,6 +429,7 @@ struct Backward {
                 launch_v(lean, n0, ShadeRecorded{scene.d, elist[0], ea, esink});
                 int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
                 edim += trace_edge_paths(rng_edge, edim, n1, nA, d + 1, q, esink, false);
+                if (side) adjoint_done.gate(main_stream);          // the only stage of the edge pass that touches the adjoint records
                 exec::launch(nA, SecondaryEdgeDerivatives{scene.d, grads.g, act, sec_recs, hit_pos, ea.n, edge_contrib, adj});
             }
         }
