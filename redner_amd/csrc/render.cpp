@@ -433,8 +433,20 @@ struct Backward {
                 exec::launch(nA, SecondaryEdgeDerivatives{scene.d, grads.g, act, sec_recs, hit_pos, ea.n, edge_contrib, adj});
             }
         }
-        launch_v(lean, P, AdjPrimary{scene.d, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
-                                   adj, screen_grad, ch});
+        // the camera-vertex adjoint runs beside the primary-edge pass unless both would add to the screen-gradient image
+        const bool adj_primary_aside = overlap && screen_grad == nullptr && edges_on && scene.use_primary_edges;
+        if (adj_primary_aside) {
+            hipStream_t main_stream = exec::ctx().stream;
+            depth_begin.after(main_stream);
+            exec::StreamScope on(exec::side_stream(0));
+            depth_begin.gate(exec::ctx().stream);
+            launch_v(lean, P, AdjPrimary{scene.d, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
+                                       adj, screen_grad, ch});
+            adjoint_done.after(exec::ctx().stream);
+        } else {
+            launch_v(lean, P, AdjPrimary{scene.d, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
+                                       adj, screen_grad, ch});
+        }
         if (edges_on && scene.use_primary_edges) {
             // ---- primary (camera-visible silhouette) edges, :766-942 ----
             const EdgeSceneD &es = scene.edges->d;
@@ -453,6 +465,7 @@ struct Backward {
             edim += trace_edge_paths(rng_edge, edim, n1, P, 0, q, esink, true);
             launch_v(lean, P, PrimaryEdgeDerivatives{scene.d, grads.g, prim_recs, edge_contrib, screen_grad});
         }
+        if (adj_primary_aside) adjoint_done.gate(exec::ctx().stream);      // the next sample clears the adjoint records
     }
 };
 
