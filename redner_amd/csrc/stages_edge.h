@@ -263,14 +263,21 @@ RDR_FN double min_abs_bound(double lo, double hi) {
 RDR_FN double ltc_bound(V3 lo, V3 hi, const LtcCtx &c) {
     V3 dir = V3{0, 0, 1};
     if (!box_contains(lo, hi, c.pos)) {
-        double inf = INFINITY;
-        V3 bl = v3(inf), bh = v3(-inf);
-        for (int i = 0; i < 8; ++i) {
-            V3 corner = V3{(i & 1) == 0 ? lo.x : hi.x, (i & 2) == 0 ? lo.y : hi.y, (i & 4) == 0 ? lo.z : hi.z};
-            V3 q = m3_apply(c.m_inv, corner - c.pos);
-            bl = V3{dmin(bl.x, q.x), dmin(bl.y, q.y), dmin(bl.z, q.z)};
-            bh = V3{dmax(bh.x, q.x), dmax(bh.y, q.y), dmax(bh.z, q.z)};
+        // Bounds of the eight transformed corners m_inv (corner - pos).  A coordinate of a transformed corner is
+        // m3_apply's left-to-right sum of three products, one per box axis, each with the low or the high face; every
+        // rounding in that sum is monotone in its operands and the corners are all eight combinations, so the
+        // minimum (maximum) over the corners is the same sum of the per-axis minima (maxima) -- the identical
+        // double, a third of the arithmetic of transforming eight corners.
+        const V3 fl = lo - c.pos, fh = hi - c.pos;
+        double blv[3], bhv[3];
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) {
+            const double xl = c.m_inv.m[r][0] * fl.x, xh = c.m_inv.m[r][0] * fh.x;
+            const double yl = c.m_inv.m[r][1] * fl.y, yh = c.m_inv.m[r][1] * fh.y;
+            const double zl = c.m_inv.m[r][2] * fl.z, zh = c.m_inv.m[r][2] * fh.z;
+            blv[r] = ((0.0 + dmin(xl, xh)) + dmin(yl, yh)) + dmin(zl, zh);
+            bhv[r] = ((0.0 + dmax(xl, xh)) + dmax(yl, yh)) + dmax(zl, zh);
         }
+        const V3 bl = V3{blv[0], blv[1], blv[2]}, bh = V3{bhv[0], bhv[1], bhv[2]};
         if (bh.z < 0) return 0;
         dir.x = min_abs_bound(bl.x, bh.x);
         dir.y = min_abs_bound(bl.y, bh.y);
