@@ -1,2 +1,2 @@
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'], d['scene_build_ms'], d['roofline']['mean_launch_ms'], d['roofline']['frac'])"; done
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4
+for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench', d['value'], d['ms_per_step'], d['roofline']['mean_launch_ms'], d['roofline']['frac'], d['roofline']['nodes_per_ray'])"; done
