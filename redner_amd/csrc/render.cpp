@@ -247,7 +247,23 @@ struct GradStore {
         }
     }
     void flush() {
-        for (const Pair &p : pairs) exec::launch((int)p.count, FlushGrad{p.acc, p.out, stride, replicas});
+        std::vector<FlushSegment> seg;
+        for (const Pair &p : pairs) seg.push_back(FlushSegment{(size_t)(p.acc - block), p.count, p.out});
+        std::sort(seg.begin(), seg.end(), [](const FlushSegment &a, const FlushSegment &b) { return a.begin < b.begin; });
+        if (!seg.empty()) {
+            if (stride > (size_t)0x7fffffff) throw std::runtime_error("render: gradient block too large");
+            FlushSegment *d_seg = arena.get<FlushSegment>(seg.size());
+            exec::upload(d_seg, seg.data(), sizeof(FlushSegment) * seg.size());
+            // one launch for all tensors, unless two mirrors feed overlapping output ranges (a tensor shared by two
+            // DScene entries): those must add one after the other
+            std::vector<FlushSegment> by_out(seg);
+            std::sort(by_out.begin(), by_out.end(), [](const FlushSegment &a, const FlushSegment &b) { return a.out < b.out; });
+            bool aliased = false;
+            for (size_t i = 1; i < by_out.size(); ++i) aliased = aliased || by_out[i - 1].out + by_out[i - 1].count > by_out[i].out;
+            if (!aliased) exec::launch((int)stride, FlushGrad{block, stride, replicas, d_seg, (int)seg.size()});
+            else for (size_t i = 0; i < seg.size(); ++i)
+                exec::launch((int)(seg[i].begin + seg[i].count), FlushGrad{block, stride, replicas, d_seg + i, 1});
+        }
         exec::set_replicas(0, 1);
     }
 };

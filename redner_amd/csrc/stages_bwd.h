@@ -412,13 +412,23 @@ struct AdjPrimary {
     }
 };
 
-// fp64 accumulator -> caller's fp32 gradient tensor (+=)
+// fp64 accumulators -> the caller's fp32 gradient tensors (+=), all tensors in one launch: lane i owns element i of the
+// replicated block, sums its replicas in fixed order and finds the tensor it belongs to in the sorted segment table.
+struct FlushSegment { size_t begin, count; float *out; };      // elements [begin, begin + count) of the block
 struct FlushGrad {
-    const double *acc; float *out; size_t stride; int replicas;
+    const double *block; size_t stride; int replicas;
+    const FlushSegment *segments; int num_segments;
     RDR_FN void operator()(int i) const {
+        int lo = 0, hi = num_segments;                 // last segment with begin <= i
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (segments[mid].begin <= (size_t)i) lo = mid; else hi = mid;
+        }
+        const FlushSegment sg = segments[lo];
+        if ((size_t)i < sg.begin || (size_t)i >= sg.begin + sg.count) return;       // padding between tensors
         double s = 0;
-        for (int r = 0; r < replicas; ++r) s += acc[(size_t)r * stride + i];
-        out[i] += (float)s;
+        for (int r = 0; r < replicas; ++r) s += block[(size_t)r * stride + i];
+        sg.out[(size_t)i - sg.begin] += (float)s;
     }
 };
 
