@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <exception>
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(256) compact_count(const int *in, int n, P pre
 }
 
 // exclusive scan of up to 256*16 workgroup counts by one workgroup
-static __global__ void __launch_bounds__(256) compact_scan(int *block_counts, int nblocks, int *total) {
+static __global__ void __launch_bounds__(256) compact_scan(int *block_counts, int nblocks, int *total, int ticket) {
     __shared__ int part[256];
     int per = (nblocks + 255) / 256;
     int beg = threadIdx.x * per, end = min(beg + per, nblocks);
@@ -313,7 +314,9 @@ static __global__ void __launch_bounds__(256) compact_scan(int *block_counts, in
     if (threadIdx.x == 0) {
         int run = 0;
         for (int i = 0; i < 256; ++i) { int t = part[i]; part[i] = run; run += t; }
-        *total = run;
+        total[0] = run;
+        // the host spins on the ticket (mapped pinned memory): release at system scope publishes the count first
+        __hip_atomic_store(total + 1, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
     int run = part[threadIdx.x];
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(256) compact_scatter(const int *in, int n, P p
 // `total` lives in pinned, device-mapped host memory: the scan kernel stores the count straight into
 // it, so reading it back costs one stream synchronisation and no copy launch (a pageable 4-byte
 // hipMemcpy measured ~195 us per call in the rocprofv3 trace, profiles/r1_notes.md).
-struct CompactScratch { int *block_counts = nullptr; int *total = nullptr; volatile int *total_host = nullptr; int capacity = 0; };
+struct CompactScratch { int *block_counts = nullptr; int *total = nullptr; volatile int *total_host = nullptr; int capacity = 0; int ticket = 0; };
 CompactScratch &compact_scratch(int nblocks);
 
 // `out` must not alias `in`: a workgroup may scatter into a tile that an earlier-numbered
@@ -360,11 +363,22 @@ inline int compact(const int *in, int n, int *out, const P &pred) {
     CompactScratch &sc = compact_scratch(nblocks);
     hipStream_t st = ctx().stream;
     hipLaunchKernelGGL(compact_count<P>, dim3(nblocks), dim3(256), 0, st, in, n, pred, sc.block_counts);
-    hipLaunchKernelGGL(compact_scan, dim3(1), dim3(256), 0, st, sc.block_counts, nblocks, sc.total);
+    const int ticket = ++sc.ticket;
+    hipLaunchKernelGGL(compact_scan, dim3(1), dim3(256), 0, st, sc.block_counts, nblocks, sc.total, ticket);
     hipLaunchKernelGGL(compact_scatter<P>, dim3(nblocks), dim3(256), 0, st, in, n, pred, sc.block_counts, out);
     check(hipGetLastError(), "compact launch");
-    check(hipStreamSynchronize(st), "compact sync");
-    return *sc.total_host;
+    // The count is needed on the host (loop control, launch sizes).  Spinning on the ticket the scan kernel publishes
+    // costs a few microseconds; hipStreamSynchronize wakes the thread ~20 us after the stream drains and also waits
+    // for the scatter kernel, which the next launch is ordered behind anyway.
+    for (long spins = 0; sc.total_host[1] != ticket; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(st) != hipErrorNotReady) {   // finished or failed without publishing
+            check(hipStreamSynchronize(st), "compact sync");
+            if (sc.total_host[1] != ticket) throw std::runtime_error("compact: count was not published");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return sc.total_host[0];
 }
 
 // ---- traversal kernels (trace.hip) --------------------------------------------------------------

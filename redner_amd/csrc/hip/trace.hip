@@ -39,6 +39,7 @@ CompactScratch &compact_scratch(int nblocks) {
             check(hipHostGetDevicePointer(&d, h, 0), "hipHostGetDevicePointer");
             s.total_host = (volatile int *)h;
             s.total = (int *)d;
+            s.total_host[0] = 0; s.total_host[1] = 0;       // [count, ticket of the compaction that wrote it]
         }
         s.capacity = nblocks + 1024;
         s.block_counts = (int *)dmalloc(sizeof(int) * s.capacity);
