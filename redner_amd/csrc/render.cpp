@@ -283,7 +283,7 @@ struct Backward {
 
     Backward(const Scene &scene_, const rdr_render_options &opt_, GradStore &grads_, int P_, int B_,
              const float *d_image_, float *screen_grad_, double weight_, int nd_, int radiance_dim_, const ChannelsD &ch_,
-             bool may_run_ahead)
+             int ahead_helper_)
         : scene(scene_), opt(opt_), P(P_), B(B_), d_image(d_image_), screen_grad(screen_grad_), weight(weight_),
           nd(nd_), radiance_dim(radiance_dim_), grads(grads_), ch(ch_) {
         lean = scene_is_lean(scene, ch);
@@ -320,7 +320,8 @@ struct Backward {
                 exec::launch(P, PcgInit{pcg_edge, pcg_stream_seed(opt) + 131071U});
             }
             // plain scenes + stateless sampler only: the general stages replay stale-buffer quirks that tie the passes together
-            ahead_ok = may_run_ahead && overlap && lean && scene.use_primary_edges && opt.sampler_type == RDR_SAMPLER_SOBOL;
+            ahead_helper = ahead_helper_;
+            ahead_ok = ahead_helper >= 0 && overlap && lean && scene.use_primary_edges && opt.sampler_type == RDR_SAMPLER_SOBOL;
             if (ahead_ok) {
                 ahead_set.ea = make_slice(arena, L, false);
                 ahead_set.eb = make_slice(arena, L, false);
@@ -339,6 +340,7 @@ struct Backward {
     struct EdgeSet { VSlice ea, eb; int *elist[3]; double *edge_contrib; };
     EdgeSet own_set() const { return EdgeSet{ea, eb, {elist[0], elist[1], elist[2]}, edge_contrib}; }
     bool ahead_ok = false;         // the primary-edge pass of a sample may be started before the sample's secondary passes
+    int ahead_helper = -1;         // which helper thread runs it
     EdgeSet ahead_set{};
     Queues ahead_q{};
     int ahead_edim_guess = -1;     // where the previous sample's primary-edge pass started in the edge sampler's dimensions
@@ -412,7 +414,7 @@ struct Backward {
     }
     bool ahead_running = false;
     ~Backward() {
-        if (ahead_running) { try { exec::SecondThread::get(exec::kMaxHelpers - 1).wait(); } catch (...) {} }
+        if (ahead_running) { try { exec::SecondThread::get(ahead_helper).wait(); } catch (...) {} }
     }
 
     void run_sample(int sample_id, const SamplerD &main_rng, std::vector<VSlice> &vs, int *active, std::vector<int> &num_active, const Queues &q) {
@@ -429,7 +431,7 @@ struct Backward {
         if (ahead_ok && ahead_edim_guess >= 0) {
             const int guess = ahead_edim_guess;
             ahead_running = true;
-            exec::SecondThread::get(exec::kMaxHelpers - 1).start([this, rng_edge, guess] {
+            exec::SecondThread::get(ahead_helper).start([this, rng_edge, guess] {
                 ahead_edim_end = primary_edge_paths(ahead_set, ahead_q, rng_edge, guess);
             });
         }
@@ -524,7 +526,7 @@ struct Backward {
             const int edim_start = edim;
             bool done = false;
             if (ahead_running) {
-                exec::SecondThread::get(exec::kMaxHelpers - 1).wait();
+                exec::SecondThread::get(ahead_helper).wait();
                 ahead_running = false;
                 done = ahead_edim_guess == edim_start;        // else: the secondary passes consumed another number of dimensions
             }
@@ -587,8 +589,8 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     };
     int workers = 1;            // host threads that drive samples (see below)
     if (d_image != nullptr && image == nullptr && lean && opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on)
-        workers = std::max(1, std::min(exec::sample_workers(P), opt.num_samples));
-    auto make_worker = [&](Worker &w) {
+        workers = std::max(1, std::min(exec::sample_workers(P), opt.num_samples / 4));      // a worker pays from ~4 samples each
+    auto make_worker = [&](Worker &w, int ahead_helper) {
         w.vs.resize(B + 1);
         for (int d = 0; d <= B; ++d) w.vs[d] = make_slice(w.arena, P, d < B);
         w.active = w.arena.get<int>((size_t)(B + 1) * P);
@@ -596,7 +598,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         w.q.h_nee = w.arena.get<rt::HitRec>((size_t)2 * P); w.q.h_bsdf = w.arena.get<rt::HitRec>((size_t)2 * P);
         w.num_active.assign(B + 2, 0);
         if (d_image) w.bwd.reset(new Backward(scene, opt, *grads, P, B, d_image, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch,
-                                              workers == 1));
+                                              ahead_helper));
     };
     // samples first, first + stride, ... on the calling thread's stream
     auto run_samples = [&](Worker &w, int first, int stride) {
@@ -635,7 +637,10 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     // host threads drive samples k, k + workers, ... on their own streams with their own buffers.  The forward image
     // needs its fp32 adds in sample order and stays on one stream.
     Worker w0;
-    make_worker(w0);
+    // helpers 0.. drive samples; the last one runs the primary-edge pass ahead when there is a single sample worker (four
+    // busy host threads are slower than two: 256x256x4 spp backward 34 ms with one worker + run-ahead, 36 ms with two
+    // workers, 44 ms with two workers + run-ahead each)
+    make_worker(w0, workers == 1 ? exec::kMaxHelpers - 1 : -1);
     if (timer.on) exec::sync();
     timer.lap("buffers, accumulators");
     if (workers == 1) {
@@ -645,7 +650,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         for (int k = 1; k < workers; ++k)
             exec::SecondThread::get(k - 1).start([&, k] {
                 Worker w;
-                make_worker(w);
+                make_worker(w, -1);
                 run_samples(w, k, workers);
                 exec::sync();
             });

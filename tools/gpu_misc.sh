@@ -1,2 +1,4 @@
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 1 --warmup 0 --spp 4 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -2
+timeout 250 python tools/small_loop_timing.py 256 4 2>&1 | grep backward
+timeout 250 python tools/small_loop_timing.py 256 16 2>&1 | grep backward
+timeout 250 python tools/small_loop_timing.py 512 8 2>&1 | grep backward
