@@ -282,8 +282,7 @@ struct Backward {
     double *multipliers = nullptr;     // [2P x nd], primary-edge channel weights (non-radiance channels only)
 
     Backward(const Scene &scene_, const rdr_render_options &opt_, GradStore &grads_, int P_, int B_,
-             const float *d_image_, float *screen_grad_, double weight_, int nd_, int radiance_dim_, const ChannelsD &ch_,
-             int ahead_helper_)
+             const float *d_image_, float *screen_grad_, double weight_, int nd_, int radiance_dim_, const ChannelsD &ch_)
         : scene(scene_), opt(opt_), P(P_), B(B_), d_image(d_image_), screen_grad(screen_grad_), weight(weight_),
           nd(nd_), radiance_dim(radiance_dim_), grads(grads_), ch(ch_) {
         lean = scene_is_lean(scene, ch);
@@ -319,32 +318,11 @@ struct Backward {
                 pcg_edge = arena.get<uint64_t>(P);
                 exec::launch(P, PcgInit{pcg_edge, pcg_stream_seed(opt) + 131071U});
             }
-            // plain scenes + stateless sampler only: the general stages replay stale-buffer quirks that tie the passes together
-            ahead_helper = ahead_helper_;
-            ahead_ok = ahead_helper >= 0 && overlap && lean && scene.use_primary_edges && opt.sampler_type == RDR_SAMPLER_SOBOL;
-            if (ahead_ok) {
-                ahead_set.ea = make_slice(arena, L, false);
-                ahead_set.eb = make_slice(arena, L, false);
-                for (int k = 0; k < 3; ++k) ahead_set.elist[k] = arena.get<int>(L);
-                ahead_set.edge_contrib = arena.get<double>(L);
-                ahead_q.nee = arena.get<rt::RayRec>(L); ahead_q.bsdf = arena.get<rt::RayRec>(L);
-                ahead_q.h_nee = arena.get<rt::HitRec>(L); ahead_q.h_bsdf = arena.get<rt::HitRec>(L);
-            }
         }
     }
 
     VSlice ea, eb;                 // ping-pong vertex slices of the edge sub-paths (2P lanes each)
     int *elist[3] = {nullptr, nullptr, nullptr};
-    // What one edge pass works in.  The secondary passes use the members above; the primary-edge pass has a second set
-    // (and its own ray queues) when it may run ahead on a helper thread, see run_sample().
-    struct EdgeSet { VSlice ea, eb; int *elist[3]; double *edge_contrib; };
-    EdgeSet own_set() const { return EdgeSet{ea, eb, {elist[0], elist[1], elist[2]}, edge_contrib}; }
-    bool ahead_ok = false;         // the primary-edge pass of a sample may be started before the sample's secondary passes
-    int ahead_helper = -1;         // which helper thread runs it
-    EdgeSet ahead_set{};
-    Queues ahead_q{};
-    int ahead_edim_guess = -1;     // where the previous sample's primary-edge pass started in the edge sampler's dimensions
-    int ahead_edim_end = 0;
     int *nee_slots = nullptr;                  // slots of the NEE-mode edge pick (its walk runs beside the hierarchical pick)
     exec::Fence depth_begin, adjoint_done, setup_done, walk_done;
     const bool overlap = std::getenv("RDR_NO_OVERLAP") == nullptr && std::getenv("RDR_DEBUG_DUMP") == nullptr;
@@ -373,48 +351,21 @@ struct Backward {
         else go(SecEdgePickNWalk<64>{sa, nee_slots, sec_picks});
     }
 
-    int trace_edge_paths(const EdgeSet &S, const SamplerD &rng_edge, int edim, int n_act, int n_slots, int first_depth,
-                         const Queues &q, const Sink &sink, bool need_lights) {
+    int trace_edge_paths(const SamplerD &rng_edge, int edim, int n_act, int n_slots, int first_depth, const Queues &q,
+                         const Sink &sink, bool need_lights) {
         int used = 0;
         const bool has_lights = scene.d.num_lights > 0;
         int cur = 1;
         for (int depth = first_depth, k = 0; depth < B && n_act > 0 && (!need_lights || has_lights); ++depth, ++k) {
-            const VSlice &m = (k % 2 == 0) ? S.ea : S.eb;
-            const VSlice &nx = (k % 2 == 0) ? S.eb : S.ea;
+            const VSlice &m = (k % 2 == 0) ? ea : eb;
+            const VSlice &nx = (k % 2 == 0) ? eb : ea;
             int nxt = (cur == 1) ? 2 : 1;
-            n_act = run_bounce(scene, edge_rng_at(rng_edge, edim + used), edim + used, 1, S.elist[cur], n_act, m, nx, q, sink, S.elist[nxt]);
+            n_act = run_bounce(scene, edge_rng_at(rng_edge, edim + used), edim + used, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt]);
             edge_rng_consumed(n_slots, 7);
             cur = nxt;
             used += 7;
         }
         return used;
-    }
-
-    // Primary (camera-visible silhouette) edges, src/pathtracer.cpp:766-942, up to but not including the gradient scatter:
-    // sample the edges, trace both sides, path-trace them to the end.  Writes prim_recs and S.edge_contrib only, so it can run
-    // ahead of the sample's secondary passes on another thread and stream.  Returns the edge sampler's dimension after it.
-    int primary_edge_paths(const EdgeSet &S, const Queues &q, const SamplerD &rng_edge, int edim) {
-        const EdgeSceneD &es = scene.edges->d;
-        const int lanes = 2 * P;
-        Sink esink{nullptr, S.edge_contrib, nd, radiance_dim, weight, ch, nullptr};
-        Sink psink{nullptr, S.edge_contrib, nd, radiance_dim, weight, ch, multipliers};
-        exec::zero(S.edge_contrib, sizeof(double) * lanes);
-        launch_v(lean, P, SamplePrimaryEdges{scene.d, es, edge_rng_at(rng_edge, edim), edim, d_image, nd, radiance_dim, prim_recs, S.ea, multipliers});
-        edim += 2;
-        edge_rng_consumed(P, 2);
-        int n0 = exec::compact((const int *)nullptr, lanes, S.elist[0], KeepNonZeroDir{S.ea.ray, S.ea.n});
-        if (S.ea.erd) exec::launch(n0, LoadLaneDiff{S.elist[0], S.ea});
-        exec::launch(n0, QueueRays{S.elist[0], S.ea, nullptr, q.bsdf});
-        exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
-        launch_v(lean, n0, ShadePrimary{scene.d, S.elist[0], S.ea, q.h_bsdf, psink});
-        if (S.ea.erd) exec::launch(n0, MirrorSurfDiff{scene.d, S.elist[0], S.ea});
-        int n1 = exec::compact(S.elist[0], n0, S.elist[1], KeepHit{S.ea.shape});
-        edim += trace_edge_paths(S, rng_edge, edim, n1, P, 0, q, esink, true);
-        return edim;
-    }
-    bool ahead_running = false;
-    ~Backward() {
-        if (ahead_running) { try { exec::SecondThread::get(ahead_helper).wait(); } catch (...) {} }
     }
 
     void run_sample(int sample_id, const SamplerD &main_rng, std::vector<VSlice> &vs, int *active, std::vector<int> &num_active, const Queues &q) {
@@ -423,18 +374,8 @@ struct Backward {
         const bool has_lights = scene.d.num_lights > 0;
         const bool edges_on = prim_recs != nullptr;
         Sink esink{nullptr, edge_contrib, nd, radiance_dim, weight, ch, nullptr};
+        Sink psink{nullptr, edge_contrib, nd, radiance_dim, weight, ch, multipliers};
         int edim = 0;
-        // The primary-edge pass needs nothing from this sample's path -- only where the secondary passes will leave the edge
-        // sampler's dimension counter, which depends on which of their loops run.  That is the same from sample to sample
-        // almost always, so the pass starts now on a helper thread from the previous sample's value and is kept if the guess
-        // turns out right; otherwise it is repeated in place.
-        if (ahead_ok && ahead_edim_guess >= 0) {
-            const int guess = ahead_edim_guess;
-            ahead_running = true;
-            exec::SecondThread::get(ahead_helper).start([this, rng_edge, guess] {
-                ahead_edim_end = primary_edge_paths(ahead_set, ahead_q, rng_edge, guess);
-            });
-        }
         exec::zero(adj.thr, sizeof(double) * 3 * P);
         exec::zero(adj.ray_dir, sizeof(double) * 3 * P);
         exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * P);
@@ -503,7 +444,7 @@ struct Backward {
                 exec::zero(edge_contrib, sizeof(double) * lanes);
                 launch_v(lean, n0, ShadeRecorded{scene.d, elist[0], ea, esink});
                 int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
-                edim += trace_edge_paths(own_set(), rng_edge, edim, n1, nA, d + 1, q, esink, false);
+                edim += trace_edge_paths(rng_edge, edim, n1, nA, d + 1, q, esink, false);
                 if (side) adjoint_done.gate(main_stream);          // the only stage of the edge pass that touches the adjoint records
                 exec::launch(nA, SecondaryEdgeDerivatives{scene.d, grads.g, act, sec_recs, hit_pos, ea.n, edge_contrib, adj});
             }
@@ -523,18 +464,22 @@ struct Backward {
                                        adj, screen_grad, ch});
         }
         if (edges_on && scene.use_primary_edges) {
-            const int edim_start = edim;
-            bool done = false;
-            if (ahead_running) {
-                exec::SecondThread::get(ahead_helper).wait();
-                ahead_running = false;
-                done = ahead_edim_guess == edim_start;        // else: the secondary passes consumed another number of dimensions
-            }
-            const EdgeSet S = done ? ahead_set : own_set();
-            if (done) edim = ahead_edim_end;
-            else edim = primary_edge_paths(S, q, rng_edge, edim_start);
-            launch_v(lean, P, PrimaryEdgeDerivatives{scene.d, grads.g, prim_recs, S.edge_contrib, screen_grad});
-            ahead_edim_guess = edim_start;
+            // ---- primary (camera-visible silhouette) edges, :766-942 ----
+            const EdgeSceneD &es = scene.edges->d;
+            const int lanes = 2 * P;
+            exec::zero(edge_contrib, sizeof(double) * lanes);
+            launch_v(lean, P, SamplePrimaryEdges{scene.d, es, edge_rng_at(rng_edge, edim), edim, d_image, nd, radiance_dim, prim_recs, ea, multipliers});
+            edim += 2;
+            edge_rng_consumed(P, 2);
+            int n0 = exec::compact((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
+            if (ea.erd) exec::launch(n0, LoadLaneDiff{elist[0], ea});
+            exec::launch(n0, QueueRays{elist[0], ea, nullptr, q.bsdf});
+            exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
+            launch_v(lean, n0, ShadePrimary{scene.d, elist[0], ea, q.h_bsdf, psink});
+            if (ea.erd) exec::launch(n0, MirrorSurfDiff{scene.d, elist[0], ea});
+            int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
+            edim += trace_edge_paths(rng_edge, edim, n1, P, 0, q, esink, true);
+            launch_v(lean, P, PrimaryEdgeDerivatives{scene.d, grads.g, prim_recs, edge_contrib, screen_grad});
         }
         if (adj_primary_aside) adjoint_done.gate(exec::ctx().stream);      // the next sample clears the adjoint records
     }
@@ -587,18 +532,14 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         std::vector<int> num_active;
         std::unique_ptr<Backward> bwd;
     };
-    int workers = 1;            // host threads that drive samples (see below)
-    if (d_image != nullptr && image == nullptr && lean && opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on)
-        workers = std::max(1, std::min(exec::sample_workers(P), opt.num_samples / 4));      // a worker pays from ~4 samples each
-    auto make_worker = [&](Worker &w, int ahead_helper) {
+    auto make_worker = [&](Worker &w) {
         w.vs.resize(B + 1);
         for (int d = 0; d <= B; ++d) w.vs[d] = make_slice(w.arena, P, d < B);
         w.active = w.arena.get<int>((size_t)(B + 1) * P);
         w.q.nee = w.arena.get<rt::RayRec>((size_t)2 * P); w.q.bsdf = w.arena.get<rt::RayRec>((size_t)2 * P);
         w.q.h_nee = w.arena.get<rt::HitRec>((size_t)2 * P); w.q.h_bsdf = w.arena.get<rt::HitRec>((size_t)2 * P);
         w.num_active.assign(B + 2, 0);
-        if (d_image) w.bwd.reset(new Backward(scene, opt, *grads, P, B, d_image, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch,
-                                              ahead_helper));
+        if (d_image) w.bwd.reset(new Backward(scene, opt, *grads, P, B, d_image, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch));
     };
     // samples first, first + stride, ... on the calling thread's stream
     auto run_samples = [&](Worker &w, int first, int stride) {
@@ -636,11 +577,11 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     // optimisation loops run at (256x256, a few spp) one sample is a chain of short, latency-bound launches, so helper
     // host threads drive samples k, k + workers, ... on their own streams with their own buffers.  The forward image
     // needs its fp32 adds in sample order and stays on one stream.
+    int workers = 1;
+    if (d_image != nullptr && image == nullptr && lean && opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on)
+        workers = std::max(1, std::min(exec::sample_workers(P), opt.num_samples));
     Worker w0;
-    // helpers 0.. drive samples; the last one runs the primary-edge pass ahead when there is a single sample worker (four
-    // busy host threads are slower than two: 256x256x4 spp backward 34 ms with one worker + run-ahead, 36 ms with two
-    // workers, 44 ms with two workers + run-ahead each)
-    make_worker(w0, workers == 1 ? exec::kMaxHelpers - 1 : -1);
+    make_worker(w0);
     if (timer.on) exec::sync();
     timer.lap("buffers, accumulators");
     if (workers == 1) {
@@ -650,7 +591,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         for (int k = 1; k < workers; ++k)
             exec::SecondThread::get(k - 1).start([&, k] {
                 Worker w;
-                make_worker(w, -1);
+                make_worker(w);
                 run_samples(w, k, workers);
                 exec::sync();
             });
