@@ -139,6 +139,14 @@ def cpu_baseline(max_bounces):
                       % (res, res, spp, max_bounces, reps, dt)}
 
 
+def alone_leg(st, alg_bytes_launch):
+    """The same kernel in an extra untimed step on one stream (RDR_NO_OVERLAP=1): informative, not the headline."""
+    ms = st.closest_ms / max(st.closest_launches, 1)
+    achieved = alg_bytes_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {'mean_launch_ms': ms, 'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS,
+            'note': 'untimed extra step with every stage on one stream'}
+
+
 def measured_traffic(a):
     """HBM bytes per closest-hit launch from the PMC passes (rocprofv3 cannot run inside this process): the
     committed measurement in profiles/r1_traffic.json, valid for the default workload only, else None."""
@@ -223,6 +231,17 @@ def main():
     cnt = trace_stats()
     lib.rdr_trace_stats_enable(0, 0)
 
+    # untimed pass on ONE stream: the traversal kernel's launch duration without a neighbour on the GPU (in the timed
+    # region the shadow-ray launch of the same bounce runs beside every closest-hit launch)
+    os.environ['RDR_NO_OVERLAP'] = '1'
+    lib.rdr_trace_stats_enable(1, 0)
+    trace_stats(reset=True)
+    prep.step(a.warmup)
+    torch.cuda.synchronize(dev)
+    alone = trace_stats()
+    lib.rdr_trace_stats_enable(0, 0)
+    del os.environ['RDR_NO_OVERLAP']
+
     out = None
     if rank == 0:
         per_step_launches = cnt.closest_launches
@@ -247,7 +266,8 @@ def main():
                          'rays_per_step': rays, 'nodes_per_ray': cnt.closest_nodes / max(rays, 1),
                          'tris_per_ray': cnt.closest_tris / max(rays, 1),
                          'algorithmic_bytes_per_launch': alg_bytes_launch,
-                         'traversal_share_of_step': (st.closest_ms + st.any_ms) / (dt * 1e3)},
+                         'traversal_share_of_step': (st.closest_ms + st.any_ms) / (dt * 1e3),
+                         'alone': alone_leg(alone, alg_bytes_launch)},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:

@@ -7,6 +7,7 @@
 // the reference's, because sample-exact parity depends on it; how a bounce is cut into kernels
 // and what is kept in HBM is ours (stages_fwd.h / stages_bwd.h / stages_edge.h).
 #include "render.h"
+#include <atomic>
 #include <exception>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +22,10 @@
 namespace rdr {
 
 namespace {
+
+// Independent stages on side streams (DESIGN.md section 3 "Streams")?  Re-read from the environment by every render() call so
+// that bench.py can time the traversal kernel on its own in an extra, untimed pass (RDR_NO_OVERLAP=1).
+std::atomic<bool> g_overlap{true};
 
 // Device arena: one allocation per render() call, carved into typed arrays.
 struct Arena {
@@ -114,7 +119,7 @@ int run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng_shift,
     launch_v(lean, num_active, BounceSample{scene.d, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
     // the shadow-ray and the continuation-ray queue are traced side by side: both kernels wait on dependent loads
     // with a fraction of their lanes active (profiles/r1_notes.md), so they fill each other's gaps
-    static const bool side = std::getenv("RDR_NO_OVERLAP") == nullptr;
+    const bool side = g_overlap.load(std::memory_order_relaxed);
     if (side) {
         static thread_local exec::Fence *queued = new exec::Fence(), *shadow_done = new exec::Fence();   // per host thread
         hipStream_t main_stream = exec::ctx().stream;
@@ -325,7 +330,7 @@ struct Backward {
     int *elist[3] = {nullptr, nullptr, nullptr};
     int *nee_slots = nullptr;                  // slots of the NEE-mode edge pick (its walk runs beside the hierarchical pick)
     exec::Fence depth_begin, adjoint_done, setup_done, walk_done;
-    const bool overlap = std::getenv("RDR_NO_OVERLAP") == nullptr && std::getenv("RDR_DEBUG_DUMP") == nullptr;
+    const bool overlap = g_overlap.load(std::memory_order_relaxed);
     double *edge_contrib = nullptr, *edge_tmin = nullptr, *hit_pos = nullptr;
     PrimaryEdgeRec *prim_recs = nullptr;
     SecondaryEdgeRec *sec_recs = nullptr;
@@ -506,6 +511,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     const bool has_lights = scene.d.num_lights > 0;
     if (2 + 7 * B > kSamplerDims) throw std::runtime_error("render: max_bounces exceeds the Sobol' table");
 
+    g_overlap.store(std::getenv("RDR_NO_OVERLAP") == nullptr && std::getenv("RDR_DEBUG_DUMP") == nullptr);
     PhaseTimer timer(d_image ? "render (backward)" : "render (forward)");
     Arena arena;
     {
