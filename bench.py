@@ -169,6 +169,7 @@ def main():
     ap.add_argument('--res', type=int, default=1024)
     ap.add_argument('--max-bounces', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alone-leg', action='store_true', help='skip the extra single-stream step behind roofline.alone (profiling runs)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -233,14 +234,16 @@ def main():
 
     # untimed pass on ONE stream: the traversal kernel's launch duration without a neighbour on the GPU (in the timed
     # region the shadow-ray launch of the same bounce runs beside every closest-hit launch)
-    os.environ['RDR_NO_OVERLAP'] = '1'
-    lib.rdr_trace_stats_enable(1, 0)
-    trace_stats(reset=True)
-    prep.step(a.warmup)
-    torch.cuda.synchronize(dev)
-    alone = trace_stats()
-    lib.rdr_trace_stats_enable(0, 0)
-    del os.environ['RDR_NO_OVERLAP']
+    alone = None
+    if not a.no_alone_leg:
+        os.environ['RDR_NO_OVERLAP'] = '1'
+        lib.rdr_trace_stats_enable(1, 0)
+        trace_stats(reset=True)
+        prep.step(a.warmup)
+        torch.cuda.synchronize(dev)
+        alone = trace_stats()
+        lib.rdr_trace_stats_enable(0, 0)
+        del os.environ['RDR_NO_OVERLAP']
 
     out = None
     if rank == 0:
@@ -267,7 +270,7 @@ def main():
                          'tris_per_ray': cnt.closest_tris / max(rays, 1),
                          'algorithmic_bytes_per_launch': alg_bytes_launch,
                          'traversal_share_of_step': (st.closest_ms + st.any_ms) / (dt * 1e3),
-                         'alone': alone_leg(alone, alg_bytes_launch)},
+                         'alone': alone_leg(alone, alg_bytes_launch) if alone is not None else None},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
