@@ -457,6 +457,7 @@ EdgeData *build_edge_data(Scene &scene) {
     // host views of the shapes (same records, pointers into the host mirrors)
     std::vector<ShapeD> hs(scene.shapes);
     for (int i = 0; i < ns; ++i) {
+        hs[i].geom = nullptr;          // host view: read the mesh arrays
         hs[i].vertices = scene.h_vertices[i].data();
         hs[i].indices = scene.h_indices[i].data();
         hs[i].normals = scene.shapes[i].normals ? scene.h_normals[i].data() : nullptr;
@@ -635,7 +636,7 @@ EdgeData *build_edge_data(Scene &scene) {
         // per-edge geometry records, from the host copies of the shapes
         std::vector<EdgeGeom> geom(edges.size());
         std::vector<ShapeD> hs(scene.shapes.begin(), scene.shapes.end());
-        for (size_t i = 0; i < hs.size(); ++i) { hs[i].vertices = scene.h_vertices[i].data(); hs[i].indices = scene.h_indices[i].data(); }
+        for (size_t i = 0; i < hs.size(); ++i) { hs[i].geom = nullptr; hs[i].vertices = scene.h_vertices[i].data(); hs[i].indices = scene.h_indices[i].data(); }
         for (size_t i = 0; i < edges.size(); ++i) {
             const EdgeD &e = edges[i];
             EdgeGeom &g = geom[i];

@@ -123,6 +123,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         const rdr_shape_desc &in = shapes[i];
         ShapeD &o = s.shapes[i];
         o.vertices = in.vertices; o.indices = in.indices; o.uvs = in.uvs; o.normals = in.normals;
+        o.geom = nullptr;              // set when the gathered triangle records have been uploaded (below)
         o.uv_indices = in.uv_indices; o.normal_indices = in.normal_indices; o.colors = in.colors;
         if (in.colors) s.has_vertex_colors = true;
         o.num_vertices = in.num_vertices; o.num_uv_vertices = in.num_uv_vertices;
@@ -180,7 +181,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         for (int l = 0; l < num_area_lights; ++l) {
             int sid = s.lights[l].shape_id;
             ShapeD hs = s.shapes[sid];     // host view of the same shape
-            hs.vertices = s.h_vertices[sid].data(); hs.indices = s.h_indices[sid].data();
+            hs.vertices = s.h_vertices[sid].data(); hs.indices = s.h_indices[sid].data(); hs.geom = nullptr;
             double *cdf = s.area_cdf_pool.data() + s.area_cdf_offset[l];
             double total = 0;
             for (int t = 0; t < hs.num_triangles; ++t) { cdf[t] = tri_area(hs, t); total += cdf[t]; }
@@ -233,6 +234,42 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     struct JoinOnExit { std::future<rt::BvhHost> &f; ~JoinOnExit() { if (f.valid()) f.wait(); } } join_bvh{bvh_job};
 
     // ---- device copies of the flat tables ----
+    // ---- gathered per-triangle records (scene_data.h: TriGeomD) ----
+    {
+        size_t total = 0;
+        for (int i = 0; i < num_shapes; ++i) total += (size_t)s.shapes[i].num_triangles;
+        std::vector<TriGeomD> geom(total);
+        std::vector<size_t> first(num_shapes, 0);
+        size_t at = 0;
+        for (int i = 0; i < num_shapes; ++i) {
+            first[i] = at;
+            const ShapeD &sh = s.shapes[i];
+            const std::vector<float> &vtx = s.h_vertices[i], &uvs = s.h_uvs[i], &nrm = s.h_normals[i];
+            const std::vector<int> &idx = s.h_indices[i], &uidx = s.h_uv_indices[i], &nidx = s.h_normal_indices[i];
+            const int nuv = (int)uvs.size() / 2, nn = (int)nrm.size() / 3;
+            for (int t = 0; t < sh.num_triangles; ++t, ++at) {
+                TriGeomD &g = geom[at];
+                std::memset(&g, 0, sizeof(g));
+                for (int k = 0; k < 3; ++k) {
+                    const int vi = idx[3 * t + k];
+                    const int ui = sh.uv_indices ? uidx[3 * t + k] : vi;
+                    const int ni = sh.normal_indices ? nidx[3 * t + k] : vi;
+                    g.vi[k] = vi; g.ui[k] = ui; g.ni[k] = ni;
+                    for (int c = 0; c < 3; ++c) g.p[3 * k + c] = vtx[3 * (size_t)vi + c];
+                    if (sh.uvs) {
+                        if (ui < 0 || ui >= nuv) throw std::runtime_error("Scene: uv index out of range in shape " + std::to_string(i));
+                        g.uv[2 * k] = uvs[2 * (size_t)ui]; g.uv[2 * k + 1] = uvs[2 * (size_t)ui + 1];
+                    }
+                    if (sh.normals) {
+                        if (ni < 0 || ni >= nn) throw std::runtime_error("Scene: normal index out of range in shape " + std::to_string(i));
+                        for (int c = 0; c < 3; ++c) g.n[3 * k + c] = nrm[3 * (size_t)ni + c];
+                    }
+                }
+            }
+        }
+        const TriGeomD *d_geom = to_device(s, geom.data(), geom.size());
+        for (int i = 0; i < num_shapes; ++i) s.shapes[i].geom = s.shapes[i].num_triangles > 0 ? d_geom + first[i] : nullptr;
+    }
     s.d.shapes = to_device(s, s.shapes.data(), s.shapes.size());
     s.d.materials = to_device(s, s.materials.data(), s.materials.size());
     s.d.lights = to_device(s, s.lights.data(), s.lights.size());

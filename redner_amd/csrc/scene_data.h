@@ -17,7 +17,18 @@ namespace rdr {
 
 constexpr int kMaxMip = 8;   // src/texture.h:11
 
+// Everything the shading stages read about one triangle, gathered at Scene construction (scene.cpp) so that a lane
+// reaches it with one dependent fetch of nine aligned 16-byte loads instead of the index -> vertex / uv / normal chains
+// through five arrays.  The values are copies of the mesh arrays' floats, so results are unchanged.
+struct alignas(16) TriGeomD {
+    float p[9]; int vi[3];          // corners, vertex indices
+    float n[9]; int ni[3];          // shading normals (zero when the shape has none), their indices
+    float uv[6]; int ui[3]; int pad[3];
+};
+static_assert(sizeof(TriGeomD) == 144, "triangle record size");
+
 struct ShapeD {
+    const TriGeomD *geom;           // per triangle; nullptr in host-side views of a shape (they read the mesh arrays)
     const float *vertices;
     const int *indices;
     const float *uvs;

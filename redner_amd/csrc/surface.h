@@ -42,6 +42,12 @@ RDR_FN Surf surf_zero() {
 struct TriVerts { V3 p0, p1, p2; int i0, i1, i2; };
 RDR_FN TriVerts load_tri(const ShapeD &sh, int tri) {
     TriVerts t;
+    if (sh.geom) {
+        const TriGeomD &g = sh.geom[tri];
+        t.i0 = g.vi[0]; t.i1 = g.vi[1]; t.i2 = g.vi[2];
+        t.p0 = v3f(g.p); t.p1 = v3f(g.p + 3); t.p2 = v3f(g.p + 6);
+        return t;
+    }
     t.i0 = sh.indices[3 * tri]; t.i1 = sh.indices[3 * tri + 1]; t.i2 = sh.indices[3 * tri + 2];
     t.p0 = v3f(sh.vertices + 3 * t.i0); t.p1 = v3f(sh.vertices + 3 * t.i1); t.p2 = v3f(sh.vertices + 3 * t.i2);
     return t;
@@ -200,6 +206,14 @@ struct TriAttr {     // per-corner attributes resolved through the optional inde
 };
 RDR_FN TriAttr load_attr(const ShapeD &sh, int tri, const TriVerts &tv) {
     TriAttr a;
+    if (sh.geom) {
+        const TriGeomD &g = sh.geom[tri];
+        a.ui0 = g.ui[0]; a.ui1 = g.ui[1]; a.ui2 = g.ui[2];
+        a.ni0 = g.ni[0]; a.ni1 = g.ni[1]; a.ni2 = g.ni[2];
+        if (sh.uvs) { a.uv0 = v2(g.uv[0], g.uv[1]); a.uv1 = v2(g.uv[2], g.uv[3]); a.uv2 = v2(g.uv[4], g.uv[5]); }
+        else { a.uv0 = v2(0, 0); a.uv1 = v2(1, 0); a.uv2 = v2(1, 1); }
+        return a;
+    }
     a.ui0 = tv.i0; a.ui1 = tv.i1; a.ui2 = tv.i2;
     if (sh.uv_indices) { a.ui0 = sh.uv_indices[3 * tri]; a.ui1 = sh.uv_indices[3 * tri + 1]; a.ui2 = sh.uv_indices[3 * tri + 2]; }
     a.ni0 = tv.i0; a.ni1 = tv.i1; a.ni2 = tv.i2;
@@ -212,6 +226,16 @@ RDR_FN TriAttr load_attr(const ShapeD &sh, int tri, const TriVerts &tv) {
         a.uv0 = v2(0, 0); a.uv1 = v2(1, 0); a.uv2 = v2(1, 1);
     }
     return a;
+}
+
+// The three shading normals of triangle `tri` (the shape has normals).
+RDR_FN void load_normals(const ShapeD &sh, int tri, const TriAttr &at, V3 &n0, V3 &n1, V3 &n2) {
+    if (sh.geom) {
+        const TriGeomD &g = sh.geom[tri];
+        n0 = v3f(g.n); n1 = v3f(g.n + 3); n2 = v3f(g.n + 6);
+        return;
+    }
+    n0 = v3f(sh.normals + 3 * at.ni0); n1 = v3f(sh.normals + 3 * at.ni1); n2 = v3f(sh.normals + 3 * at.ni2);
 }
 
 // Shading point of `ray` on triangle `tri` of `sh`; also transfers the ray differential onto the
@@ -247,7 +271,8 @@ RDR_FN Surf surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff &rd
     V3 sn = gn;
     sp.dn_dx = sp.dn_dy = v3(0);
     if (sh.normals) {
-        V3 n0 = v3f(sh.normals + 3 * at.ni0), n1 = v3f(sh.normals + 3 * at.ni1), n2 = v3f(sh.normals + 3 * at.ni2);
+        V3 n0, n1, n2;
+        load_normals(sh, tri, at, n0, n1, n2);
         V3 nn = w * n0 + u * n1 + v * n2;
         if (diffs) {
             V3 dnn_dx = (-h.u_dxy.x - h.v_dxy.x) * n0 + h.u_dxy.x * n1 + h.v_dxy.x * n2;
@@ -316,7 +341,7 @@ RDR_FN void adj_surf_at(const ShapeD &sh, int tri, const Ray &ray, const RayDiff
     V3 dn_dx = v3(0), dn_dy = v3(0);
     double l2 = 0, l = 0;
     if (sh.normals) {
-        n0 = v3f(sh.normals + 3 * at.ni0); n1 = v3f(sh.normals + 3 * at.ni1); n2 = v3f(sh.normals + 3 * at.ni2);
+        load_normals(sh, tri, at, n0, n1, n2);
         nn = w * n0 + u * n1 + v * n2;
         l2 = dot(nn, nn); l = sqrt(l2);
         if (diffs) {
