@@ -273,14 +273,19 @@ struct TreeBuilder {
         // leaves + bottom-up bounds / weighted length
         std::vector<int> counter(n_internal + n, 0);
         std::vector<int> leaves_below(n_internal + n, 1);
+        parallel_chunks(n, 2048, [&](int begin, int end) {
+            for (int i = begin; i < end; ++i) {
+                EdgeNode &lf = nodes[leaf_ref(i)];
+                const Box6 &b = bounds[ids[i]];
+                lf.p_min = b.p_min; lf.p_max = b.p_max;
+                if (!is3d) { lf.d_min = b.d_min; lf.d_max = b.d_max; }
+                const EdgeD &e = edges[ids[i]];
+                lf.wlen = f3_distance(edge_v0f(shapes, e), edge_v1f(shapes, e)) * edge_exterior_dihedral(shapes, e);
+                lf.edge_id = ids[i];
+            }
+        });
         for (int i = 0; i < n; ++i) {
             EdgeNode &lf = nodes[leaf_ref(i)];
-            const Box6 &b = bounds[ids[i]];
-            lf.p_min = b.p_min; lf.p_max = b.p_max;
-            if (!is3d) { lf.d_min = b.d_min; lf.d_max = b.d_max; }
-            const EdgeD &e = edges[ids[i]];
-            lf.wlen = f3_distance(edge_v0f(shapes, e), edge_v1f(shapes, e)) * edge_exterior_dihedral(shapes, e);
-            lf.edge_id = ids[i];
             int cur = lf.parent;
             while (cur >= 0) {
                 if (++counter[cur] == 1) break;       // first arrival waits for the sibling
@@ -519,17 +524,20 @@ EdgeData *build_edge_data(Scene &scene) {
     }
     // drop edges between coplanar faces
     {
-        std::vector<EdgeD> kept;
-        for (const EdgeD &e : edges) {
-            bool remove = false;
-            if (e.f0 != -1 && e.f1 != -1) {
+        std::vector<unsigned char> remove(edges.size(), 0);
+        parallel_chunks((int)edges.size(), 4096, [&](int begin, int end) {
+            for (int i = begin; i < end; ++i) {
+                const EdgeD &e = edges[i];
+                if (e.f0 == -1 || e.f1 == -1) continue;
                 V3 a = edge_v0(shapes, e), b = edge_v1(shapes, e);
                 V3 o0 = to_v3(edge_opp0f(shapes, e)), o1 = to_v3(edge_opp1f(shapes, e));
                 V3 n0 = normalize(cross(a - o0, b - o0)), n1 = normalize(cross(b - o1, a - o1));
-                remove = dot(n0, n1) >= (1 - 1e-6f);
+                remove[i] = dot(n0, n1) >= (1 - 1e-6f);
             }
-            if (!remove) kept.push_back(e);
-        }
+        });
+        std::vector<EdgeD> kept;
+        kept.reserve(edges.size());
+        for (size_t i = 0; i < edges.size(); ++i) if (!remove[i]) kept.push_back(edges[i]);
         edges.swap(kept);
     }
     const int ne = (int)edges.size();
@@ -540,17 +548,19 @@ EdgeData *build_edge_data(Scene &scene) {
     if (scene.use_primary_edges) {
         timer.lap("edge list (sort, merge)");
         ed->primary_pmf.assign(ne, 0); ed->primary_cdf.assign(ne, 0);
+        parallel_chunks(ne, 4096, [&](int begin, int end) {
+            for (int i = begin; i < end; ++i) {
+                const EdgeD &e = edges[i];
+                V2 s0, s1, c0, c1;
+                double w = 0;
+                if (project_segment(cam, edge_v0(shapes, e), edge_v1(shapes, e), s0, s1))
+                    if (clip_unit_square(s0, s1, c0, c1))
+                        if (edge_is_silhouette(shapes, cam_org, e)) w = len(c1 - c0);
+                ed->primary_pmf[i] = w;
+            }
+        });
         double total = 0;
-        for (int i = 0; i < ne; ++i) {
-            const EdgeD &e = edges[i];
-            V2 s0, s1, c0, c1;
-            double w = 0;
-            if (project_segment(cam, edge_v0(shapes, e), edge_v1(shapes, e), s0, s1))
-                if (clip_unit_square(s0, s1, c0, c1))
-                    if (edge_is_silhouette(shapes, cam_org, e)) w = len(c1 - c0);
-            ed->primary_pmf[i] = w;
-            total += w;
-        }
+        for (int i = 0; i < ne; ++i) total += ed->primary_pmf[i];          // in edge order, like the reference's running sum
         double run = 0;
         for (int i = 0; i < ne; ++i) { ed->primary_pmf[i] = ed->primary_pmf[i] / total; }
         for (int i = 0; i < ne; ++i) { ed->primary_cdf[i] = run; run += ed->primary_pmf[i]; }
@@ -559,9 +569,11 @@ EdgeData *build_edge_data(Scene &scene) {
     // ---- secondary edges: the two hierarchies (src/edge_tree.cpp:724-882) ----
     if (scene.use_secondary_edges && ne > 0) {
         std::vector<int> cs_ids, ncs_ids;
-        for (int i = 0; i < ne; ++i) (edge_is_silhouette(shapes, cam_org, edges[i]) ? cs_ids : ncs_ids).push_back(i);
+        std::vector<unsigned char> is_sil(ne, 0);
         std::vector<Box6> bounds(ne);
-        for (int i = 0; i < ne; ++i) {
+        parallel_chunks(ne, 4096, [&](int begin, int end) {
+        for (int i = begin; i < end; ++i) {
+            is_sil[i] = edge_is_silhouette(shapes, cam_org, edges[i]);
             const EdgeD &e = edges[i];
             F3 a = edge_v0f(shapes, e), b = edge_v1f(shapes, e);
             Box6 bx;
@@ -576,6 +588,8 @@ EdgeData *build_edge_data(Scene &scene) {
             bx.d_min = vmin(h0, h1); bx.d_max = vmax(h0, h1);
             bounds[i] = bx;
         }
+        });
+        for (int i = 0; i < ne; ++i) (is_sil[i] ? cs_ids : ncs_ids).push_back(i);
         // mean absolute deviation of the endpoints -> billboard half-width
         std::vector<int> all_ids(cs_ids);
         all_ids.insert(all_ids.end(), ncs_ids.begin(), ncs_ids.end());

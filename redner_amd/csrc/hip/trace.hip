@@ -1,11 +1,11 @@
 // trace.hip -- closest-hit / any-hit traversal kernels for gfx950 and the small amount of device
 // state behind exec.h (stream, compaction scratch, timing).
 //
-// v1: one ray per lane, 256-thread workgroups, per-lane traversal stack in scratch; nodes and
-// triangles are read straight from HBM/L2 (the whole bunny_box hierarchy is ~1 MB and lives in the
-// 4 MiB per-XCD L2).  rt::traverse<> is the shared per-ray routine, so results are bit-identical
-// to the brute-force rule in raytri.h.  Measured numbers and the LDS-staged successor are tracked
-// in DESIGN.md section "traversal kernel".
+// One ray per lane, 256-thread workgroups, per-lane traversal stack in an LDS column (16-bit entries when the
+// hierarchy allows); nodes and triangles are read through L1/L2 (the whole bunny_box hierarchy is ~1 MB and lives in
+// the 4 MiB per-XCD L2).  rt::traverse<> is the shared per-ray routine, so results are bit-identical to the
+// brute-force rule in raytri.h.  Measured numbers, what bounds the kernel and the loop shapes that were tried and
+// rejected are in DESIGN.md section "Traversal kernel" and profiles/r1_notes.md.
 #include "exec.h"
 #include <vector>
 
