@@ -620,17 +620,25 @@ EdgeData *build_edge_data(Scene &scene) {
         ed->cs_nodes.swap(cs.nodes); ed->cs_leaves = cs.n;
         ed->ncs_nodes.swap(ncs.nodes); ed->ncs_leaves = ncs.n;
         // the NEE-mode traversal keeps one pending sibling per level in a fixed 64-entry stack
-        for (const std::vector<EdgeNode> *tree : {&ed->cs_nodes, &ed->ncs_nodes}) {
-            if (tree->empty()) continue;
-            std::vector<std::pair<int, int>> todo{{0, 1}};
+        auto depth_of = [](const std::vector<EdgeNode> &tree) {
             int max_depth = 0;
+            if (tree.empty()) return max_depth;
+            std::vector<std::pair<int, int>> todo;
+            todo.reserve(256);
+            todo.push_back({0, 1});
             while (!todo.empty()) {
                 auto [node, depth] = todo.back();
                 todo.pop_back();
                 max_depth = std::max(max_depth, depth);
-                const EdgeNode &nd = (*tree)[node];
+                const EdgeNode &nd = tree[node];
                 if (nd.edge_id == -1 && nd.child0 >= 0) { todo.push_back({nd.child0, depth + 1}); todo.push_back({nd.child1, depth + 1}); }
             }
+            return max_depth;
+        };
+        auto cs_depth = std::async(std::launch::async, [&] { return depth_of(ed->cs_nodes); });
+        const int depths[2] = {depth_of(ed->ncs_nodes), cs_depth.get()};
+        for (int max_depth : depths) {
+            if (max_depth == 0) continue;
             if (max_depth + 2 > 64) throw std::runtime_error("edge hierarchy deeper than the traversal stack (64)");
             ed->max_stack = std::max(ed->max_stack, max_depth + 2);
         }
@@ -646,12 +654,14 @@ EdgeData *build_edge_data(Scene &scene) {
     EdgeSceneD &d = ed->d;
     d.num_edges = ne;
     d.edges = (const EdgeD *)up(edges.data(), sizeof(EdgeD) * edges.size());
+    timer.lap("copy: edges");
     {
         // per-edge geometry records, from the host copies of the shapes
         std::vector<EdgeGeom> geom(edges.size());
         std::vector<ShapeD> hs(scene.shapes.begin(), scene.shapes.end());
         for (size_t i = 0; i < hs.size(); ++i) { hs[i].geom = nullptr; hs[i].vertices = scene.h_vertices[i].data(); hs[i].indices = scene.h_indices[i].data(); }
-        for (size_t i = 0; i < edges.size(); ++i) {
+        parallel_chunks((int)edges.size(), 4096, [&](int begin, int end) {
+        for (int i = begin; i < end; ++i) {
             const EdgeD &e = edges[i];
             EdgeGeom &g = geom[i];
             F3 a = edge_v0f(hs.data(), e), b = edge_v1f(hs.data(), e);
@@ -660,8 +670,10 @@ EdgeData *build_edge_data(Scene &scene) {
             g.o0[0] = o0.x; g.o0[1] = o0.y; g.o0[2] = o0.z; g.o1[0] = o1.x; g.o1[1] = o1.y; g.o1[2] = o1.z;
             g.f0 = e.f0; g.f1 = e.f1; g.has_normals = scene.shapes[e.shape_id].normals != nullptr; g.pad = 0;
         }
+        });
         d.geom = (const EdgeGeom *)up(geom.data(), sizeof(EdgeGeom) * geom.size());
     }
+    timer.lap("copy: edge geometry");
     d.primary_pmf = ed->primary_pmf.empty() ? nullptr : (const double *)up(ed->primary_pmf.data(), sizeof(double) * ne);
     d.primary_cdf = ed->primary_cdf.empty() ? nullptr : (const double *)up(ed->primary_cdf.data(), sizeof(double) * ne);
     // [internal | leaves]: n - 1 interior nodes first, then the n leaves (see TreeBuilder)
@@ -678,7 +690,8 @@ EdgeData *build_edge_data(Scene &scene) {
         root = nodes[0].edge_id != -1 ? ~nodes[0].edge_id : (0 | tree_bit);
         if (num_inner <= 0) return nullptr;               // a single edge: the root reference is the leaf
         std::vector<EdgeNodeP> out(num_inner);
-        for (int i = 0; i < num_inner; ++i) {
+        parallel_chunks(num_inner, 4096, [&](int begin, int end) {
+        for (int i = begin; i < end; ++i) {
             const EdgeNode &n = nodes[i];
             EdgeNodeP &o = out[i];
             const double lo[3] = {n.p_min.x, n.p_min.y, n.p_min.z}, hi[3] = {n.p_max.x, n.p_max.y, n.p_max.z};
@@ -692,9 +705,12 @@ EdgeData *build_edge_data(Scene &scene) {
                 o.c_ref[c] = ref_of(ch[c]);
             }
         }
+        });
         return (const EdgeNodeP *)up(out.data(), sizeof(EdgeNodeP) * out.size());
     };
+    timer.lap("copy: pmf, cdf");
     d.cs_nodes = fatten(ed->cs_nodes, ed->cs_leaves, 0, d.cs_root);
+    timer.lap("copy: 3-D nodes");
     d.ncs_nodes = fatten(ed->ncs_nodes, ed->ncs_leaves, kEdgeTreeBit, d.ncs_root);
     timer.lap("device copies");
     d.edge_bounds_expand = ed->edge_bounds_expand;
