@@ -6,10 +6,15 @@
 #include "scene.h"
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <string>
 
 namespace {
 thread_local std::string g_last_error;
+// rdr_render / rdr_scene_create / rdr_scene_trace are serialised process-wide: the reference's render() is not re-entrant
+// either (global thread pool, src/parallel.cpp:10-14) but runs with the GIL held; ctypes releases the GIL, and two
+// concurrent calls would share the replicated-accumulator symbols, the helper threads and the per-thread scratch.
+std::recursive_mutex g_api_lock;
 void set_error(const char *what) { g_last_error = what ? what : "unknown error"; }
 }
 
@@ -24,6 +29,7 @@ rdr_scene *rdr_scene_create(const rdr_camera_desc *camera, const rdr_shape_desc 
                             int use_primary_edge_sampling, int use_secondary_edge_sampling) {
     try {
         g_last_error.clear();
+        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
         return reinterpret_cast<rdr_scene *>(rdr::create_scene(camera, shapes, num_shapes, materials, num_materials,
                                                                area_lights, num_area_lights, envmap, use_gpu, gpu_index,
                                                                use_primary_edge_sampling, use_secondary_edge_sampling));
@@ -46,6 +52,7 @@ int rdr_render(const rdr_scene *scene, const rdr_render_options *options, float 
         g_last_error.clear();
         if (!scene || !options) throw std::runtime_error("rdr_render: scene and options are required");
         const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
+        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
         exec::select_device(1, s.gpu_index);
         rdr::render(s, *options, rendered_image, d_rendered_image, d_scene, screen_gradient_image, debug_image);
         return 0;
@@ -112,6 +119,7 @@ int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, in
     try {
         g_last_error.clear();
         const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
+        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
         exec::select_device(1, s.gpu_index);
         exec::trace(s.bvh, reinterpret_cast<const rt::RayRec *>(rays), reinterpret_cast<rt::HitRec *>(hits), num_rays, any_hit != 0);
         exec::sync();

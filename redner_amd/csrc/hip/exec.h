@@ -119,6 +119,7 @@ inline void download(void *dst, const void *src, size_t bytes) {
     check(hipStreamSynchronize(ctx().stream), "download sync");
 }
 inline void sync() { check(hipStreamSynchronize(ctx().stream), "sync"); }
+inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 
 // Side streams for stages that do not depend on each other (the edge-pick walks and the bounce adjoint of one path
 // depth): each of them keeps a fraction of the lanes busy and waits on dependent loads, so they fill each other's gaps.
@@ -144,6 +145,7 @@ public:
         int dev = 0;
         check(hipGetDevice(&dev), "hipGetDevice");
         std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return state_ == 0; });              // never overwrite a job that has not been taken / finished
         job_ = std::move(job); device_ = dev; state_ = 1;
         cv_.notify_all();
     }

@@ -84,9 +84,14 @@ hipStream_t side_stream(int k) {
 }
 
 int *persistent_counter() {
-    static thread_local int *ring = nullptr;        // per host thread: its launches are ordered on its own streams
-    static thread_local int slot = 0;
+    // per host thread (its launches are ordered on its own streams) and per device
+    static thread_local int *rings[16] = {};
+    static thread_local int slots[16] = {};
     constexpr int kRing = 4096;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int *&ring = rings[dev & 15];
+    int &slot = slots[dev & 15];
     if (!ring) ring = (int *)dmalloc(sizeof(int) * kRing);
     if (slot == 0) zero(ring, sizeof(int) * kRing);        // stream-ordered: re-zeroed once per lap
     int *p = ring + slot;

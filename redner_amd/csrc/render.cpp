@@ -121,7 +121,10 @@ int run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng_shift,
     // with a fraction of their lanes active (profiles/r1_notes.md), so they fill each other's gaps
     const bool side = g_overlap.load(std::memory_order_relaxed);
     if (side) {
-        static thread_local exec::Fence *queued = new exec::Fence(), *shadow_done = new exec::Fence();   // per host thread
+        static thread_local exec::Fence *fences[16][2] = {};                   // per host thread and device
+        const int dev = exec::current_device();
+        exec::Fence *&queued = fences[dev & 15][0], *&shadow_done = fences[dev & 15][1];
+        if (!queued) { queued = new exec::Fence(); shadow_done = new exec::Fence(); }
         hipStream_t main_stream = exec::ctx().stream;
         queued->after(main_stream);
         {
@@ -584,7 +587,9 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     // host threads drive samples k, k + workers, ... on their own streams with their own buffers.  The forward image
     // needs its fp32 adds in sample order and stays on one stream.
     int workers = 1;
-    if (d_image != nullptr && image == nullptr && lean && opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on)
+    // (the camera-vertex adjoint adds to the screen-gradient image with plain read-modify-writes: one worker then)
+    if (d_image != nullptr && image == nullptr && screen_gradient_image == nullptr && lean &&
+        opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on)
         workers = std::max(1, std::min(exec::sample_workers(P), opt.num_samples));
     Worker w0;
     make_worker(w0);

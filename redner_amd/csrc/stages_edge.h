@@ -240,8 +240,10 @@ struct PrimaryEdgeDerivatives {
         accum3(gv + 3 * rec.edge.v1, pb_bar);
         if (screen_grad) {
             int vw = sc.cam.vp_x1 - sc.cam.vp_x0, vh = sc.cam.vp_y1 - sc.cam.vp_y0;
-            int xi = iclamp(int(pt.x * sc.cam.width - sc.cam.vp_x0), 0, vw);
-            int yi = iclamp(int(pt.y * sc.cam.height - sc.cam.vp_y0), 0, vh);
+            // the reference clamps to [0, vw] x [0, vh] inclusive and writes past the image for a point on the right /
+            // bottom border (src/edge.cpp:765-773); clamped to the last pixel here instead of reproducing the overflow
+            int xi = iclamp(int(pt.x * sc.cam.width - sc.cam.vp_x0), 0, vw - 1);
+            int yi = iclamp(int(pt.y * sc.cam.height - sc.cam.vp_y0), 0, vh - 1);
             accum_f32(screen_grad + 2 * (yi * vw + xi), (float)pt_bar.x);
             accum_f32(screen_grad + 2 * (yi * vw + xi) + 1, (float)pt_bar.y);
         }

@@ -7,12 +7,16 @@ unmodified `pyredner/render_pytorch.py` runs against it:
     import redner_amd; redner_amd.install()     # registers this module as `redner`
     import pyredner                              # the reference's Python package, unchanged
 
-Only what `render_pytorch.py` touches is mirrored (rendering); asset loaders
-(`load_serialized`, `automatic_uv_map`, ...) are out of scope.
+What `render_pytorch.py` touches (rendering) is mirrored in full; of the asset helpers only `load_serialized` is
+provided (pure Python: zlib + numpy), so that `pyredner.load_mitsuba('scenes/bunny_box.xml')` -- the reference's own
+tests/test_bunny_box.py -- runs on this module; `automatic_uv_map` / `rebuild_topology` (xatlas, host-side mesh
+processing) raise NotImplementedError (out of scope).
 Errors raise RuntimeError instead of aborting the process (the reference: assert / exit(1)).
 """
 import ctypes as C
 import enum
+import struct
+import zlib
 
 from . import _capi
 
@@ -398,3 +402,72 @@ def render(scene, options, rendered_image, d_rendered_image, d_scene, screen_gra
                                _addr(screen_gradient_image), _addr(debug_image))
     if rc != 0:
         raise RuntimeError('redner.render: ' + _capi.last_error())
+
+
+# ---- Mitsuba .serialized meshes (src/redner.cpp:232-238, src/load_serialized.cpp:124-288) -----------------------------
+class MitsubaTriMesh:
+    """vertices [V,3] f32, indices [T,3] i32, uvs [V,2] f32 or [0], normals [V,3] f32 or [0] (numpy)."""
+
+    def __init__(self, vertices, indices, uvs, normals):
+        self.vertices, self.indices, self.uvs, self.normals = vertices, indices, uvs, normals
+
+
+def load_serialized(filename, idx):
+    """Sub-mesh `idx` of a Mitsuba 0.5 serialized file: u16 magic, u16 version (3 / 4), a zlib stream per mesh, and
+    at the end of the file the offset table (u64 entries for v4, u32 for v3) followed by the mesh count (u32)."""
+    import numpy as np
+    E_NORMALS, E_TEXCOORDS, E_COLORS, E_DOUBLE = 0x0001, 0x0002, 0x0008, 0x2000
+    with open(filename, 'rb') as f:
+        data = f.read()
+    if len(data) < 8:
+        raise RuntimeError('load_serialized: %s is not a serialized mesh file' % filename)
+    version = struct.unpack_from('<H', data, 2)[0]
+    start = 4
+    if idx > 0:
+        count = struct.unpack_from('<I', data, len(data) - 4)[0]
+        if idx >= count:
+            raise RuntimeError('load_serialized: shape index %d out of range (%d meshes)' % (idx, count))
+        if version == 4:
+            off = struct.unpack_from('<Q', data, len(data) - 4 - 8 * (count - idx))[0]
+        else:
+            off = struct.unpack_from('<I', data, len(data) - 4 * (count - idx + 1))[0]
+        start = off + 4                                   # skip that mesh's own magic + version
+    try:
+        raw = zlib.decompressobj().decompress(data[start:])
+    except zlib.error as e:
+        raise RuntimeError('load_serialized: inflate(): %s' % e)
+    pos = 0
+    flags = struct.unpack_from('<I', raw, pos)[0]
+    pos += 4
+    if version == 4:
+        pos = raw.index(b'\0', pos) + 1                   # null-terminated mesh name
+    n_vert, n_tri = struct.unpack_from('<QQ', raw, pos)
+    pos += 16
+    real = np.dtype('<f8') if flags & E_DOUBLE else np.dtype('<f4')
+
+    def block(count, width, dtype):
+        nonlocal pos
+        a = np.frombuffer(raw, dtype=dtype, count=count * width, offset=pos).reshape(count, width)
+        pos += a.nbytes
+        return a
+
+    vertices = block(n_vert, 3, real).astype(np.float32)
+    normals = block(n_vert, 3, real).astype(np.float32) if flags & E_NORMALS else np.zeros((0,), np.float32)
+    uvs = block(n_vert, 2, real).astype(np.float32) if flags & E_TEXCOORDS else np.zeros((0,), np.float32)
+    if flags & E_COLORS:
+        block(n_vert, 3, real)                             # read and dropped, like the reference
+    indices = block(n_tri, 3, np.dtype('<i4')).astype(np.int32)
+    return MitsubaTriMesh(np.ascontiguousarray(vertices), np.ascontiguousarray(indices), uvs, normals)
+
+
+def _host_mesh_tool(name):
+    def stub(*_a, **_k):
+        raise NotImplementedError('redner.%s is host-side mesh processing outside the renderer hot path '
+                                  '(SURVEY.md section 2.1); use the reference build for it' % name)
+    stub.__name__ = name
+    return stub
+
+
+automatic_uv_map = _host_mesh_tool('automatic_uv_map')
+copy_texture_atlas = _host_mesh_tool('copy_texture_atlas')
+rebuild_topology = _host_mesh_tool('rebuild_topology')

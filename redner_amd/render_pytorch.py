@@ -310,12 +310,11 @@ class RenderFunction(torch.autograd.Function):
         return img
 
     @staticmethod
-    def backward(ctx, grad_img):
-        meta, tensors, u = ctx.meta, ctx.tensors, ctx.u
+    def create_gradient_buffers(meta, tensors):
+        """Zero-initialised gradient tensors mirroring the inputs + the redner.DScene that points at them
+        (pyredner/render_pytorch.py:710-980 create_gradient_buffers).  -> (d_scene, grads)"""
         rd = meta['backend']
         device = meta['device']
-        grad_img = grad_img.contiguous()
-        assert torch.isfinite(grad_img).all()
         grads = [None] * len(tensors)
 
         def zeros_like_arg(i):
@@ -366,6 +365,15 @@ class RenderFunction(torch.autograd.Function):
                                    3, fp(zeros_like_arg(em['uv_scale'])))
             d_envmap = rd.DEnvironmentMap(d_values, fp(zeros_like_arg(em['world_to_env'])))
         d_scene = rd.DScene(d_camera, d_shapes, d_materials, d_lights, d_envmap, device.type == 'cuda', index)
+        return d_scene, grads
+
+    @staticmethod
+    def backward(ctx, grad_img):
+        meta, tensors, u = ctx.meta, ctx.tensors, ctx.u
+        rd = meta['backend']
+        grad_img = grad_img.contiguous()
+        assert torch.isfinite(grad_img).all()
+        d_scene, grads = RenderFunction.create_gradient_buffers(meta, tensors)
         u.options.seed = ctx.seed[1]
         u.options.num_samples = meta['num_samples'][1]
         if 'sample_offset' in meta:
@@ -377,6 +385,32 @@ class RenderFunction(torch.autograd.Function):
         for t, g in zip(tensors, grads):
             out.append(g.to(t.device) if g is not None and t.is_floating_point() else None)
         return (None, None) + tuple(out)
+
+    @staticmethod
+    def visualize_screen_gradient(grad_img, seed, scene, num_samples, max_bounces, use_primary_edge_sampling=True,
+                                  use_secondary_edge_sampling=True, **kw):
+        """Two-channel image of d(pixel colour)/d(screen position) (pyredner/render_pytorch.py:983-1048): one backward
+        render() with a screen_gradient_image; fed by d_primary_intersection (src/primary_intersection.cpp:111-114) and the
+        primary-edge estimator (src/edge.cpp:765-773).  grad_img None = all ones.  kw as for serialize_scene."""
+        args = RenderFunction.serialize_scene(scene, num_samples, max_bounces, **kw)
+        meta, tensors = args[0], args[1:]
+        rd = meta['backend']
+        # the reference passes the two flags straight to unpack_args here (:1014-1015), whatever requires grad
+        meta['use_primary_edge_sampling'] = bool(use_primary_edge_sampling)
+        meta['use_secondary_edge_sampling'] = bool(use_secondary_edge_sampling)
+        u = RenderFunction.unpack_args((seed, seed), meta, tensors)
+        d_scene, _grads = RenderFunction.create_gradient_buffers(meta, tensors)
+        vp = meta['camera']['viewport']
+        nc = rd.compute_num_channels(meta['channels'], u.scene.max_generic_texture_dimension)
+        h, w = vp[2] - vp[0], vp[3] - vp[1]
+        screen_gradient_image = torch.zeros(h, w, 2, device=meta['device'])
+        if grad_img is None:
+            grad_img = torch.ones(h, w, nc, device=meta['device'])
+        grad_img = grad_img.contiguous()
+        assert grad_img.shape == (h, w, nc)
+        rd.render(u.scene, u.options, rd.float_ptr(0), rd.float_ptr(grad_img.data_ptr()), d_scene,
+                  rd.float_ptr(screen_gradient_image.data_ptr()), rd.float_ptr(0))
+        return screen_gradient_image
 
 
 def render(scene, seed, num_samples, max_bounces, **kw):

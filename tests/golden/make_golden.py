@@ -83,6 +83,9 @@ CASES = {
     'single_triangle_64x64x4': ('single_triangle', 64, 4, 1),
     'two_triangles_64x64x16': ('two_triangles', 64, 16, 1),
     'bunny_box_32x32x4': ('bunny_box', 32, 4, 4),
+    # big enough that every scheduling feature of the GPU build is on: side streams, the second sample worker (8 spp),
+    # wave-summed gradient scatters
+    'bunny_box_96x96x8': ('bunny_box', 96, 8, 4),
     # every output channel at once (tests/test_g_buffer.py renders them in groups) + mip-mapped textures
     'textured_sphere_gbuffer_48x48x4': ('textured_sphere', 48, 4, 1, EDGE_SAFE_CHANNELS),
     # The reference itself cannot run these two channels with edge sampling: its generic-texture scratch is
@@ -116,6 +119,15 @@ CASES = {
                                        ['depth', 'shading_normal', 'diffuse_reflectance', 'uv']),
 }
 
+
+# BASELINE configs at their real sizes: config 2 in full; config 3 as a full 512 x 512 frame at
+# reduced spp plus a full-resolution 128 x 128 viewport tile at the full 128 spp.  GPU tests only (tests/test_config_parity.py):
+# the single-threaded CPU harness would need minutes per case.
+CONFIG_CASES = {
+    'two_triangles_256x256x64': ('two_triangles', 256, 64, 1),
+    'bunny_box_512x512x8': ('bunny_box', 512, 8, 4),
+    'bunny_box_tile_512x512x128': ('bunny_box_tile', 512, 128, 4),
+}
 
 # Cases whose backward pass can only be reproduced sample-for-sample by a build that shares the oracle's libm
 # (the CPU harness).  The reference's hierarchical edge pick threads ONE random number through the whole tree
@@ -187,6 +199,67 @@ def render_case(backend, builder, res, spp, mb, channels=None, opts=None, device
     return out
 
 
+# Screen-space gradient images (RenderFunction.visualize_screen_gradient, tests/test_screen_gradient.py: a G-buffer
+# channel at max_bounces 0 with the default sampler); name -> (builder, resolution, spp, max_bounces, channels, options)
+SCREEN_GRADIENT_CASES = {
+    # the reference's script: one reflectance channel, no bounces, PCG sampler, both edge estimators on
+    'screengrad_textured_sphere_albedo_48x48x4': ('textured_sphere', 48, 4, 0, ['diffuse_reflectance'], {'sampler': 'independent'}),
+    # radiance with one bounce: camera-vertex adjoint + primary edges both add to the image
+    'screengrad_two_triangles_64x64x4': ('two_triangles', 64, 4, 1, None, {}),
+    # several channels of different widths, pixel-centre samples
+    'screengrad_textured_sphere_gbuffer_48x48x2': ('textured_sphere', 48, 2, 0, ['depth', 'shading_normal', 'uv'],
+                                                   {'sample_pixel_center': True}),
+}
+
+
+def screen_gradient_case(backend, builder, res, spp, mb, channels=None, opts=None, device=torch.device('cpu')):
+    import scenes
+    from redner_amd.render_pytorch import RenderFunction
+    sc = getattr(scenes, builder)(device, resolution=res if isinstance(res, tuple) else (res, res))
+    ch = None if channels is None else [getattr(backend.channels, c) for c in channels]
+    opts = dict(opts or {})
+    sampler = getattr(backend.SamplerType, opts.pop('sampler', 'sobol'))
+    img = RenderFunction.visualize_screen_gradient(None, 3, sc, spp, mb, channels=ch, sampler_type=sampler, device=device,
+                                                   backend=backend, **opts)
+    return {'screen_gradient': img.cpu().numpy()}
+
+
+# ---- statistical fixtures for the cases a GPU cannot reproduce sample for sample (SAMPLE_EXACT_ON_CPU_ONLY) -------------------
+# Per seed, a vector of linear functionals of the gradient: the translation gradient of the bunny (3), 8 fixed random
+# projections of its vertex gradient, light intensity (3), camera position (3).  tests/test_statistical_parity.py compares
+# the GPU's per-seed vectors with the oracle's: both are draws of the same estimator on the same Sobol' points, differing only
+# in the chaotic edge picks, so their means must agree within Monte-Carlo error.
+STAT_CASES = {
+    'stat_bunny_box_fisheye_32x32x4': ('bunny_box_fisheye', 32, 4, 2),
+    'stat_bunny_box_panorama_32x32x4': ('bunny_box_panorama', 32, 4, 2),
+}
+STAT_SEEDS = list(range(1, 25))
+
+
+def stat_case(backend, builder, res, spp, mb, device=torch.device('cpu'), seeds=STAT_SEEDS):
+    import scenes
+    from redner_amd.render_pytorch import RenderFunction
+    rows = []
+    proj = None
+    for seed in seeds:
+        sc = getattr(scenes, builder)(device, resolution=(res, res))
+        for l in sc.area_lights:
+            l.intensity.requires_grad_(True)
+        sc.camera.position.requires_grad_(True)
+        args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=backend.SamplerType.sobol, device=device, backend=backend)
+        img = RenderFunction.apply(seed, *args)
+        img.sum().backward()
+        verts = [sh.vertices for sh in sc.shapes if sh.vertices.grad is not None]
+        g = verts[0].grad.double().cpu().numpy()
+        if proj is None:
+            proj = np.random.RandomState(12345).standard_normal((8,) + g.shape)
+        row = list(g.sum(0)) + [float((p * g).sum()) for p in proj]
+        row += list(sc.area_lights[0].intensity.grad.double().cpu().numpy()) + list(sc.camera.position.grad.double().cpu().numpy())
+        row.append(float(img.detach().double().mean()))
+        rows.append(row)
+    return {'stats': np.asarray(rows, np.float64)}
+
+
 def main():
     # The reference's primary-edge pass reads ray differentials from a scratch buffer at indices it never
     # wrote (slot- vs lane-indexed, src/edge.cpp:608 vs src/scene.cpp:585), i.e. whatever malloc returned.
@@ -199,12 +272,24 @@ def main():
         export_bunny_box()
     ref = oracle_util.load_oracle()
     only = [a for a in sys.argv[1:] if not a.startswith('--')]
-    for name, case in CASES.items():
-        if only and name not in only:
-            continue
+    for name, case in list(CASES.items()) + list(CONFIG_CASES.items()):
+        if (only and name not in only) or (not only and name in CONFIG_CASES and os.path.exists(os.path.join(HERE, name + '.npz'))):
+            continue                                   # the config-size fixtures take minutes: made once, or on request
         out = render_case(ref, *case)
         np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
         print(name, {k: v.shape for k, v in out.items()})
+    for name, case in STAT_CASES.items():
+        if only and name not in only:
+            continue
+        out = stat_case(ref, *case)
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+        print(name, out['stats'].shape, out['stats'].mean(0)[:4], out['stats'].std(0)[:4])
+    for name, case in SCREEN_GRADIENT_CASES.items():
+        if only and name not in only:
+            continue
+        out = screen_gradient_case(ref, *case)
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+        print(name, {k: (v.shape, float(np.abs(v).sum())) for k, v in out.items()})
 
 
 if __name__ == '__main__':

@@ -33,6 +33,7 @@ inline void zero(void *p, size_t bytes) { memset(p, 0, bytes); }
 inline void upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void download(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void sync() {}
+inline int current_device() { return 0; }
 }
 typedef void *hipStream_t;       // the host driver names streams; the harness has one implicit stream
 namespace exec {

@@ -1,0 +1,57 @@
+"""Shared comparison of a rendered case against the oracle's fixture: whole-tensor relative L2 per tensor, no masks.
+
+`flipped_rows` is reported (not used to excuse anything): the number of vertex rows whose error stands out of the
+fp32-atomics noise floor.  A Monte-Carlo decision that differs from the oracle (one edge sample landing on another
+edge) changes <= 4 rows by an O(1/N) amount; 0 means the two runs drew the same samples everywhere."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle_util import rel_l2
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+TOL = 1e-4           # BASELINE.json north_star: 1e-4 relative L2, forward image and every gradient tensor
+
+
+def compare(out, gold):
+    """-> {tensor: {'rel_l2': e, 'flipped_rows': k}}; asserts keys match and values are finite."""
+    gold = {k: gold[k] for k in (gold.files if hasattr(gold, 'files') else gold)}
+    assert set(out.keys()) == set(gold.keys()), (sorted(out.keys()), sorted(gold.keys()))
+    rep = {}
+    for k, gv in gold.items():
+        g, mine = torch.from_numpy(np.asarray(gv)), torch.from_numpy(np.asarray(out[k]))
+        assert torch.isfinite(mine).all(), k
+        gn = float(g.double().norm())
+        if gn == 0.0:
+            rep[k] = {'rel_l2': float(mine.double().norm()), 'flipped_rows': 0, 'zero_reference': True}
+            continue
+        entry = {'rel_l2': rel_l2(mine, g), 'flipped_rows': 0}
+        if k.endswith('_vertices') and g.dim() == 2:
+            row_err = (mine.double() - g.double()).norm(dim=1)
+            entry['flipped_rows'] = int((row_err > 1e-5 * gn).sum())
+        rep[k] = entry
+    return rep
+
+
+def assert_parity(rep, name=''):
+    """Whole-tensor bar, every tensor, no row dropping."""
+    for k, e in rep.items():
+        if e.get('zero_reference'):
+            assert e['rel_l2'] < 1e-12, (name, k, e)
+        else:
+            assert e['rel_l2'] < TOL, (name, k, e)
+
+
+def summary(rep):
+    worst = max((e['rel_l2'] for e in rep.values() if not e.get('zero_reference')), default=0.0)
+    return {'worst_rel_l2': worst, 'flipped_rows': sum(e['flipped_rows'] for e in rep.values())}
+
+
+def record(name, rep, backend_tag):
+    """Append the per-tensor numbers of one case to $RDR_PARITY_REPORT (a JSON-lines file), if set."""
+    path = os.environ.get('RDR_PARITY_REPORT')
+    if path:
+        with open(path, 'a') as f:
+            f.write(json.dumps({'case': name, 'backend': backend_tag, **summary(rep), 'tensors': rep}) + '\n')

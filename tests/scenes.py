@@ -83,6 +83,15 @@ def bunny_box(device, resolution=(512, 512), vertex_grad=True):
     return Scene(cam, shapes, mats, lights)
 
 
+def bunny_box_tile(device, resolution=(512, 512)):
+    """BASELINE config 3 at full resolution and full spp, restricted by the camera viewport to the 128 x 128 tile
+    (rows 256..384, columns 128..256) that holds the bunny's ears, head and back against the back wall
+    ("full-resolution tile via viewport")."""
+    sc = bunny_box(device, resolution)
+    sc.camera.viewport = (256, 128, 384, 256)
+    return sc
+
+
 def _mip_chain(base):
     """Box-filtered mip levels down to 1x1 ([H, W, C] tensors); stands in for pyredner.Texture's
     own generation (pyredner/texture.py), which is host-side Python outside the hot path."""

@@ -57,3 +57,66 @@ def test_unmodified_pyredner_runs_on_our_redner(hostsim_backend, tmp_path):
     assert np.array_equal(a['image'], b['image'])
     rel = np.linalg.norm(a['grad'].astype(np.float64) - b['grad']) / np.linalg.norm(b['grad'])
     assert rel < 1e-4, rel
+
+
+# ---- the reference's own tests/test_bunny_box.py recipe: load_mitsuba -> serialize -> render -> backward ------------
+BUNNY_SCRIPT = r'''
+import os, sys
+sys.path[:0] = [%(root)r, %(root)r + '/tests', %(root)r + '/oracle/pystubs', %(ref)r]
+import numpy as np, torch
+which = sys.argv[1]
+if which == 'mine':
+    from redner_amd import _capi
+    _capi.load(%(lib)r)
+    import redner_amd
+    redner_amd.install()
+else:
+    import oracle_util
+    sys.modules['redner'] = oracle_util.load_oracle()
+import redner, pyredner
+pyredner.set_use_gpu(False)
+os.chdir(%(ref)r + '/tests')
+scene = pyredner.load_mitsuba('scenes/bunny_box.xml')          # goes through redner.load_serialized
+scene.shapes[-1].vertices.requires_grad = True
+scene.camera.resolution = (24, 24)
+args = pyredner.RenderFunction.serialize_scene(scene=scene, num_samples=2, max_bounces=4,
+                                               sampler_type=redner.SamplerType.sobol)
+img = pyredner.RenderFunction.apply(1, *args)
+img.sum().backward()
+np.savez(sys.argv[2], image=img.detach().numpy(), grad=scene.shapes[-1].vertices.grad.numpy())
+'''
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, 'pyredner')), reason='reference checkout not mounted')
+def test_load_mitsuba_bunny_box_on_our_redner(hostsim_backend, tmp_path):
+    import numpy as np
+    from conftest import HOSTSIM_LIB
+    script = tmp_path / 'dropin_bunny.py'
+    script.write_text(BUNNY_SCRIPT % {'root': ROOT, 'ref': REF, 'lib': HOSTSIM_LIB})
+    outs = {}
+    for which in ('mine', 'oracle'):
+        out = str(tmp_path / (which + '.npz'))
+        subprocess.check_call([sys.executable, str(script), which, out], stdout=subprocess.DEVNULL, timeout=900)
+        outs[which] = np.load(out)
+    a, b = outs['mine'], outs['oracle']
+    assert np.array_equal(a['image'], b['image'])
+    rel = np.linalg.norm(a['grad'].astype(np.float64) - b['grad']) / np.linalg.norm(b['grad'])
+    assert rel < 1e-4, rel
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, 'tests/scenes/teapot.serialized')), reason='reference checkout not mounted')
+def test_load_serialized_equals_reference():
+    """redner.load_serialized (zlib + numpy) vs the reference's C++ loader (src/load_serialized.cpp) on every sub-mesh."""
+    import numpy as np
+    import oracle_util
+    from redner_amd import redner
+    ref = oracle_util.load_oracle()
+    for fn, n in (('bunny_box.serialized', 7), ('teapot.serialized', 6), ('teapot_specular.serialized', 7)):
+        path = os.path.join(REF, 'tests/scenes', fn)
+        for i in range(n):
+            a, b = redner.load_serialized(path, i), ref.load_serialized(path, i)
+            for name in ('vertices', 'indices', 'uvs', 'normals'):
+                x, y = getattr(a, name), getattr(b, name)
+                assert x.dtype == y.dtype and np.array_equal(x.reshape(-1), y.reshape(-1)), (fn, i, name)
+        with pytest.raises(RuntimeError):
+            redner.load_serialized(path, n)

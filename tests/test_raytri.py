@@ -115,3 +115,49 @@ def test_gpu_traversal_equals_host_rule(gpu_backend, any_hit):
         assert np.array_equal(hits[:, 0] >= 0, ref[:, 0] >= 0)
     else:
         assert np.array_equal(hits, ref)
+
+
+# ---- the reference's own known-answer test at this boundary, through the product ------------------------------------
+def _kat_scene(device):
+    """test_scene_intersect (src/scene.cpp:761-848): one triangle at z = 1, a 1 x 1 camera at the origin looking down +z
+    with identity intrinsics; ray 0 = (0,0,0)->(0,0,1) must hit (shape 0, triangle 0) at (0,0,1), ray 1 = ->(0,0,-1) must miss."""
+    from redner_amd.render_pytorch import Camera, Material, Scene, Shape
+    cam = Camera(position=torch.tensor([0.0, 0.0, 0.0]), look_at=torch.tensor([0.0, 0.0, 1.0]), up=torch.tensor([0.0, 1.0, 0.0]),
+                 intrinsic_mat=torch.eye(3), clip_near=1e-2, resolution=(1, 1))
+    tri = Shape(torch.tensor([[-1.0, 0.0, 1.0], [1.0, 0.0, 1.0], [0.0, 1.0, 1.0]], device=device),
+                torch.tensor([[0, 1, 2]], dtype=torch.int32, device=device), 0)
+    return Scene(cam, [tri], [Material(diffuse_reflectance=torch.tensor([0.5, 0.5, 0.5], device=device))], [])
+
+
+def _run_reference_kat(backend, device):
+    from redner_amd import _capi
+    sc = _kat_scene(device)
+    args = RenderFunction.serialize_scene(sc, 1, 0, channels=[backend.channels.position, backend.channels.shape_id,
+                                                            backend.channels.triangle_id],
+                                          sampler_type=backend.SamplerType.sobol, device=device, backend=backend,
+                                          sample_pixel_center=True)
+    u = RenderFunction.unpack_args((1, 2), args[0], args[1:])
+    rays = torch.tensor([[0, 0, 0, 1e-3, 0, 0, 1, float('inf')], [0, 0, 0, 1e-3, 0, 0, -1, float('inf')]],
+                        dtype=torch.float32, device=device)
+    for any_hit in (0, 1):
+        hits = torch.full((2, 2), 7, dtype=torch.int32, device=device)
+        assert _capi.lib().rdr_scene_trace(u.scene._handle, rays.data_ptr(), hits.data_ptr(), 2, any_hit) == 0
+        h = hits.cpu().numpy()
+        if any_hit:
+            assert h[0, 0] >= 0 and h[1, 0] < 0
+        else:
+            assert h.tolist() == [[0, 0], [-1, -1]]          # isects[0] = (0, 0), isects[1] = (-1, -1)
+    # surface_points[0].position == (0, 0, 1): the fp64 re-intersection, seen through the position channel of the
+    # camera ray of that 1 x 1 image (the same ray as ray 0)
+    img = RenderFunction.apply(1, *args).cpu().numpy()
+    assert np.allclose(img[0, 0, 0:3], [0.0, 0.0, 1.0], atol=1e-6)
+    assert img[0, 0, 3] == 0 and img[0, 0, 4] == 0
+
+
+def test_reference_scene_intersect_kat_hostsim(hostsim_backend):
+    _run_reference_kat(hostsim_backend, torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_reference_scene_intersect_kat_gpu(gpu_backend):
+    _run_reference_kat(gpu_backend, torch.device('cuda:0'))
