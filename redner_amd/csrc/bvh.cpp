@@ -156,6 +156,28 @@ struct Builder {
 
 } // namespace
 
+// Hierarchy over axis-aligned boxes (6 floats each: lo.xyz, hi.xyz) with the same builder: leaves list box indices in
+// `ids` ({0, box index} per slot), `tris` stays empty.  Node bounds are padded unions of the given boxes, so a query that
+// is monotone in box inclusion can cull with the nodes and decide exactly at the leaves (the NEE-mode edge gather).
+BvhHost build_box_bvh(const float *boxes, int n) {
+    Builder bd;
+    if (n <= 0) return bd.out;
+    std::vector<Prim> prims((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        Prim &p = prims[i];
+        p.shape = 0; p.prim = i;
+        for (int a = 0; a < 3; ++a) {
+            p.lo[a] = boxes[6 * i + a]; p.hi[a] = boxes[6 * i + 3 + a];
+            p.c[a] = 0.5f * (p.lo[a] + p.hi[a]);
+        }
+        for (int k = 0; k < 9; ++k) p.v[k] = 0.f;
+    }
+    bd.prims = prims.data();
+    bd.build_top(0, n, 0);
+    bd.out.tris.clear();
+    return bd.out;
+}
+
 BvhHost build_bvh(const std::vector<MeshView> &meshes) {
     Builder bd;
     std::vector<Prim> prims;

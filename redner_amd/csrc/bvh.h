@@ -111,4 +111,6 @@ struct BvhHost {
 struct MeshView { const float *vertices; const int *indices; int num_triangles; };
 // Binned-SAH top-down build over all triangles of all shapes (shape id = position in `meshes`).
 BvhHost build_bvh(const std::vector<MeshView> &meshes);
+// Same builder over boxes (lo.xyz, hi.xyz per box); leaf slots hold {0, box index} in `ids`, no triangle records.
+BvhHost build_box_bvh(const float *boxes, int n);
 }

@@ -642,11 +642,53 @@ EdgeData *build_edge_data(Scene &scene) {
             if (max_depth + 2 > 64) throw std::runtime_error("edge hierarchy deeper than the traversal stack (64)");
             ed->max_stack = std::max(ed->max_stack, max_depth + 2);
         }
+        timer.lap("depth check");
+        // ---- the order-free form of the NEE-mode pick (stages_edge.h: SecEdgeGatherN) ----
+        // (a) the order in which the reference's walk reaches the leaves: roots pushed 3-D tree first, 6-D tree second,
+        //     children pushed 0 then 1, last pushed popped first (src/edge.cpp:1239-1318)
+        ed->leaf_rank.assign(ne, 0);
+        ed->leaf_dx.assign((size_t)2 * ne, 0.0);
+        {
+            int rank = 0;
+            const double inf = std::numeric_limits<double>::infinity();
+            std::vector<int> todo;
+            for (int t = 1; t >= 0; --t) {            // 6-D tree first
+                const std::vector<EdgeNode> &tree = t == 1 ? ed->ncs_nodes : ed->cs_nodes;
+                if (tree.empty()) continue;
+                todo.assign(1, 0);
+                while (!todo.empty()) {
+                    const EdgeNode &nd = tree[todo.back()];
+                    todo.pop_back();
+                    if (nd.edge_id != -1) {
+                        ed->leaf_rank[nd.edge_id] = rank++;
+                        ed->leaf_dx[2 * (size_t)nd.edge_id] = t == 1 ? nd.d_min.x : -inf;
+                        ed->leaf_dx[2 * (size_t)nd.edge_id + 1] = t == 1 ? nd.d_max.x : inf;
+                    } else { todo.push_back(nd.child0); todo.push_back(nd.child1); }
+                }
+            }
+        }
+        // (b) spatial hierarchy over the billboard boxes: each edge's own spatial bounds grown by the billboard half-width
+        //     (rounded outwards; the builder pads every node box on top of that)
+        {
+            std::vector<float> boxes((size_t)6 * ne);
+            const double e = ed->edge_bounds_expand;
+            for (int i = 0; i < ne; ++i) {
+                const double lo[3] = {bounds[i].p_min.x - e, bounds[i].p_min.y - e, bounds[i].p_min.z - e};
+                const double hi[3] = {bounds[i].p_max.x + e, bounds[i].p_max.y + e, bounds[i].p_max.z + e};
+                for (int k = 0; k < 3; ++k) {
+                    boxes[6 * (size_t)i + k] = std::nextafterf((float)lo[k], -std::numeric_limits<float>::infinity());
+                    boxes[6 * (size_t)i + 3 + k] = std::nextafterf((float)hi[k], std::numeric_limits<float>::infinity());
+                }
+            }
+            ed->gather = rt::build_box_bvh(boxes.data(), ne);
+            if (ed->gather.depth + 2 > 64) throw std::runtime_error("edge gather hierarchy deeper than the traversal stack (64)");
+        }
+        timer.lap("gather hierarchy");
     }
 
     // ---- device view ----
     auto up = [&](const void *src, size_t bytes) -> void * {
-        void *p = exec::dmalloc(bytes);
+        void *p = exec::pool_alloc(bytes);
         scene.owned.push_back(p);
         if (bytes) exec::upload(p, src, bytes);
         return p;
@@ -713,6 +755,18 @@ EdgeData *build_edge_data(Scene &scene) {
     timer.lap("copy: 3-D nodes");
     d.ncs_nodes = fatten(ed->ncs_nodes, ed->ncs_leaves, kEdgeTreeBit, d.ncs_root);
     timer.lap("device copies");
+    d.gather = rt::BvhD{nullptr, nullptr, nullptr, 0, 0, 2};
+    d.leaf_dx = nullptr; d.leaf_rank = nullptr;
+    if (!ed->gather.nodes.empty()) {
+        d.gather.nodes = (const rt::Node *)up(ed->gather.nodes.data(), sizeof(rt::Node) * ed->gather.nodes.size());
+        d.gather.ids = (const int *)up(ed->gather.ids.data(), sizeof(int) * ed->gather.ids.size());
+        d.gather.num_nodes = (int)ed->gather.nodes.size();
+        d.gather.num_tris = (int)ed->gather.ids.size() / 2;
+        d.gather.stack_need = ed->gather.depth + 2;
+        d.leaf_dx = (const double *)up(ed->leaf_dx.data(), sizeof(double) * ed->leaf_dx.size());
+        d.leaf_rank = (const int *)up(ed->leaf_rank.data(), sizeof(int) * ed->leaf_rank.size());
+    }
+    timer.lap("copy: gather");
     d.edge_bounds_expand = ed->edge_bounds_expand;
     d.max_stack = ed->max_stack;
     d.cam_org = cam_org;

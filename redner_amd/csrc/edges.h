@@ -14,6 +14,7 @@
 // reference's build step by step, including the behaviour of the sequential sort it runs on CPU.
 #pragma once
 #include "surface.h"
+#include "bvh.h"
 #include <vector>
 
 namespace rdr {
@@ -49,6 +50,10 @@ RDR_FN V3 v3_of(const float *p) { return V3{(double)p[0], (double)p[1], (double)
 
 constexpr int kEdgeTreeBit = 1 << 30;
 
+// One positive-weight leaf found by the NEE-mode gather (stages_edge.h: SecEdgeGatherN), replayed in `rank` order.
+struct GatherCand { int rank, eid; double w; };
+constexpr int kGatherCands = 8;          // per slot; a slot that finds more falls back to the reference-order walk
+
 struct EdgeGeom;
 struct EdgeSceneD {
     const EdgeD *edges;
@@ -61,6 +66,13 @@ struct EdgeSceneD {
     int max_stack;           // entries the NEE-mode traversal can need: deepest leaf level + 1
     V3 cam_org;
     const float *ltc;                         // tabM, 128 x 128 x 9
+    // NEE-mode pick as an order-free gather (see SecEdgeGatherN): a spatial hierarchy over the billboard boxes of ALL
+    // edges (rt::Node records; leaf slot s holds edge id gather.ids[2 s + 1]), the Hough x-interval of each edge's own
+    // leaf in the reference's 6-D tree ((-inf, +inf) for edges of the 3-D tree, which is never Hough-tested), and each
+    // edge's position in the order the reference's traversal reaches the leaves (for the reservoir replay).
+    rt::BvhD gather;
+    const double *leaf_dx;                    // 2 per edge
+    const int *leaf_rank;                     // 1 per edge
 };
 
 constexpr int kNoEdgeTree = 0x7fffffff;
@@ -192,6 +204,9 @@ struct EdgeData {
     int cs_leaves = 0, ncs_leaves = 0;
     int max_stack = 2;             // see EdgeSceneD::max_stack
     double edge_bounds_expand = 0;
+    rt::BvhHost gather;            // see EdgeSceneD::gather
+    std::vector<double> leaf_dx;
+    std::vector<int> leaf_rank;
     EdgeSceneD d;            // device view
 };
 EdgeData *build_edge_data(Scene &scene);

@@ -109,6 +109,13 @@ inline void *dmalloc(size_t bytes) {
     return p;
 }
 inline void dfree(void *p) { if (p) (void)hipFree(p); }
+// Caching allocator behind every per-call buffer (trace.hip): blocks go back to a per-device free list instead of
+// hipFree, so a render() / Scene of the same shape as an earlier one allocates nothing (hipMalloc + hipFree of the ~60
+// arrays of a 1024 x 1024 render cost milliseconds and hipFree synchronises the device).  pool_trim() releases the cache.
+void *pool_alloc(size_t bytes);
+void pool_free(void *p);
+void pool_trim();
+size_t pool_device_mallocs();          // number of hipMalloc calls made by the pool so far (tests: steady state adds none)
 inline void zero(void *p, size_t bytes) { if (bytes) check(hipMemsetAsync(p, 0, bytes, ctx().stream), "hipMemsetAsync"); }
 inline void upload(void *dst, const void *src, size_t bytes) {
     if (bytes) check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().stream), "upload");

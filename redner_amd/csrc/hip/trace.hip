@@ -7,6 +7,9 @@
 // brute-force rule in raytri.h.  Measured numbers, what bounds the kernel and the loop shapes that were tried and
 // rejected are in DESIGN.md section "Traversal kernel" and profiles/r1_notes.md.
 #include "exec.h"
+#include <algorithm>
+#include <map>
+#include <unordered_map>
 #include <vector>
 
 namespace exec {
@@ -25,6 +28,66 @@ void select_device(int use_gpu, int gpu_index) {
     if (gpu_index >= count) throw std::runtime_error("redner_amd: gpu_index out of range");
     check(hipSetDevice(gpu_index), "hipSetDevice");
 }
+
+namespace {
+struct Pool {
+    std::mutex lock;
+    std::multimap<size_t, void *> free_blocks[16];              // per device, by capacity
+    std::unordered_map<void *, std::pair<size_t, int>> live;    // block -> (capacity, device)
+    size_t device_mallocs = 0;
+};
+Pool &pool() { static Pool *p = new Pool(); return *p; }       // never destroyed: blocks may be returned during exit
+}
+
+void *pool_alloc(size_t bytes) {
+    const size_t want = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Pool &pl = pool();
+    {
+        std::lock_guard<std::mutex> lk(pl.lock);
+        auto &fl = pl.free_blocks[dev & 15];
+        auto it = fl.lower_bound(want);
+        if (it != fl.end() && it->first <= want + want / 4 + 4096) {          // close fit: reuse
+            void *p = it->second;
+            pl.live[p] = {it->first, dev};
+            fl.erase(it);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {             // out of memory with blocks parked in the cache: release them and retry once
+        (void)hipGetLastError();
+        pool_trim();
+        check(hipMalloc(&p, want), "hipMalloc");
+    }
+    std::lock_guard<std::mutex> lk(pl.lock);
+    pl.device_mallocs++;
+    pl.live[p] = {want, dev};
+    return p;
+}
+
+void pool_free(void *p) {
+    if (!p) return;
+    Pool &pl = pool();
+    std::lock_guard<std::mutex> lk(pl.lock);
+    auto it = pl.live.find(p);
+    if (it == pl.live.end()) { (void)hipFree(p); return; }
+    pl.free_blocks[it->second.second & 15].emplace(it->second.first, p);
+    pl.live.erase(it);
+}
+
+void pool_trim() {
+    Pool &pl = pool();
+    std::lock_guard<std::mutex> lk(pl.lock);
+    for (auto &fl : pl.free_blocks) {
+        for (auto &kv : fl) (void)hipFree(kv.second);
+        fl.clear();
+    }
+}
+
+size_t pool_device_mallocs() { Pool &pl = pool(); std::lock_guard<std::mutex> lk(pl.lock); return pl.device_mallocs; }
 
 CompactScratch &compact_scratch(int nblocks) {
     static thread_local CompactScratch per_device[16];

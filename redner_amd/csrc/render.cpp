@@ -27,15 +27,16 @@ namespace {
 // that bench.py can time the traversal kernel on its own in an extra, untimed pass (RDR_NO_OVERLAP=1).
 std::atomic<bool> g_overlap{true};
 
-// Device arena: one allocation per render() call, carved into typed arrays.
+// Device arena: typed arrays from the caching allocator (exec::pool_alloc); they go back to its free lists when the
+// call ends, so the next render() of the same shape performs no hipMalloc / hipFree at all.
 struct Arena {
     std::vector<void *> blocks;
     template <class T> T *get(size_t count) {
-        T *p = (T *)exec::dmalloc(sizeof(T) * (count ? count : 1));
+        T *p = (T *)exec::pool_alloc(sizeof(T) * (count ? count : 1));
         blocks.push_back(p);
         return p;
     }
-    ~Arena() { for (void *p : blocks) exec::dfree(p); }
+    ~Arena() { for (void *p : blocks) exec::pool_free(p); }
 };
 
 VSlice make_slice(Arena &a, int n, bool with_occl) {
@@ -311,6 +312,9 @@ struct Backward {
             }
             for (int k = 0; k < 3; ++k) elist[k] = arena.get<int>(L);
             nee_slots = arena.get<int>(P);
+            gather_cands = arena.get<GatherCand>((size_t)kGatherCands * P);
+            h_leaves = arena.get<HLeaf>((size_t)kHSamples * P);
+            h_spill = arena.get<HLeaf>((size_t)(kHSamples - kHStackLds) * P);
             edge_contrib = arena.get<double>(L);
             edge_tmin = arena.get<double>(L);
             hit_pos = arena.get<double>((size_t)3 * L);
@@ -331,6 +335,8 @@ struct Backward {
 
     VSlice ea, eb;                 // ping-pong vertex slices of the edge sub-paths (2P lanes each)
     int *elist[3] = {nullptr, nullptr, nullptr};
+    HLeaf *h_leaves = nullptr, *h_spill = nullptr;   // hierarchical pick: recorded leaves / spilled stack entries per list position
+    GatherCand *gather_cands = nullptr;        // positive leaves found by the NEE-mode gather, kGatherCands per list position
     int *nee_slots = nullptr;                  // slots of the NEE-mode edge pick (its walk runs beside the hierarchical pick)
     exec::Fence depth_begin, adjoint_done, setup_done, walk_done;
     const bool overlap = g_overlap.load(std::memory_order_relaxed);
@@ -349,14 +355,30 @@ struct Backward {
     SamplerD edge_rng_at(const SamplerD &rng_edge, int edim) const { SamplerD r = rng_edge; r.pcg_base = edim; return r; }
 
     template <bool LEAN> void launch_pick_n(int need, int nN, const SecEdgeArgs &sa) {
+        // order-free gather over the billboard hierarchy (SecEdgeGatherN), then the reference-order walk for the slots it
+        // marked kPickOverflow (none in practice); RDR_PICKN_WALK=1 walks every slot instead (A/B measurements)
+        static const bool walk_all = std::getenv("RDR_PICKN_WALK") != nullptr;
+        const bool gather = !walk_all && sa.es.gather.num_nodes > 0;
+        if (gather) {
+            auto run = [&](auto stage) {
+                if (LEAN) exec::launch(nN, LeanStage<decltype(stage)>{stage}); else exec::launch(nN, stage);
+            };
+            const int gneed = sa.es.gather.stack_need;
+            const bool narrow = sa.es.gather.num_nodes < 65536;
+            if (gneed <= 32 && narrow) run(SecEdgeGatherN<32, unsigned short>{sa, nee_slots, sec_picks, gather_cands});
+            else if (gneed <= 32) run(SecEdgeGatherN<32, int>{sa, nee_slots, sec_picks, gather_cands});
+            else if (narrow) run(SecEdgeGatherN<64, unsigned short>{sa, nee_slots, sec_picks, gather_cands});
+            else run(SecEdgeGatherN<64, int>{sa, nee_slots, sec_picks, gather_cands});
+        }
+        const int only_overflow = gather ? 1 : 0;
         auto go = [&](auto walk) {
             if (LEAN) exec::launch_persistent(nN, LeanWalk<decltype(walk)>{walk});
             else exec::launch_persistent(nN, walk);
         };
-        if (need <= 24) go(SecEdgePickNWalk<24>{sa, nee_slots, sec_picks});
-        else if (need <= 32) go(SecEdgePickNWalk<32>{sa, nee_slots, sec_picks});
-        else if (need <= 48) go(SecEdgePickNWalk<48>{sa, nee_slots, sec_picks});
-        else go(SecEdgePickNWalk<64>{sa, nee_slots, sec_picks});
+        if (need <= 24) go(SecEdgePickNWalk<24>{sa, nee_slots, sec_picks, only_overflow});
+        else if (need <= 32) go(SecEdgePickNWalk<32>{sa, nee_slots, sec_picks, only_overflow});
+        else if (need <= 48) go(SecEdgePickNWalk<48>{sa, nee_slots, sec_picks, only_overflow});
+        else go(SecEdgePickNWalk<64>{sa, nee_slots, sec_picks, only_overflow});
     }
 
     int trace_edge_paths(const SamplerD &rng_edge, int edim, int n_act, int n_slots, int first_depth, const Queues &q,
@@ -427,7 +449,9 @@ struct Backward {
                     else launch_pick_n<false>(need, nN, sa);
                     if (side) walk_done.after(exec::ctx().stream);
                 }
-                launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
+                static const bool pickh_fused = std::getenv("RDR_PICKH_FUSED") != nullptr;     // A/B: the one-loop form
+                if (pickh_fused) launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
+                else launch_v(lean, nH, SecEdgePickH2{sa, elist[0], sec_picks, h_leaves, h_spill, nH});
                 if (side) walk_done.gate(main_stream);
                 if (nH == 0 && nN == 0) {
                     // no slot samples an edge here (typically: every path already passed a diffuse vertex,

@@ -20,7 +20,7 @@ namespace {
 
 template <class T>
 T *to_device(Scene &s, const T *src, size_t count) {
-    T *p = (T *)exec::dmalloc(sizeof(T) * (count ? count : 1));
+    T *p = (T *)exec::pool_alloc(sizeof(T) * (count ? count : 1));
     s.owned.push_back(p);
     if (count) exec::upload(p, src, sizeof(T) * count);
     return p;
@@ -50,7 +50,7 @@ M3 m3_from(const float *p) { M3 m; for (int i = 0; i < 3; ++i) for (int j = 0; j
 
 Scene::~Scene() {
     delete_edge_data(edges);
-    for (void *p : owned) exec::dfree(p);
+    for (void *p : owned) exec::pool_free(p);
 }
 
 int compute_num_channels(const int *channels, int n, int max_generic) {

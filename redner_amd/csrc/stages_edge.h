@@ -486,6 +486,97 @@ RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, co
 #undef RDR_H_PUSH
 }
 
+// The same pick with the leaf work deferred (SecEdgePickH2).  Interior steps consume only `sample`, leaf steps only
+// `resample` and the reservoir, so the two sequences are independent: the descent records the leaves it pops, in pop
+// order, and a second loop evaluates their importance and runs the reservoir -- the same operations on the same operands
+// in the same order per variable.  On the GPU the lanes of a wave then run the (cheap, uniform) descent together and the
+// (expensive: silhouette test + two LTC line integrals) leaf evaluations together instead of serialising the two bodies
+// whenever a wave holds both kinds of entries (lane utilisation of the fused loop: 0.44, profiles/r1_pmc_sq.csv).
+// The descent stack keeps kHStackLds entries per lane in LDS (13 B each: 4 workgroups per CU instead of 3) and spills the
+// rare deeper entries to `spill`; the leaf list lives in HBM (written and read once, coalesced by entry index).
+struct HLeaf { int ref, num; double pmf; };        // 16 B; ref: ~edge id for leaves, node reference for spilled stack entries
+constexpr int kHStackLds = 12;
+RDR_DEV_FN int pick_edge_hierarchical_deferred(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c, double sample, double resample,
+                                               double &weight, HLeaf *leaves, HLeaf *spill, size_t stride) {
+    const SilQuery q_pos = sil_query(es, c.pos);
+    RDR_STACK_DECL(int, st_ref, kHStackLds);
+    RDR_STACK_DECL(unsigned char, st_num, kHStackLds);
+    RDR_STACK_DECL(double, st_pmf, kHStackLds);
+    int sp = 0, nleaf = 0;
+    auto push = [&](int r, int n, double p) {
+        if (sp < kHStackLds) { RDR_STACK_AT(st_ref, sp) = r; RDR_STACK_AT(st_num, sp) = (unsigned char)n; RDR_STACK_AT(st_pmf, sp) = p; }
+        else spill[(size_t)(sp - kHStackLds) * stride] = HLeaf{r, n, p};
+        sp++;
+    };
+    double imp_cs = es.cs_root != kNoEdgeTree ? 1.0 : 0.0, imp_ncs = es.ncs_root != kNoEdgeTree ? 1.0 : 0.0;
+    if (imp_cs <= 0 && imp_ncs <= 0) return -1;
+    double prob_cs = imp_cs / (imp_cs + imp_ncs), prob_ncs = 1 - prob_cs;
+    double exp_cs = kHSamples * prob_cs, exp_ncs = kHSamples * prob_ncs;
+    int n_cs = int(floor(exp_cs)), n_ncs = int(floor(exp_ncs));
+    if (n_cs + n_ncs < kHSamples) {
+        double prob = exp_cs - n_cs;
+        if (sample < prob) { n_cs++; sample /= prob; }
+        else { n_ncs++; sample = (sample - prob) / (1 - prob); }
+    }
+    if (n_cs > 0) push(es.cs_root, n_cs, prob_cs);
+    if (n_ncs > 0) push(es.ncs_root, n_ncs, prob_ncs);
+    // every live entry (pending or recorded leaf) carries >= 1 of the kHSamples samples: sp + nleaf <= kHSamples
+    while (sp > 0) {
+        --sp;
+        HItem it;
+        if (sp < kHStackLds) it = HItem{RDR_STACK_AT(st_ref, sp), (int)RDR_STACK_AT(st_num, sp), RDR_STACK_AT(st_pmf, sp)};
+        else { const HLeaf sl = spill[(size_t)(sp - kHStackLds) * stride]; it = HItem{sl.ref, sl.num, sl.pmf}; }
+        if (it.ref < 0) {
+            leaves[(size_t)nleaf * stride] = HLeaf{it.ref, it.num, it.pmf};
+            nleaf++;
+            continue;
+        }
+        const EdgeNodeP &nd = edge_node(es, it.ref);
+        const int tree = it.ref & kEdgeTreeBit;
+        const bool tree3d = tree == 0;
+        int c0 = nd.c_ref[0] < 0 ? nd.c_ref[0] : (nd.c_ref[0] | tree);
+        int c1 = nd.c_ref[1] < 0 ? nd.c_ref[1] : (nd.c_ref[1] | tree);
+        double i0, i1;
+        if (box_contains(v3_of(nd.p_min), v3_of(nd.p_max), c.pos)) { i0 = i1 = 1; }
+        else { i0 = node_importance(nd, 0, tree3d, c, q_pos); i1 = node_importance(nd, 1, tree3d, c, q_pos); }
+        if (i0 > 0 || i1 > 0) {
+            double p0 = i0 / (i0 + i1), p1 = 1 - p0;
+            double e0 = it.num * p0, e1 = it.num * p1;
+            int s0 = int(floor(e0)), s1 = int(floor(e1));
+            if (s0 + s1 < it.num) {
+                double prob = e0 - s0;
+                if (sample < prob) { s0++; sample /= prob; }
+                else { s1++; sample = (sample - prob) / (1 - prob); }
+            }
+            if (s0 > 0 && sp + nleaf < kHSamples) push(c0, s0, it.pmf * p0);
+            if (s1 > 0 && sp + nleaf < kHSamples) push(c1, s1, it.pmf * p1);
+        }
+    }
+    int selected = -1;
+    double edge_w = 0, wsum = 0;
+    for (int j = 0; j < nleaf; ++j) {
+        const HLeaf it = leaves[(size_t)j * stride];
+        const int leaf_edge = ~it.ref;
+        double w = it.num * leaf_importance_h(sc, es, leaf_edge, c) / it.pmf;
+        if (w > 0) {
+            double prev = wsum;
+            wsum += w;
+            double nw = w / wsum;
+            if (resample <= nw || prev == 0) {
+                selected = leaf_edge;
+                edge_w = w * it.pmf;
+                resample /= nw;
+            } else {
+                resample = (resample - nw) / (1 - nw);
+            }
+        }
+    }
+    if (edge_w <= 0 || wsum <= 0) return -1;
+    double pmf_h = edge_w * kHSamples / wsum;
+    weight = 1 / pmf_h;
+    return selected;
+}
+
 // Tail of the NEE-mode pick: pmf of the selected edge, Jacobian of the NEE-ray / billboard intersection, point on the edge.
 RDR_FN int finish_edge_nee(const SceneD &sc, const EdgeSceneD &es, const Ray &nee, bool nee_valid, const Surf &nee_pt, int nee_shape,
                            int selected, double edge_w, double wsum, double &weight, V3 &edge_pt, V3 &mwt) {
@@ -653,10 +744,40 @@ struct SecEdgePickH {
         picks[idx] = SecPick{eid, ew, v3(0), v3(0)};
     }
 };
+struct SecEdgePickH2 {        // the hierarchical pick with deferred leaf evaluation (pick_edge_hierarchical_deferred)
+    SecEdgeArgs a; const int *slots; SecPick *picks; HLeaf *leaves, *spill; int n;      // leaves: kHSamples x n, spill: (kHSamples - kHStackLds) x n
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void operator()(int i) const {
+        int idx = slots[i];
+        SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
+        double ew = 0;
+        int eid = pick_edge_hierarchical_deferred(a.sc, a.es, s.lc, s.edge_sel, s.resample_sel, ew, leaves + i, spill + i, (size_t)n);
+        picks[idx] = SecPick{eid, ew, v3(0), v3(0)};
+    }
+};
 // The NEE-mode pick as a resumable walk for exec::launch_persistent: same tests in the same order as
 // the reference's sample_edge_l (src/edge.cpp:1239-1364), one popped reference per step.
+#ifdef RDR_HOSTSIM
+// debugging harness only: how much work the gather does per slot (printed at exit when RDR_GATHER_STATS is set)
+struct GatherStats {
+    long slots = 0, nodes = 0, edges = 0, cands = 0, overflow = 0, hist[12] = {0};
+    ~GatherStats() {
+        if (!getenv("RDR_GATHER_STATS") || slots == 0) return;
+        fprintf(stderr, "[gather] slots %ld nodes/slot %.1f edge tests/slot %.2f positive leaves/slot %.4f overflow %ld  hist:", slots,
+                (double)nodes / slots, (double)edges / slots, (double)cands / slots, overflow);
+        for (int i = 0; i < 12; ++i) fprintf(stderr, " %ld", hist[i]);
+        fprintf(stderr, "\n");
+    }
+};
+inline void gather_stats_add(long nodes, long edges, int ncand) {
+    static GatherStats st;
+    st.slots++; st.nodes += nodes; st.edges += edges; st.cands += ncand; st.overflow += ncand > kGatherCands; st.hist[ncand < 11 ? ncand : 11]++;
+}
+#endif
+constexpr int kPickOverflow = -2;     // SecPick::eid of a slot the gather hands to the reference-order walk
 template <int NS> struct SecEdgePickNWalk {
     SecEdgeArgs a; const int *slots; SecPick *picks;
+    int only_overflow;          // 1: walk only the slots SecEdgeGatherN marked kPickOverflow, leave the others alone
     struct State {
         int idx, sp, selected;
         double edge_w, wsum, resample;
@@ -669,6 +790,7 @@ template <int NS> struct SecEdgePickNWalk {
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
     RDR_DEV_FN bool begin(int i, State &st) const {
         st.idx = slots[i];
+        if (only_overflow && picks[st.idx].eid != kPickOverflow) { st.idx = -1; st.sp = 0; st.selected = -1; return false; }
         SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[st.idx], st.idx);
         st.sp = 0; st.selected = -1; st.edge_w = 0; st.wsum = 0; st.resample = s.resample_sel;
         st.c = s.lc; st.nee = s.nee; st.nee_valid = s.nee_valid;
@@ -711,6 +833,7 @@ template <int NS> struct SecEdgePickNWalk {
     // is rebuilt from the slot rather than carried through the walk
     RDR_DEV_FN void finish(State &st) const {
         const SceneD &sc = a.sc; const EdgeSceneD &es = a.es;
+        if (st.idx < 0) return;
         SecPick out{-1, 0.0, v3(0), v3(0)};
         if (st.selected != -1) {
             SecPre s = sec_prepare(sc, es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[st.idx], st.idx);
@@ -720,6 +843,113 @@ template <int NS> struct SecEdgePickNWalk {
             out = SecPick{eid, ew, sample_p, mwt};
         }
         picks[st.idx] = out;
+    }
+};
+
+// The NEE-mode pick without the reference's traversal order.
+//
+// sample_edge_l (src/edge.cpp:1239-1364) walks both edge hierarchies depth-first, descends into a child when (i) its Hough
+// x-interval may hold a silhouette seen from the shading point and from the light point and (ii) the NEE segment passes its
+// spatial box grown by the billboard half-width, evaluates leaf_importance_l at every leaf it reaches and keeps one leaf by
+// reservoir sampling.  All three node tests are monotone in box inclusion, also in floating point (a bigger interval /
+// box passes whenever a smaller one does: every operation in them is monotone and rounds monotonically), and an inner
+// node's bounds are the unions of its children's.  So a leaf is reached exactly when its OWN bounds pass the tests -- the
+// hierarchy only prunes -- and the outcome is determined by the set of leaves with positive importance and by the order in
+// which the walk meets them, which is a fixed order of the leaves (EdgeSceneD::leaf_rank).
+// This stage therefore finds those leaves with any traversal it likes -- here a SAH hierarchy over the billboard boxes
+// (EdgeSceneD::gather; the reference's trees are built for importance sampling, a segment query visits 100 ... 600+ of their
+// nodes per slot with a long tail, profiles/r1_notes.md) -- applies the reference's own tests to each candidate edge, and
+// replays the reservoir over the positive leaves in rank order: identical arithmetic on identical operands, identical picks.
+// Slots with more than kGatherCands positive leaves are marked kPickOverflow and walked by SecEdgePickNWalk.
+template <int NS, class IDX> struct SecEdgeGatherN {
+    SecEdgeArgs a; const int *slots; SecPick *picks; GatherCand *cands;     // cands: kGatherCands per list position i
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void operator()(int i) const {
+        const SceneD &sc = a.sc; const EdgeSceneD &es = a.es;
+        const int idx = slots[i];
+        LtcCtx lc; Ray nee; bool nee_valid; double resample; SilQuery q_pos, q_nee;
+        {
+            SecPre s = sec_prepare(sc, es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
+            lc = s.lc; nee = s.nee; nee_valid = s.nee_valid; resample = s.resample_sel;
+            q_pos = sil_query(es, s.lc.pos); q_nee = sil_query(es, s.nee_pt.position);
+        }
+        const V3 inv_dir = V3{1 / nee.dir.x, 1 / nee.dir.y, 1 / nee.dir.z};
+        GatherCand *mine = cands + (size_t)kGatherCands * i;
+        int ncand = 0;
+        RDR_STACK_DECL(IDX, stk, NS);
+        int sp = 0;
+        const rt::BvhD &g = es.gather;
+        if (g.num_nodes > 0) {
+            const rt::Node &root = g.nodes[0];
+            if (ray_box_expand(v3_of(root.lo), v3_of(root.hi), nee, inv_dir, 0.0)) { RDR_STACK_AT(stk, sp) = (IDX)0; sp++; }
+        }
+#ifdef RDR_HOSTSIM
+        long h_nodes = 0, h_edges = 0, h_imp = 0;
+#endif
+        while (sp > 0) {
+            --sp;
+            const rt::Node &n = g.nodes[(int)RDR_STACK_AT(stk, sp)];
+#ifdef RDR_HOSTSIM
+            h_nodes++;
+#endif
+            if (n.b > 0) {
+                for (int k = 0; k < n.b; ++k) {
+                    const int eid = g.ids[2 * (n.a + k) + 1];
+#ifdef RDR_HOSTSIM
+                    h_edges++;
+#endif
+                    // the edge's own leaf, tested like the reference tests it from its parent
+                    const double dx_lo = es.leaf_dx[2 * (size_t)eid], dx_hi = es.leaf_dx[2 * (size_t)eid + 1];
+                    if (!sphere_box_x(q_pos, dx_lo, dx_hi)) continue;
+                    if (nee_valid && !sphere_box_x(q_nee, dx_lo, dx_hi)) continue;
+                    const EdgeGeom &eg = es.geom[eid];
+                    const V3 p0 = v3_of(eg.v0), p1 = v3_of(eg.v1);
+                    const V3 blo = V3{dmin(p0.x, p1.x), dmin(p0.y, p1.y), dmin(p0.z, p1.z)}, bhi = V3{dmax(p0.x, p1.x), dmax(p0.y, p1.y), dmax(p0.z, p1.z)};
+                    if (!ray_box_expand(blo, bhi, nee, inv_dir, es.edge_bounds_expand)) continue;
+                    const double w = leaf_importance_l(sc, es, eid, lc, nee, nee_valid);
+                    if (w > 0) {
+                        if (ncand < kGatherCands) mine[ncand] = GatherCand{es.leaf_rank[eid], eid, w};
+                        ncand++;
+                    }
+                }
+            } else {
+                const rt::Node &l = g.nodes[n.a], &r = g.nodes[n.a + 1];
+                const bool hl = ray_box_expand(v3_of(l.lo), v3_of(l.hi), nee, inv_dir, 0.0);
+                const bool hr = ray_box_expand(v3_of(r.lo), v3_of(r.hi), nee, inv_dir, 0.0);
+                if (hl && sp < NS) { RDR_STACK_AT(stk, sp) = (IDX)n.a; sp++; }
+                if (hr && sp < NS) { RDR_STACK_AT(stk, sp) = (IDX)(n.a + 1); sp++; }
+            }
+        }
+#ifdef RDR_HOSTSIM
+        gather_stats_add(h_nodes, h_edges, ncand);
+#endif
+        if (ncand > kGatherCands) { picks[idx] = SecPick{kPickOverflow, 0.0, v3(0), v3(0)}; return; }
+        // reservoir replay in the reference's leaf order (src/edge.cpp:1300-1316)
+        int selected = -1, last_rank = -1;
+        double edge_w = 0, wsum = 0;
+        for (int t = 0; t < ncand; ++t) {
+            int best = -1, best_rank = 0x7fffffff;
+            for (int j = 0; j < ncand; ++j) {
+                const int r = mine[j].rank;
+                if (r > last_rank && r < best_rank) { best_rank = r; best = j; }
+            }
+            const GatherCand cd = mine[best];
+            last_rank = best_rank;
+            const double prev = wsum;
+            wsum += cd.w;
+            const double nw = cd.w / wsum;
+            if (resample <= nw || prev == 0) { selected = cd.eid; edge_w = cd.w; resample /= nw; }
+            else resample = (resample - nw) / (1 - nw);
+        }
+        SecPick out{-1, 0.0, v3(0), v3(0)};
+        if (selected != -1) {
+            SecPre s = sec_prepare(sc, es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
+            double ew = 0;
+            V3 sample_p = v3(0), mwt = v3(0);
+            int eid = finish_edge_nee(sc, es, s.nee, s.nee_valid, s.nee_pt, s.nee_shape, selected, edge_w, wsum, ew, sample_p, mwt);
+            out = SecPick{eid, ew, sample_p, mwt};
+        }
+        picks[idx] = out;
     }
 };
 

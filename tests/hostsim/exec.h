@@ -29,6 +29,10 @@ inline void accum(double *p, double v) { *p += v; }
 namespace exec {
 inline void *dmalloc(size_t bytes) { void *p = malloc(bytes ? bytes : 16); if (!p) throw std::bad_alloc(); return p; }
 inline void dfree(void *p) { free(p); }
+inline void *pool_alloc(size_t bytes) { return dmalloc(bytes); }
+inline void pool_free(void *p) { free(p); }
+inline void pool_trim() {}
+inline size_t pool_device_mallocs() { return 0; }
 inline void zero(void *p, size_t bytes) { memset(p, 0, bytes); }
 inline void upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void download(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
