@@ -610,6 +610,22 @@ EdgeData *build_edge_data(Scene &scene) {
         ed->edge_bounds_expand = 0.01f * len(mad);
 
         timer.lap("pmf, bounds, split");
+        // The billboard hierarchy of the NEE-mode gather (stages_edge.h: SecEdgeGatherN) needs only the edge bounds and
+        // the billboard half-width: it is built on another thread while this one builds the two reference hierarchies.
+        // Boxes: each edge's own spatial bounds grown by the half-width (rounded outwards; the builder pads on top).
+        std::future<rt::BvhHost> gather_job = std::async(std::launch::async, [&bounds, ne, e = ed->edge_bounds_expand] {
+            std::vector<float> boxes((size_t)6 * ne);
+            for (int i = 0; i < ne; ++i) {
+                const double lo[3] = {bounds[i].p_min.x - e, bounds[i].p_min.y - e, bounds[i].p_min.z - e};
+                const double hi[3] = {bounds[i].p_max.x + e, bounds[i].p_max.y + e, bounds[i].p_max.z + e};
+                for (int k = 0; k < 3; ++k) {
+                    boxes[6 * (size_t)i + k] = std::nextafterf((float)lo[k], -std::numeric_limits<float>::infinity());
+                    boxes[6 * (size_t)i + 3 + k] = std::nextafterf((float)hi[k], std::numeric_limits<float>::infinity());
+                }
+            }
+            return rt::build_box_bvh(boxes.data(), ne);
+        });
+        struct JoinGather { std::future<rt::BvhHost> &f; ~JoinGather() { if (f.valid()) f.wait(); } } join_gather{gather_job};
         TreeBuilder cs(true, shapes, edges, bounds), ncs(false, shapes, edges, bounds);
         {   // the two hierarchies are independent
             auto cs_job = std::async(std::launch::async, [&] { cs.build(cs_ids); });
@@ -619,10 +635,16 @@ EdgeData *build_edge_data(Scene &scene) {
         timer.lap("3-D and 6-D trees");
         ed->cs_nodes.swap(cs.nodes); ed->cs_leaves = cs.n;
         ed->ncs_nodes.swap(ncs.nodes); ed->ncs_leaves = ncs.n;
-        // the NEE-mode traversal keeps one pending sibling per level in a fixed 64-entry stack
-        auto depth_of = [](const std::vector<EdgeNode> &tree) {
-            int max_depth = 0;
+        // One depth-first pass per tree gives (a) its depth -- the NEE-mode walk keeps one pending sibling per level in a
+        // fixed stack -- and (b) the order in which the reference's walk reaches the leaves: roots pushed 3-D tree first,
+        // 6-D tree second, children pushed 0 then 1, last pushed popped first (src/edge.cpp:1239-1318); a leaf's rank is
+        // its position in that order, which is all the order-free gather needs to replay the reservoir.
+        std::vector<int> leaf_rank(ne, 0);
+        std::vector<double> leaf_dx((size_t)2 * ne, 0.0);
+        auto walk_tree = [&](const std::vector<EdgeNode> &tree, bool hough, int first_rank) {
+            int max_depth = 0, rank = first_rank;
             if (tree.empty()) return max_depth;
+            const double inf = std::numeric_limits<double>::infinity();
             std::vector<std::pair<int, int>> todo;
             todo.reserve(256);
             todo.push_back({0, 1});
@@ -631,57 +653,41 @@ EdgeData *build_edge_data(Scene &scene) {
                 todo.pop_back();
                 max_depth = std::max(max_depth, depth);
                 const EdgeNode &nd = tree[node];
-                if (nd.edge_id == -1 && nd.child0 >= 0) { todo.push_back({nd.child0, depth + 1}); todo.push_back({nd.child1, depth + 1}); }
+                if (nd.edge_id != -1) {
+                    leaf_rank[nd.edge_id] = rank++;
+                    leaf_dx[2 * (size_t)nd.edge_id] = hough ? nd.d_min.x : -inf;
+                    leaf_dx[2 * (size_t)nd.edge_id + 1] = hough ? nd.d_max.x : inf;
+                } else if (nd.child0 >= 0) { todo.push_back({nd.child0, depth + 1}); todo.push_back({nd.child1, depth + 1}); }
             }
             return max_depth;
         };
-        auto cs_depth = std::async(std::launch::async, [&] { return depth_of(ed->cs_nodes); });
-        const int depths[2] = {depth_of(ed->ncs_nodes), cs_depth.get()};
+        // the 6-D tree is walked first, so the 3-D tree's ranks start after its leaves
+        auto cs_depth = std::async(std::launch::async, [&] { return walk_tree(ed->cs_nodes, false, ed->ncs_leaves); });
+        const int depths[2] = {walk_tree(ed->ncs_nodes, true, 0), cs_depth.get()};
         for (int max_depth : depths) {
             if (max_depth == 0) continue;
             if (max_depth + 2 > 64) throw std::runtime_error("edge hierarchy deeper than the traversal stack (64)");
             ed->max_stack = std::max(ed->max_stack, max_depth + 2);
         }
-        timer.lap("depth check");
-        // ---- the order-free form of the NEE-mode pick (stages_edge.h: SecEdgeGatherN) ----
-        // (a) the order in which the reference's walk reaches the leaves: roots pushed 3-D tree first, 6-D tree second,
-        //     children pushed 0 then 1, last pushed popped first (src/edge.cpp:1239-1318)
-        ed->leaf_rank.assign(ne, 0);
-        ed->leaf_dx.assign((size_t)2 * ne, 0.0);
+        timer.lap("depth, leaf order");
         {
-            int rank = 0;
-            const double inf = std::numeric_limits<double>::infinity();
-            std::vector<int> todo;
-            for (int t = 1; t >= 0; --t) {            // 6-D tree first
-                const std::vector<EdgeNode> &tree = t == 1 ? ed->ncs_nodes : ed->cs_nodes;
-                if (tree.empty()) continue;
-                todo.assign(1, 0);
-                while (!todo.empty()) {
-                    const EdgeNode &nd = tree[todo.back()];
-                    todo.pop_back();
-                    if (nd.edge_id != -1) {
-                        ed->leaf_rank[nd.edge_id] = rank++;
-                        ed->leaf_dx[2 * (size_t)nd.edge_id] = t == 1 ? nd.d_min.x : -inf;
-                        ed->leaf_dx[2 * (size_t)nd.edge_id + 1] = t == 1 ? nd.d_max.x : inf;
-                    } else { todo.push_back(nd.child0); todo.push_back(nd.child1); }
-                }
-            }
-        }
-        // (b) spatial hierarchy over the billboard boxes: each edge's own spatial bounds grown by the billboard half-width
-        //     (rounded outwards; the builder pads every node box on top of that)
-        {
-            std::vector<float> boxes((size_t)6 * ne);
-            const double e = ed->edge_bounds_expand;
-            for (int i = 0; i < ne; ++i) {
-                const double lo[3] = {bounds[i].p_min.x - e, bounds[i].p_min.y - e, bounds[i].p_min.z - e};
-                const double hi[3] = {bounds[i].p_max.x + e, bounds[i].p_max.y + e, bounds[i].p_max.z + e};
-                for (int k = 0; k < 3; ++k) {
-                    boxes[6 * (size_t)i + k] = std::nextafterf((float)lo[k], -std::numeric_limits<float>::infinity());
-                    boxes[6 * (size_t)i + 3 + k] = std::nextafterf((float)hi[k], std::numeric_limits<float>::infinity());
-                }
-            }
-            ed->gather = rt::build_box_bvh(boxes.data(), ne);
+            ed->gather = gather_job.get();
             if (ed->gather.depth + 2 > 64) throw std::runtime_error("edge gather hierarchy deeper than the traversal stack (64)");
+            const size_t slots = ed->gather.ids.size() / 2;
+            ed->gleaf.resize(slots);
+            for (size_t sl = 0; sl < slots; ++sl) {
+                const int eid = ed->gather.ids[2 * sl + 1];
+                GatherLeaf &gl = ed->gleaf[sl];
+                gl.dx_lo = leaf_dx[2 * (size_t)eid]; gl.dx_hi = leaf_dx[2 * (size_t)eid + 1];
+                F3 a = edge_v0f(shapes, edges[eid]), b = edge_v1f(shapes, edges[eid]);
+                const EdgeD &e = edges[eid];
+                F3 o0 = e.f0 != -1 ? edge_opp0f(shapes, e) : a, o1 = e.f1 != -1 ? edge_opp1f(shapes, e) : b;      // as in EdgeGeom
+                gl.v0[0] = a.x; gl.v0[1] = a.y; gl.v0[2] = a.z; gl.v1[0] = b.x; gl.v1[1] = b.y; gl.v1[2] = b.z;
+                gl.o0[0] = o0.x; gl.o0[1] = o0.y; gl.o0[2] = o0.z; gl.o1[0] = o1.x; gl.o1[1] = o1.y; gl.o1[2] = o1.z;
+                gl.eid = eid; gl.rank = leaf_rank[eid];
+                gl.f0 = e.f0 == -1 ? -1 : 0; gl.f1 = e.f1 == -1 ? -1 : 0;
+                gl.has_normals = scene.shapes[e.shape_id].normals != nullptr;
+            }
         }
         timer.lap("gather hierarchy");
     }
@@ -690,7 +696,7 @@ EdgeData *build_edge_data(Scene &scene) {
     auto up = [&](const void *src, size_t bytes) -> void * {
         void *p = exec::pool_alloc(bytes);
         scene.owned.push_back(p);
-        if (bytes) exec::upload(p, src, bytes);
+        if (bytes) exec::upload_async(p, src, bytes);          // create_scene() flushes the batch
         return p;
     };
     EdgeSceneD &d = ed->d;
@@ -756,15 +762,13 @@ EdgeData *build_edge_data(Scene &scene) {
     d.ncs_nodes = fatten(ed->ncs_nodes, ed->ncs_leaves, kEdgeTreeBit, d.ncs_root);
     timer.lap("device copies");
     d.gather = rt::BvhD{nullptr, nullptr, nullptr, 0, 0, 2};
-    d.leaf_dx = nullptr; d.leaf_rank = nullptr;
+    d.gleaf = nullptr;
     if (!ed->gather.nodes.empty()) {
         d.gather.nodes = (const rt::Node *)up(ed->gather.nodes.data(), sizeof(rt::Node) * ed->gather.nodes.size());
-        d.gather.ids = (const int *)up(ed->gather.ids.data(), sizeof(int) * ed->gather.ids.size());
         d.gather.num_nodes = (int)ed->gather.nodes.size();
-        d.gather.num_tris = (int)ed->gather.ids.size() / 2;
+        d.gather.num_tris = (int)ed->gleaf.size();
         d.gather.stack_need = ed->gather.depth + 2;
-        d.leaf_dx = (const double *)up(ed->leaf_dx.data(), sizeof(double) * ed->leaf_dx.size());
-        d.leaf_rank = (const int *)up(ed->leaf_rank.data(), sizeof(int) * ed->leaf_rank.size());
+        d.gleaf = (const GatherLeaf *)up(ed->gleaf.data(), sizeof(GatherLeaf) * ed->gleaf.size());
     }
     timer.lap("copy: gather");
     d.edge_bounds_expand = ed->edge_bounds_expand;

@@ -50,6 +50,20 @@ RDR_FN V3 v3_of(const float *p) { return V3{(double)p[0], (double)p[1], (double)
 
 constexpr int kEdgeTreeBit = 1 << 30;
 
+// Everything the NEE-mode gather needs about one edge (80 B, stored in the leaf-slot order of the billboard hierarchy so
+// that a leaf's 1..4 candidates arrive with one contiguous fetch and nothing else has to be chased): the Hough x-interval
+// of the edge's leaf in the reference's 6-D tree ((-inf, +inf) for edges of the 3-D tree, which is never Hough-tested),
+// the edge's geometry record (end points -- its spatial bounds are their component-wise min / max -- and the third corner
+// of each adjacent face, as in EdgeGeom), its id and its position in the reference's leaf order.
+struct GatherLeaf {
+    double dx_lo, dx_hi;
+    float v0[3], v1[3], o0[3], o1[3];
+    int eid, rank;
+    short f0, f1;            // -1: no such face, else 0 (only the sign is used)
+    int has_normals;
+};
+static_assert(sizeof(GatherLeaf) == 80, "GatherLeaf must stay 80 bytes");
+
 // One positive-weight leaf found by the NEE-mode gather (stages_edge.h: SecEdgeGatherN), replayed in `rank` order.
 struct GatherCand { int rank, eid; double w; };
 constexpr int kGatherCands = 8;          // per slot; a slot that finds more falls back to the reference-order walk
@@ -71,8 +85,7 @@ struct EdgeSceneD {
     // leaf in the reference's 6-D tree ((-inf, +inf) for edges of the 3-D tree, which is never Hough-tested), and each
     // edge's position in the order the reference's traversal reaches the leaves (for the reservoir replay).
     rt::BvhD gather;
-    const double *leaf_dx;                    // 2 per edge
-    const int *leaf_rank;                     // 1 per edge
+    const GatherLeaf *gleaf;                  // one per leaf slot of `gather`, in slot order
 };
 
 constexpr int kNoEdgeTree = 0x7fffffff;
@@ -205,8 +218,7 @@ struct EdgeData {
     int max_stack = 2;             // see EdgeSceneD::max_stack
     double edge_bounds_expand = 0;
     rt::BvhHost gather;            // see EdgeSceneD::gather
-    std::vector<double> leaf_dx;
-    std::vector<int> leaf_rank;
+    std::vector<GatherLeaf> gleaf;
     EdgeSceneD d;            // device view
 };
 EdgeData *build_edge_data(Scene &scene);

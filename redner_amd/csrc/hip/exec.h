@@ -90,6 +90,8 @@ __device__ inline void accum(double *p, double v) {
     if (mine) unsafeAtomicAdd(p, v);
 }
 __host__ inline void accum(double *p, double v) { *p += v; }   // host instantiation is never executed
+__device__ inline int atomic_fetch_add(int *p, int v) { return atomicAdd(p, v); }
+__host__ inline int atomic_fetch_add(int *p, int v) { int o = *p; *p += v; return o; }
 }
 
 namespace exec {
@@ -126,6 +128,15 @@ inline void download(void *dst, const void *src, size_t bytes) {
     check(hipStreamSynchronize(ctx().stream), "download sync");
 }
 inline void sync() { check(hipStreamSynchronize(ctx().stream), "sync"); }
+// Batched transfers for the Scene build (trace.hip): every array goes through one pinned staging buffer, the copies are
+// queued on the stream and ONE synchronisation ends the batch -- a pageable hipMemcpy + sync per array cost 30-200 us each,
+// ~50 of them per Scene.
+void upload_async(void *dst, const void *src, size_t bytes);      // src may be reused as soon as this returns
+void upload_flush();                                              // all queued uploads have landed
+struct DownloadItem { void *dst; const void *src; size_t bytes; };
+void download_batch(const DownloadItem *items, int n);            // device -> host, one synchronisation
+// Constant tables shared by every Scene on a device (Sobol' direction numbers, LTC matrices): uploaded once per device.
+const void *device_constant(const void *host, size_t bytes);
 inline int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 
 // Side streams for stages that do not depend on each other (the edge-pick walks and the bounce adjoint of one path

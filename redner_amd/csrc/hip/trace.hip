@@ -8,6 +8,7 @@
 // rejected are in DESIGN.md section "Traversal kernel" and profiles/r1_notes.md.
 #include "exec.h"
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <unordered_map>
 #include <vector>
@@ -88,6 +89,69 @@ void pool_trim() {
 }
 
 size_t pool_device_mallocs() { Pool &pl = pool(); std::lock_guard<std::mutex> lk(pl.lock); return pl.device_mallocs; }
+
+namespace {
+struct Staging { char *base = nullptr; size_t cap = 0, used = 0; };
+Staging &staging() { static thread_local Staging s; return s; }
+char *staging_reserve(size_t bytes) {          // 256-byte aligned slice of the pinned buffer; grows when idle
+    Staging &st = staging();
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (st.used + need > st.cap) {
+        sync();                                 // nothing in flight may still read the old buffer
+        st.used = 0;
+        if (need > st.cap) {
+            if (st.base) (void)hipHostFree(st.base);
+            st.cap = std::max<size_t>(need * 2, (size_t)32 << 20);
+            check(hipHostMalloc((void **)&st.base, st.cap, hipHostMallocDefault), "hipHostMalloc (staging)");
+        }
+    }
+    char *p = st.base + st.used;
+    st.used += need;
+    return p;
+}
+}
+
+void upload_async(void *dst, const void *src, size_t bytes) {
+    if (!bytes) return;
+    char *stage = staging_reserve(bytes);
+    std::memcpy(stage, src, bytes);
+    check(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, ctx().stream), "upload_async");
+}
+void upload_flush() { sync(); staging().used = 0; }
+
+void download_batch(const DownloadItem *items, int n) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (items[i].bytes + 255) & ~(size_t)255;
+    if (!total) return;
+    upload_flush();                              // the staging buffer is shared with queued uploads
+    char *stage = staging_reserve(total);
+    size_t at = 0;
+    for (int i = 0; i < n; ++i) {
+        if (items[i].bytes) check(hipMemcpyAsync(stage + at, items[i].src, items[i].bytes, hipMemcpyDeviceToHost, ctx().stream), "download_batch");
+        at += (items[i].bytes + 255) & ~(size_t)255;
+    }
+    sync();
+    at = 0;
+    for (int i = 0; i < n; ++i) {
+        if (items[i].bytes) std::memcpy(items[i].dst, stage + at, items[i].bytes);
+        at += (items[i].bytes + 255) & ~(size_t)255;
+    }
+    staging().used = 0;
+}
+
+const void *device_constant(const void *host, size_t bytes) {
+    static std::mutex lock;
+    static std::map<std::pair<const void *, int>, void *> table;      // (host table, device) -> device copy, kept for the process
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(lock);
+    void *&p = table[{host, dev}];
+    if (!p) {
+        p = dmalloc(bytes);
+        check(hipMemcpy(p, host, bytes, hipMemcpyHostToDevice), "device_constant");
+    }
+    return p;
+}
 
 CompactScratch &compact_scratch(int nblocks) {
     static thread_local CompactScratch per_device[16];

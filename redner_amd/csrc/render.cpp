@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <memory>
 #include <stdexcept>
+#include <type_traits>
 #include <vector>
 
 namespace rdr {
@@ -313,6 +314,10 @@ struct Backward {
             for (int k = 0; k < 3; ++k) elist[k] = arena.get<int>(L);
             nee_slots = arena.get<int>(P);
             gather_cands = arena.get<GatherCand>((size_t)kGatherCands * P);
+            gshared.book = arena.get<GatherBook>(1);
+            gshared.heavy_slot = arena.get<int>(kGatherHeavyCap);
+            gshared.work = arena.get<GatherWork>(kGatherWorkCap);
+            gshared.cands_big = arena.get<GatherCand>((size_t)kGatherCandsBig * kGatherHeavyCap);
             h_leaves = arena.get<HLeaf>((size_t)kHSamples * P);
             h_spill = arena.get<HLeaf>((size_t)(kHSamples - kHStackLds) * P);
             edge_contrib = arena.get<double>(L);
@@ -336,6 +341,7 @@ struct Backward {
     VSlice ea, eb;                 // ping-pong vertex slices of the edge sub-paths (2P lanes each)
     int *elist[3] = {nullptr, nullptr, nullptr};
     HLeaf *h_leaves = nullptr, *h_spill = nullptr;   // hierarchical pick: recorded leaves / spilled stack entries per list position
+    GatherShared gshared{nullptr, nullptr, nullptr, nullptr};     // heavy slots of the gather: big candidate lists, subtree work items
     GatherCand *gather_cands = nullptr;        // positive leaves found by the NEE-mode gather, kGatherCands per list position
     int *nee_slots = nullptr;                  // slots of the NEE-mode edge pick (its walk runs beside the hierarchical pick)
     exec::Fence depth_begin, adjoint_done, setup_done, walk_done;
@@ -360,15 +366,18 @@ struct Backward {
         static const bool walk_all = std::getenv("RDR_PICKN_WALK") != nullptr;
         const bool gather = !walk_all && sa.es.gather.num_nodes > 0;
         if (gather) {
-            auto run = [&](auto stage) {
-                if (LEAN) exec::launch(nN, LeanStage<decltype(stage)>{stage}); else exec::launch(nN, stage);
-            };
             const int gneed = sa.es.gather.stack_need;
-            const bool narrow = sa.es.gather.num_nodes < 65536;
-            if (gneed <= 32 && narrow) run(SecEdgeGatherN<32, unsigned short>{sa, nee_slots, sec_picks, gather_cands});
-            else if (gneed <= 32) run(SecEdgeGatherN<32, int>{sa, nee_slots, sec_picks, gather_cands});
-            else if (narrow) run(SecEdgeGatherN<64, unsigned short>{sa, nee_slots, sec_picks, gather_cands});
-            else run(SecEdgeGatherN<64, int>{sa, nee_slots, sec_picks, gather_cands});
+            exec::zero(gshared.book, sizeof(GatherBook));
+            auto passes = [&](auto tag) {
+                constexpr int NS = decltype(tag)::value;
+                static const int budget = [] { const char *e = std::getenv("RDR_GATHER_BUDGET"); return e ? std::max(1, std::atoi(e)) : kGatherBudget; }();
+                launch_v(LEAN, nN, SecEdgeGatherN<NS>{sa, nee_slots, sec_picks, gather_cands, gshared, budget});
+                launch_v(LEAN, kGatherWorkCap, SecEdgeGatherSub<NS>{sa, nee_slots, gshared});
+                launch_v(LEAN, kGatherHeavyCap, SecEdgeGatherReplay{sa, nee_slots, sec_picks, gshared});
+            };
+            if (gneed <= 24) passes(std::integral_constant<int, 24>{});
+            else if (gneed <= 40) passes(std::integral_constant<int, 40>{});
+            else passes(std::integral_constant<int, 64>{});
         }
         const int only_overflow = gather ? 1 : 0;
         auto go = [&](auto walk) {
@@ -440,6 +449,7 @@ struct Backward {
                 launch_v(lean, nA, SecEdgeSetup{sa, sec_mode, sec_recs, sec_picks, ea, edge_tmin});
                 int nH = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 1});
                 int nN = exec::compact((const int *)nullptr, nA, nee_slots, KeepMode{sec_mode, 2});
+                nN += exec::compact((const int *)nullptr, nA, nee_slots + nN, KeepMode{sec_mode, 3});     // dense-shape slots after the others
                 const int need = es.max_stack;
                 {   // NEE-mode pick: persistent waves (walk lengths: median 20, p95 640 steps)
                     if (side) setup_done.after(main_stream);
@@ -451,7 +461,11 @@ struct Backward {
                 }
                 static const bool pickh_fused = std::getenv("RDR_PICKH_FUSED") != nullptr;     // A/B: the one-loop form
                 if (pickh_fused) launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
-                else launch_v(lean, nH, SecEdgePickH2{sa, elist[0], sec_picks, h_leaves, h_spill, nH});
+                else {
+                    static const bool lazy = std::getenv("RDR_PICKH_LAZY") != nullptr;     // A/B: per-field node loads
+                    if (lazy) launch_v(lean, nH, SecEdgePickH2<false>{sa, elist[0], sec_picks, h_leaves, h_spill, nH});
+                    else launch_v(lean, nH, SecEdgePickH2<true>{sa, elist[0], sec_picks, h_leaves, h_spill, nH});
+                }
                 if (side) walk_done.gate(main_stream);
                 if (nH == 0 && nN == 0) {
                     // no slot samples an edge here (typically: every path already passed a diffuse vertex,

@@ -22,7 +22,7 @@ template <class T>
 T *to_device(Scene &s, const T *src, size_t count) {
     T *p = (T *)exec::pool_alloc(sizeof(T) * (count ? count : 1));
     s.owned.push_back(p);
-    if (count) exec::upload(p, src, sizeof(T) * count);
+    if (count) exec::upload_async(p, src, sizeof(T) * count);      // create_scene() ends the batch with upload_flush()
     return p;
 }
 
@@ -129,12 +129,26 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         o.num_vertices = in.num_vertices; o.num_uv_vertices = in.num_uv_vertices;
         o.num_normal_vertices = in.num_normal_vertices; o.num_triangles = in.num_triangles;
         o.material_id = in.material_id; o.light_id = in.light_id;
-        s.h_vertices[i] = from_device(in.vertices, (size_t)3 * in.num_vertices);
-        s.h_indices[i] = from_device(in.indices, (size_t)3 * in.num_triangles);
-        if (in.normals) s.h_normals[i] = from_device(in.normals, (size_t)3 * (in.num_normal_vertices > 0 ? in.num_normal_vertices : in.num_vertices));
-        if (in.uvs) s.h_uvs[i] = from_device(in.uvs, (size_t)2 * (in.num_uv_vertices > 0 ? in.num_uv_vertices : in.num_vertices));
-        if (in.uv_indices) s.h_uv_indices[i] = from_device(in.uv_indices, (size_t)3 * in.num_triangles);
-        if (in.normal_indices) s.h_normal_indices[i] = from_device(in.normal_indices, (size_t)3 * in.num_triangles);
+    }
+    {   // host mirrors of every mesh array: one batch, one synchronisation
+        std::vector<exec::DownloadItem> items;
+        auto want = [&](auto &vec, const auto *src, size_t count) {
+            vec.resize(count);
+            if (src && count) items.push_back(exec::DownloadItem{vec.data(), src, sizeof(vec[0]) * count});
+        };
+        for (int i = 0; i < num_shapes; ++i) {
+            const rdr_shape_desc &in = shapes[i];
+            want(s.h_vertices[i], in.vertices, (size_t)3 * in.num_vertices);
+            want(s.h_indices[i], in.indices, (size_t)3 * in.num_triangles);
+            if (in.normals) want(s.h_normals[i], in.normals, (size_t)3 * (in.num_normal_vertices > 0 ? in.num_normal_vertices : in.num_vertices));
+            if (in.uvs) want(s.h_uvs[i], in.uvs, (size_t)2 * (in.num_uv_vertices > 0 ? in.num_uv_vertices : in.num_vertices));
+            if (in.uv_indices) want(s.h_uv_indices[i], in.uv_indices, (size_t)3 * in.num_triangles);
+            if (in.normal_indices) want(s.h_normal_indices[i], in.normal_indices, (size_t)3 * in.num_triangles);
+        }
+        exec::download_batch(items.data(), (int)items.size());
+    }
+    for (int i = 0; i < num_shapes; ++i) {
+        const rdr_shape_desc &in = shapes[i];
         for (int k = 0; k < 3 * in.num_triangles; ++k)
             if (s.h_indices[i][k] < 0 || s.h_indices[i][k] >= in.num_vertices)
                 throw std::runtime_error("Scene: triangle index out of range in shape " + std::to_string(i));
@@ -301,8 +315,8 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     s.d.light_areas = to_device(s, s.light_areas.data(), s.light_areas.size());
     s.d.area_cdf_pool = to_device(s, s.area_cdf_pool.data(), s.area_cdf_pool.size());
     s.d.area_cdf_offset = to_device(s, s.area_cdf_offset.data(), s.area_cdf_offset.size());
-    s.sobol_table = to_device(s, rdr_sobol_table, (size_t)kSobolTableWords);
-    s.ltc_table = to_device(s, rdr_ltc_table, (size_t)128 * 128 * 9);
+    s.sobol_table = (const uint64_t *)exec::device_constant(rdr_sobol_table, sizeof(uint64_t) * (size_t)kSobolTableWords);
+    s.ltc_table = (const float *)exec::device_constant(rdr_ltc_table, sizeof(float) * (size_t)128 * 128 * 9);
 
     timer.lap("device copies");
     // ---- edge sampling structures ----
@@ -318,6 +332,8 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         s.bvh.ids = to_device(s, s.bvh_host.ids.data(), s.bvh_host.ids.size());
         timer.lap("triangle hierarchy (wait)");
     }
+    exec::upload_flush();
+    timer.lap("upload flush");
     return sp.release();
 }
 

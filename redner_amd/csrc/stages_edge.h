@@ -387,6 +387,33 @@ RDR_FN double leaf_importance_l(const SceneD &sc, const EdgeSceneD &es, int eid,
     return edge_line_importance(a, b, c);
 }
 
+// leaf_importance_l on a GatherLeaf record: the same four conditions and the same value, with the cheapest and most
+// selective condition first -- the distance of the NEE segment to the edge (needs only the end points, rejects 61 % of
+// the candidates on the benchmark scene), then the two silhouette tests (79 % / 10 % in the reference's order), and the LTC
+// line integral only for what is left (2.5 %).  The function is pure, so the order of the tests cannot change its result.
+RDR_FN double leaf_importance_gathered(const GatherLeaf &gl, double expand, const LtcCtx &c, const Ray &nee, bool nee_valid) {
+    const V3 a = v3_of(gl.v0), b = v3_of(gl.v1);
+    {
+        V3 pn = nee.dir;
+        double t = -(dot(nee.org, pn) - dot(a, pn)) / dot(nee.dir, pn);
+        V3 ip = nee.org + nee.dir * t;
+        V3 ap = a - ip;
+        V3 ab = normalize(b - a);
+        V3 ept = ip + ap - (dot(ap, ab)) * ab;
+        if (len_sq(ip - ept) > sq(expand)) return 0;
+    }
+    EdgeGeom g;
+    for (int k = 0; k < 3; ++k) { g.v0[k] = gl.v0[k]; g.v1[k] = gl.v1[k]; g.o0[k] = gl.o0[k]; g.o1[k] = gl.o1[k]; }
+    g.f0 = gl.f0; g.f1 = gl.f1; g.has_normals = gl.has_normals; g.pad = 0;
+    if (!edge_is_silhouette_g(g, c.pos)) return 0;
+    if (nee_valid) {
+        if (!edge_is_silhouette_g(g, nee.org + nee.tmax * nee.dir)) return 0;
+    } else {
+        if (!edge_is_silhouette_g(g, nee.dir)) return 0;
+    }
+    return edge_line_importance(a, b, c);
+}
+
 // Slab test of the reference's edge-tree traversal (src/aabb.h:176-200), boxes grown by `expand`.
 // `inv_dir` = 1 / r.dir per axis, computed once per walk (the reference divides at every node; same values).
 RDR_FN bool ray_box_expand(V3 lo, V3 hi, const Ray &r, V3 inv_dir, double expand) {
@@ -494,8 +521,26 @@ RDR_DEV_FN int pick_edge_hierarchical(const SceneD &sc, const EdgeSceneD &es, co
 // whenever a wave holds both kinds of entries (lane utilisation of the fused loop: 0.44, profiles/r1_pmc_sq.csv).
 // The descent stack keeps kHStackLds entries per lane in LDS (13 B each: 4 workgroups per CU instead of 3) and spills the
 // rare deeper entries to `spill`; the leaf list lives in HBM (written and read once, coalesced by entry index).
+// One interior node = one 128-byte line.  Left to itself the compiler sinks each field's load into the branch that first
+// uses it (the tests have early outs), which turns a step into ~9 dependent L1 round trips; this fetches the line with
+// eight 16-byte loads issued together and pins them in registers.
+RDR_DEV_FN EdgeNodeP load_node_line(const EdgeNodeP *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *q = reinterpret_cast<const u32x4 *>(p);
+    u32x4 r0 = q[0], r1 = q[1], r2 = q[2], r3 = q[3], r4 = q[4], r5 = q[5], r6 = q[6], r7 = q[7];
+    asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
+    u32x4 all[8] = {r0, r1, r2, r3, r4, r5, r6, r7};
+    EdgeNodeP out;
+    __builtin_memcpy(&out, all, sizeof(out));
+    return out;
+#else
+    return *p;
+#endif
+}
 struct HLeaf { int ref, num; double pmf; };        // 16 B; ref: ~edge id for leaves, node reference for spilled stack entries
 constexpr int kHStackLds = 12;
+template <bool PRELOAD>
 RDR_DEV_FN int pick_edge_hierarchical_deferred(const SceneD &sc, const EdgeSceneD &es, const LtcCtx &c, double sample, double resample,
                                                double &weight, HLeaf *leaves, HLeaf *spill, size_t stride) {
     const SilQuery q_pos = sil_query(es, c.pos);
@@ -531,7 +576,8 @@ RDR_DEV_FN int pick_edge_hierarchical_deferred(const SceneD &sc, const EdgeScene
             nleaf++;
             continue;
         }
-        const EdgeNodeP &nd = edge_node(es, it.ref);
+        const EdgeNodeP nd_line = PRELOAD ? load_node_line(&edge_node(es, it.ref)) : EdgeNodeP();
+        const EdgeNodeP &nd = PRELOAD ? nd_line : edge_node(es, it.ref);
         const int tree = it.ref & kEdgeTreeBit;
         const bool tree3d = tree == 0;
         int c0 = nd.c_ref[0] < 0 ? nd.c_ref[0] : (nd.c_ref[0] | tree);
@@ -703,7 +749,9 @@ struct SecEdgeArgs {          // what every stage of the sampler needs
     const int *active; VSlice v;        // main-path vertex
 };
 
-// mode[slot]: 0 = no sample, 1 = hierarchical pick, 2 = NEE-billboard pick.  Also resets the slot's outputs.
+// mode[slot]: 0 = no sample, 1 = hierarchical pick, 2 / 3 = NEE-billboard pick (3: the vertex lies on a shape with at least
+// kDenseShapeTriangles triangles).  Also resets the slot's outputs.
+constexpr int kDenseShapeTriangles = 512;
 struct SecEdgeSetup {
     SecEdgeArgs a; unsigned char *mode; SecondaryEdgeRec *recs; SecPick *picks; VSlice ev; double *edge_tmin;
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(ev); }
@@ -725,7 +773,11 @@ struct SecEdgeSetup {
             edge_tmin[l] = 1e-3f;
             store_rdiff(ev, l, raydiff_zero());
         }
-        mode[idx] = !s.live ? 0 : (s.use_nee ? 2 : 1);
+        // NEE-mode slots are listed in two groups: a segment that starts on a finely tessellated shape begins inside a cloud of
+        // billboards and meets 64 ... 250+ hierarchy entries, one that starts on a wall meets ~10 -- kept apart, every wave of
+        // the gather holds slots of one kind (its lanes otherwise idle through the longest walk of their wave)
+        const bool dense = s.live && s.c.shape->num_triangles >= kDenseShapeTriangles;
+        mode[idx] = !s.live ? 0 : (s.use_nee ? (dense ? 3 : 2) : 1);
     }
 };
 struct KeepMode {
@@ -744,14 +796,14 @@ struct SecEdgePickH {
         picks[idx] = SecPick{eid, ew, v3(0), v3(0)};
     }
 };
-struct SecEdgePickH2 {        // the hierarchical pick with deferred leaf evaluation (pick_edge_hierarchical_deferred)
+template <bool PRELOAD> struct SecEdgePickH2 {        // the hierarchical pick with deferred leaf evaluation (pick_edge_hierarchical_deferred)
     SecEdgeArgs a; const int *slots; SecPick *picks; HLeaf *leaves, *spill; int n;      // leaves: kHSamples x n, spill: (kHSamples - kHStackLds) x n
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
     RDR_FN void operator()(int i) const {
         int idx = slots[i];
         SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
         double ew = 0;
-        int eid = pick_edge_hierarchical_deferred(a.sc, a.es, s.lc, s.edge_sel, s.resample_sel, ew, leaves + i, spill + i, (size_t)n);
+        int eid = pick_edge_hierarchical_deferred<PRELOAD>(a.sc, a.es, s.lc, s.edge_sel, s.resample_sel, ew, leaves + i, spill + i, (size_t)n);
         picks[idx] = SecPick{eid, ew, v3(0), v3(0)};
     }
 };
@@ -761,17 +813,31 @@ struct SecEdgePickH2 {        // the hierarchical pick with deferred leaf evalua
 // debugging harness only: how much work the gather does per slot (printed at exit when RDR_GATHER_STATS is set)
 struct GatherStats {
     long slots = 0, nodes = 0, edges = 0, cands = 0, overflow = 0, hist[12] = {0};
+    long wave_max_nodes = 0, wave_max_edges = 0, cur_n = 0, cur_e = 0, in_wave = 0, waves = 0, nhist[16] = {0};
+    long surv = 0, cur_s = 0, wave_max_surv = 0, shist[16] = {0};
     ~GatherStats() {
         if (!getenv("RDR_GATHER_STATS") || slots == 0) return;
+        fprintf(stderr, "[gather] per-wave(64) max nodes %.1f  max edge tests %.1f ; node-count histogram (log2 buckets):", (double)wave_max_nodes / (waves ? waves : 1), (double)wave_max_edges / (waves ? waves : 1));
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %ld", nhist[i]);
+        fprintf(stderr, "\n");
+        fprintf(stderr, "[gather] survivors of the cheap tests/slot %.3f, per-wave max %.2f, hist:", (double)surv / slots, (double)wave_max_surv / (waves ? waves : 1));
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %ld", shist[i]);
+        fprintf(stderr, "\n");
         fprintf(stderr, "[gather] slots %ld nodes/slot %.1f edge tests/slot %.2f positive leaves/slot %.4f overflow %ld  hist:", slots,
                 (double)nodes / slots, (double)edges / slots, (double)cands / slots, overflow);
         for (int i = 0; i < 12; ++i) fprintf(stderr, " %ld", hist[i]);
         fprintf(stderr, "\n");
     }
 };
-inline void gather_stats_add(long nodes, long edges, int ncand) {
+inline void gather_stats_add(long nodes, long edges, int ncand, int surv) {
     static GatherStats st;
-    st.slots++; st.nodes += nodes; st.edges += edges; st.cands += ncand; st.overflow += ncand > kGatherCands; st.hist[ncand < 11 ? ncand : 11]++;
+    st.surv += surv; if (surv > st.cur_s) st.cur_s = surv; st.shist[surv < 15 ? surv : 15]++;
+    st.slots++; st.nodes += nodes; st.edges += edges; st.cands += ncand; st.overflow += ncand > 8; st.hist[ncand < 11 ? ncand : 11]++;
+    int b = 0; while ((1L << b) <= nodes && b < 15) b++;
+    st.nhist[b]++;
+    if (nodes > st.cur_n) st.cur_n = nodes;
+    if (edges > st.cur_e) st.cur_e = edges;
+    if (++st.in_wave == 64) { st.wave_max_nodes += st.cur_n; st.wave_max_edges += st.cur_e; st.wave_max_surv += st.cur_s; st.waves++; st.cur_n = st.cur_e = st.cur_s = 0; st.in_wave = 0; }
 }
 #endif
 constexpr int kPickOverflow = -2;     // SecPick::eid of a slot the gather hands to the reference-order walk
@@ -861,95 +927,198 @@ template <int NS> struct SecEdgePickNWalk {
 // nodes per slot with a long tail, profiles/r1_notes.md) -- applies the reference's own tests to each candidate edge, and
 // replays the reservoir over the positive leaves in rank order: identical arithmetic on identical operands, identical picks.
 // Slots with more than kGatherCands positive leaves are marked kPickOverflow and walked by SecEdgePickNWalk.
-template <int NS, class IDX> struct SecEdgeGatherN {
-    SecEdgeArgs a; const int *slots; SecPick *picks; GatherCand *cands;     // cands: kGatherCands per list position i
+// Stack entries are 32-bit: an inner node is pushed as the index of its first child (its two children are adjacent, one
+// 64-byte fetch per step), a leaf as kGatherLeafBit | count << 24 | first slot -- what a step needs is known when it pops.
+constexpr int kGatherLeafBit = 1 << 30;
+struct alignas(16) GatherQuad { float x, y, z; int w; };     // half an rt::Node: {lo.xyz, a} or {hi.xyz, b}
+// ray_box_expand without the per-axis early return: the entry distance only grows and the exit distance only shrinks from
+// axis to axis, so "t0 > t1 after some axis" and "t0 > t1 after the last axis" are the same verdict; without the returns the
+// three axes' loads are issued together instead of one dependent round trip per axis.
+RDR_FN bool ray_box_all_axes(V3 lo, V3 hi, const Ray &r, V3 inv_dir, double expand) {
+    double t0 = r.tmin, t1 = r.tmax;
+    for (int i = 0; i < 3; ++i) {
+        double inv = comp(inv_dir, i);
+        double tn = (comp(lo, i) - expand - comp(r.org, i)) * inv;
+        double tf = (comp(hi, i) + expand - comp(r.org, i)) * inv;
+        if (tn > tf) { double t = tn; tn = tf; tf = t; }
+        tf *= (1 + 1e-6f);
+        t0 = tn > t0 ? tn : t0;
+        t1 = tf < t1 ? tf : t1;
+    }
+    return !(t0 > t1);
+}
+RDR_FN int gather_entry(const GatherQuad &lo, const GatherQuad &hi) {      // stack entry for the node whose record is (lo, hi)
+    return hi.w > 0 ? (kGatherLeafBit | (hi.w << 24) | lo.w) : lo.w;
+}
+// Three stages.  A segment that runs along the silhouette of a finely tessellated shape meets thousands of billboards:
+// one lane walking all of them would set the duration of the whole launch (the reference-order walk has the same tail:
+// 640 steps at the 95th percentile, thousands at the end, profiles/r1_notes.md).  So
+//   SecEdgeGatherN      one lane per slot, at most kGatherBudget pops and kGatherCands positive leaves.  A lane that needs
+//                       more registers its slot as "heavy" (atomic counter), moves its candidates to the slot's big list and
+//                       hands every entry left on its stack -- a subtree each -- to the work list;
+//   SecEdgeGatherSub    one lane per work item: walks that subtree to the end, appending to the slot's big list;
+//   SecEdgeGatherReplay one lane per heavy slot: reservoir replay over the big list.
+// A slot whose lists overflow (kGatherCandsBig candidates, kGatherHeavyCap slots, kGatherWorkCap items) keeps the
+// kPickOverflow mark and is walked by SecEdgePickNWalk.
+constexpr int kGatherBudget = 256, kGatherCandsBig = 256, kGatherHeavyCap = 8192, kGatherWorkCap = 131072, kGatherPoison = 1 << 20;
+struct GatherWork { int heavy, entry; };
+struct GatherBook {                 // zeroed before every SecEdgeGatherN launch
+    int heavy_count, work_count;
+    int cand_count[kGatherHeavyCap];
+};
+struct GatherShared { GatherBook *book; int *heavy_slot; GatherWork *work; GatherCand *cands_big; };
+
+struct GatherCtx { LtcCtx lc; Ray nee; bool nee_valid; V3 inv_dir; SilQuery q_pos, q_nee; double resample; };
+RDR_FN GatherCtx gather_ctx(const SecEdgeArgs &a, int idx) {
+    GatherCtx c;
+    SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
+    c.lc = s.lc; c.nee = s.nee; c.nee_valid = s.nee_valid; c.resample = s.resample_sel;
+    c.q_pos = sil_query(a.es, s.lc.pos); c.q_nee = sil_query(a.es, s.nee_pt.position);
+    c.inv_dir = V3{1 / s.nee.dir.x, 1 / s.nee.dir.y, 1 / s.nee.dir.z};
+    return c;
+}
+RDR_FN void gather_append_big(const GatherShared &sh, int heavy, const GatherCand &cd) {
+    if (heavy < 0 || heavy >= kGatherHeavyCap) return;
+    const int k = atomic_fetch_add(&sh.book->cand_count[heavy], 1);
+    if (k >= 0 && k < kGatherCandsBig) sh.cands_big[(size_t)heavy * kGatherCandsBig + k] = cd;
+}
+// One pop of the gather: an inner entry tests its two children and pushes the ones the segment may reach, a leaf entry
+// applies the reference's own tests to its 1..4 edges and reports the positive ones through `emit`.
+template <int NS, class Emit>
+RDR_DEV_FN void gather_pop(const SceneD &sc, const EdgeSceneD &es, const GatherCtx &c, int *stk, int &sp, const Emit &emit, long &h_edges) {
+    const GatherQuad *quads = reinterpret_cast<const GatherQuad *>(es.gather.nodes);
+    --sp;
+    const int e = RDR_STACK_AT(stk, sp);
+    if (e & kGatherLeafBit) {
+        const int first = e & 0xffffff, count = (e >> 24) & 63;
+        for (int k = 0; k < count; ++k) {
+            const GatherLeaf gl = es.gleaf[first + k];
+            h_edges++;
+            // the edge's own leaf, tested like the reference tests it from its parent
+            bool ok = sphere_box_x(c.q_pos, gl.dx_lo, gl.dx_hi);
+            if (c.nee_valid) ok = ok && sphere_box_x(c.q_nee, gl.dx_lo, gl.dx_hi);
+            const V3 p0 = v3_of(gl.v0), p1 = v3_of(gl.v1);
+            const V3 blo = V3{dmin(p0.x, p1.x), dmin(p0.y, p1.y), dmin(p0.z, p1.z)}, bhi = V3{dmax(p0.x, p1.x), dmax(p0.y, p1.y), dmax(p0.z, p1.z)};
+            ok = ok && ray_box_all_axes(blo, bhi, c.nee, c.inv_dir, es.edge_bounds_expand);
+            if (!ok) continue;
+            h_edges += 1000000;          // (harness statistics: survivors of the cheap tests in the upper digits)
+            const double w = leaf_importance_gathered(gl, es.edge_bounds_expand, c.lc, c.nee, c.nee_valid);
+            if (w > 0) emit(GatherCand{gl.rank, gl.eid, w});
+        }
+    } else {
+        const GatherQuad l_lo = quads[2 * e], l_hi = quads[2 * e + 1], r_lo = quads[2 * e + 2], r_hi = quads[2 * e + 3];
+        const int el = gather_entry(l_lo, l_hi), er = gather_entry(r_lo, r_hi);      // (before the tests: whole-record loads)
+        const bool hl = ray_box_all_axes(V3{(double)l_lo.x, (double)l_lo.y, (double)l_lo.z}, V3{(double)l_hi.x, (double)l_hi.y, (double)l_hi.z}, c.nee, c.inv_dir, 0.0);
+        const bool hr = ray_box_all_axes(V3{(double)r_lo.x, (double)r_lo.y, (double)r_lo.z}, V3{(double)r_hi.x, (double)r_hi.y, (double)r_hi.z}, c.nee, c.inv_dir, 0.0);
+        if (hl && sp < NS) { RDR_STACK_AT(stk, sp) = el; sp++; }
+        if (hr && sp < NS) { RDR_STACK_AT(stk, sp) = er; sp++; }
+    }
+}
+// Reservoir replay in the reference's leaf order (src/edge.cpp:1300-1316) over `n` candidates, then the pick's tail.
+RDR_FN SecPick gather_replay(const SecEdgeArgs &a, int idx, const GatherCand *list, int n, double resample) {
+    int selected = -1, last_rank = -1;
+    double edge_w = 0, wsum = 0;
+    for (int t = 0; t < n; ++t) {
+        int best = -1, best_rank = 0x7fffffff;
+        for (int j = 0; j < n; ++j) {
+            const int r = list[j].rank;
+            if (r > last_rank && r < best_rank) { best_rank = r; best = j; }
+        }
+        const GatherCand cd = list[best];
+        last_rank = best_rank;
+        const double prev = wsum;
+        wsum += cd.w;
+        const double nw = cd.w / wsum;
+        if (resample <= nw || prev == 0) { selected = cd.eid; edge_w = cd.w; resample /= nw; }
+        else resample = (resample - nw) / (1 - nw);
+    }
+    SecPick out{-1, 0.0, v3(0), v3(0)};
+    if (selected != -1) {
+        SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
+        double ew = 0;
+        V3 sample_p = v3(0), mwt = v3(0);
+        int eid = finish_edge_nee(a.sc, a.es, s.nee, s.nee_valid, s.nee_pt, s.nee_shape, selected, edge_w, wsum, ew, sample_p, mwt);
+        out = SecPick{eid, ew, sample_p, mwt};
+    }
+    return out;
+}
+
+template <int NS> struct SecEdgeGatherN {
+    SecEdgeArgs a; const int *slots; SecPick *picks; GatherCand *cands;     // cands: kGatherCands per list position
+    GatherShared sh; int budget;                                            // budget: kGatherBudget (RDR_GATHER_BUDGET overrides)
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
     RDR_FN void operator()(int i) const {
         const SceneD &sc = a.sc; const EdgeSceneD &es = a.es;
         const int idx = slots[i];
-        LtcCtx lc; Ray nee; bool nee_valid; double resample; SilQuery q_pos, q_nee;
-        {
-            SecPre s = sec_prepare(sc, es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
-            lc = s.lc; nee = s.nee; nee_valid = s.nee_valid; resample = s.resample_sel;
-            q_pos = sil_query(es, s.lc.pos); q_nee = sil_query(es, s.nee_pt.position);
-        }
-        const V3 inv_dir = V3{1 / nee.dir.x, 1 / nee.dir.y, 1 / nee.dir.z};
+        const GatherCtx c = gather_ctx(a, idx);
         GatherCand *mine = cands + (size_t)kGatherCands * i;
-        int ncand = 0;
-        RDR_STACK_DECL(IDX, stk, NS);
+        int ncand = 0, heavy = -1;
+        RDR_STACK_DECL(int, stk, NS);
         int sp = 0;
-        const rt::BvhD &g = es.gather;
-        if (g.num_nodes > 0) {
-            const rt::Node &root = g.nodes[0];
-            if (ray_box_expand(v3_of(root.lo), v3_of(root.hi), nee, inv_dir, 0.0)) { RDR_STACK_AT(stk, sp) = (IDX)0; sp++; }
-        }
-#ifdef RDR_HOSTSIM
-        long h_nodes = 0, h_edges = 0, h_imp = 0;
-#endif
-        while (sp > 0) {
-            --sp;
-            const rt::Node &n = g.nodes[(int)RDR_STACK_AT(stk, sp)];
-#ifdef RDR_HOSTSIM
-            h_nodes++;
-#endif
-            if (n.b > 0) {
-                for (int k = 0; k < n.b; ++k) {
-                    const int eid = g.ids[2 * (n.a + k) + 1];
-#ifdef RDR_HOSTSIM
-                    h_edges++;
-#endif
-                    // the edge's own leaf, tested like the reference tests it from its parent
-                    const double dx_lo = es.leaf_dx[2 * (size_t)eid], dx_hi = es.leaf_dx[2 * (size_t)eid + 1];
-                    if (!sphere_box_x(q_pos, dx_lo, dx_hi)) continue;
-                    if (nee_valid && !sphere_box_x(q_nee, dx_lo, dx_hi)) continue;
-                    const EdgeGeom &eg = es.geom[eid];
-                    const V3 p0 = v3_of(eg.v0), p1 = v3_of(eg.v1);
-                    const V3 blo = V3{dmin(p0.x, p1.x), dmin(p0.y, p1.y), dmin(p0.z, p1.z)}, bhi = V3{dmax(p0.x, p1.x), dmax(p0.y, p1.y), dmax(p0.z, p1.z)};
-                    if (!ray_box_expand(blo, bhi, nee, inv_dir, es.edge_bounds_expand)) continue;
-                    const double w = leaf_importance_l(sc, es, eid, lc, nee, nee_valid);
-                    if (w > 0) {
-                        if (ncand < kGatherCands) mine[ncand] = GatherCand{es.leaf_rank[eid], eid, w};
-                        ncand++;
-                    }
-                }
-            } else {
-                const rt::Node &l = g.nodes[n.a], &r = g.nodes[n.a + 1];
-                const bool hl = ray_box_expand(v3_of(l.lo), v3_of(l.hi), nee, inv_dir, 0.0);
-                const bool hr = ray_box_expand(v3_of(r.lo), v3_of(r.hi), nee, inv_dir, 0.0);
-                if (hl && sp < NS) { RDR_STACK_AT(stk, sp) = (IDX)n.a; sp++; }
-                if (hr && sp < NS) { RDR_STACK_AT(stk, sp) = (IDX)(n.a + 1); sp++; }
+        if (es.gather.num_nodes > 0) {
+            const GatherQuad *quads = reinterpret_cast<const GatherQuad *>(es.gather.nodes);
+            const GatherQuad lo = quads[0], hi = quads[1];
+            if (ray_box_all_axes(V3{(double)lo.x, (double)lo.y, (double)lo.z}, V3{(double)hi.x, (double)hi.y, (double)hi.z}, c.nee, c.inv_dir, 0.0)) {
+                RDR_STACK_AT(stk, sp) = gather_entry(lo, hi); sp++;
             }
         }
-#ifdef RDR_HOSTSIM
-        gather_stats_add(h_nodes, h_edges, ncand);
-#endif
-        if (ncand > kGatherCands) { picks[idx] = SecPick{kPickOverflow, 0.0, v3(0), v3(0)}; return; }
-        // reservoir replay in the reference's leaf order (src/edge.cpp:1300-1316)
-        int selected = -1, last_rank = -1;
-        double edge_w = 0, wsum = 0;
-        for (int t = 0; t < ncand; ++t) {
-            int best = -1, best_rank = 0x7fffffff;
-            for (int j = 0; j < ncand; ++j) {
-                const int r = mine[j].rank;
-                if (r > last_rank && r < best_rank) { best_rank = r; best = j; }
+        auto promote = [&]() {              // this slot continues in the big lists
+            heavy = atomic_fetch_add(&sh.book->heavy_count, 1);
+            if (heavy < kGatherHeavyCap) sh.heavy_slot[heavy] = i;
+            for (int k = 0; k < ncand; ++k) gather_append_big(sh, heavy, mine[k]);
+        };
+        auto emit = [&](const GatherCand &cd) {
+            if (heavy < 0 && ncand < kGatherCands) { mine[ncand] = cd; ncand++; return; }
+            if (heavy < 0) promote();
+            gather_append_big(sh, heavy, cd);
+        };
+        long h_nodes = 0, h_edges = 0;
+        while (sp > 0 && h_nodes < budget) { h_nodes++; gather_pop<NS>(sc, es, c, stk, sp, emit, h_edges); }
+        if (sp > 0) {                        // budget spent: every entry left is a subtree for SecEdgeGatherSub
+            if (heavy < 0) promote();
+            bool lost = heavy >= kGatherHeavyCap;
+            for (int k = 0; k < sp && !lost; ++k) {
+                const int w = atomic_fetch_add(&sh.book->work_count, 1);
+                if (w < kGatherWorkCap) sh.work[w] = GatherWork{heavy, RDR_STACK_AT(stk, k)};
+                else lost = true;
             }
-            const GatherCand cd = mine[best];
-            last_rank = best_rank;
-            const double prev = wsum;
-            wsum += cd.w;
-            const double nw = cd.w / wsum;
-            if (resample <= nw || prev == 0) { selected = cd.eid; edge_w = cd.w; resample /= nw; }
-            else resample = (resample - nw) / (1 - nw);
+            if (lost && heavy < kGatherHeavyCap) atomic_fetch_add(&sh.book->cand_count[heavy], kGatherPoison);
         }
-        SecPick out{-1, 0.0, v3(0), v3(0)};
-        if (selected != -1) {
-            SecPre s = sec_prepare(sc, es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
-            double ew = 0;
-            V3 sample_p = v3(0), mwt = v3(0);
-            int eid = finish_edge_nee(sc, es, s.nee, s.nee_valid, s.nee_pt, s.nee_shape, selected, edge_w, wsum, ew, sample_p, mwt);
-            out = SecPick{eid, ew, sample_p, mwt};
-        }
-        picks[idx] = out;
+#ifdef RDR_HOSTSIM
+        gather_stats_add(h_nodes, h_edges % 1000000, ncand, (int)(h_edges / 1000000));
+#endif
+        if (heavy >= 0) { picks[idx] = SecPick{kPickOverflow, 0.0, v3(0), v3(0)}; return; }
+        picks[idx] = gather_replay(a, idx, mine, ncand, c.resample);
+    }
+};
+template <int NS> struct SecEdgeGatherSub {
+    SecEdgeArgs a; const int *slots; GatherShared sh;
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void operator()(int j) const {
+        const int n_work = sh.book->work_count < kGatherWorkCap ? sh.book->work_count : kGatherWorkCap;
+        if (j >= n_work) return;
+        const GatherWork wk = sh.work[j];
+        const int idx = slots[sh.heavy_slot[wk.heavy]];
+        const GatherCtx c = gather_ctx(a, idx);
+        RDR_STACK_DECL(int, stk, NS);
+        int sp = 0;
+        RDR_STACK_AT(stk, sp) = wk.entry; sp++;
+        auto emit = [&](const GatherCand &cd) { gather_append_big(sh, wk.heavy, cd); };
+        long h_edges = 0;
+        while (sp > 0) gather_pop<NS>(a.sc, a.es, c, stk, sp, emit, h_edges);
+    }
+};
+struct SecEdgeGatherReplay {
+    SecEdgeArgs a; const int *slots; SecPick *picks; GatherShared sh;
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void operator()(int h) const {
+        const int n_heavy = sh.book->heavy_count < kGatherHeavyCap ? sh.book->heavy_count : kGatherHeavyCap;
+        if (h >= n_heavy) return;
+        const int n = sh.book->cand_count[h];
+        if (n < 0 || n > kGatherCandsBig) return;          // stays kPickOverflow: SecEdgePickNWalk takes it
+        const int idx = slots[sh.heavy_slot[h]];
+        SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
+        picks[idx] = gather_replay(a, idx, sh.cands_big + (size_t)h * kGatherCandsBig, n, s.resample_sel);
     }
 };
 

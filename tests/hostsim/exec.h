@@ -24,6 +24,7 @@
 
 namespace rdr {
 inline void accum(double *p, double v) { *p += v; }
+inline int atomic_fetch_add(int *p, int v) { int o = *p; *p += v; return o; }
 }
 
 namespace exec {
@@ -38,6 +39,11 @@ inline void upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, 
 inline void download(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void sync() {}
 inline int current_device() { return 0; }
+inline void upload_async(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
+inline void upload_flush() {}
+struct DownloadItem { void *dst; const void *src; size_t bytes; };
+inline void download_batch(const DownloadItem *items, int n) { for (int i = 0; i < n; ++i) memcpy(items[i].dst, items[i].src, items[i].bytes); }
+inline const void *device_constant(const void *host, size_t) { return host; }
 }
 typedef void *hipStream_t;       // the host driver names streams; the harness has one implicit stream
 namespace exec {
@@ -54,6 +60,7 @@ struct SecondThread {          // never used: sample_workers() == 1
 };
 template <class F>
 inline void launch(int n, const F &f) { for (int i = 0; i < n; ++i) f(i); }
+inline int *persistent_counter() { static int ring[64]; static int at = 0; at = (at + 1) % 64; ring[at] = 0; return ring + at; }
 template <class W>
 inline void launch_persistent(int n, const W &w) {          // see hip/exec.h: begin / step... / finish per item
     for (int i = 0; i < n; ++i) {
