@@ -2,31 +2,44 @@
 """bench.py -- forward+backward throughput of the differentiable path tracer on MI355X.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
-torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+torch.distributed.run, one rank per GPU (backend nccl = RCCL).  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json metric "Msamples/s fwd+bwd (1024^2 x spp)"): the bunny_box scene
-(tests/scenes.py, arrays exported from the reference's tests/scenes/bunny_box.xml), 1024x1024,
-max_bounces 4, Sobol' sampler, gradients w.r.t. the bunny's vertices (+ edge sampling), as in
-tests/test_bunny_box.py.  One step = one forward render + one backward render of `--spp` samples
-per pixel PER GPU (default 32, so 8 GPUs reproduce config 4: 1024^2 x 256 spp sharded by sample
-index); weak scaling.  value = N * W * H * spp * K / t / 1e6, t = max over ranks of the wall time of
-the K steps (barrier + device sync on both sides).  Scene construction (triangle/edge hierarchy
-build) is outside the timed region and reported separately, as SURVEY.md section 8d prescribes;
-all inputs are resident in HBM when the clock starts.
+Workload (BASELINE.json metric "Msamples/s fwd+bwd (1024^2 x spp)", config 4): the bunny_box scene
+(tests/scenes.py, arrays exported from the reference's tests/scenes/bunny_box.xml), 1024 x 1024,
+max_bounces 4, Sobol' sampler, 256 spp, gradients w.r.t. the bunny's vertices with primary and
+secondary edge sampling, as in tests/test_bunny_box.py.  One step = one forward render + one backward
+render of the WHOLE 256-spp job; N ranks shard it by Sobol' sample index (rank r renders samples
+[r*256/N, (r+1)*256/N) of the full frame) and all-gather + sum the image and every
+gradient tensor in fixed rank order: strong scaling.  value = W*H*spp*K / t / 1e6 with t = max over
+ranks of the wall time of the K steps (barrier + device sync on both sides).  Scene construction is
+outside the timed region and reported separately; inputs are resident in HBM.
+
+`--workload living_room_standin` is BASELINE config 5's stand-in (tests/scenes.py): the general kernels
+(mip-mapped textures, two-sided materials, ray differentials), max_bounces 6, camera-pose gradients.
 
 Extra objects in the JSON line:
-  roofline      -- the closest-hit traversal kernel: algorithmic bytes (40 B per ray + 32 B per node
-                   record loaded + 36 B per triangle tested, counted by the instrumented kernel
-                   variant on the same rays in an untimed pass) / its mean launch time, measured with
-                   HIP events on the launch stream inside the timed region; vs 8 TB/s HBM.
+  roofline      -- the closest-hit traversal kernel by SURVEY.md section 8d: algorithmic bytes (40 B per ray +
+                   32 B per node record + 36 B per triangle tested, counted by the instrumented kernel on the
+                   same rays in an untimed pass) / mean launch time from HIP events on the launch stream inside
+                   the timed region, vs 8 TB/s.  Next to it what the hardware counters say (rocprofv3 passes
+                   run from inside this process on a 2-spp job, `profile`): HBM bytes actually moved
+                   (hbm_frac_measured), vector-ALU lane utilisation, rays/s -- and the same for the kernels that
+                   dominate the backward pass (`kernels`: fp64 VALU lane-operations/s against the 39.3 T/s the
+                   chip can issue, HBM bytes/s against 8 TB/s).
   cpu_baseline  -- the reference's own C++ core (oracle/_ref, Embree stand-in) on this box's host
                    cores, on a bounded sample of the same workload (rank 0, N = 1 only).
 """
 import argparse
+import collections
+import csv
 import ctypes
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -36,6 +49,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9     # CUs x SIMDs x lanes/clk x clock = 39.3 T lane-operations/s (79 TFLOP/s fp64 FMA)
 RAY_BYTES, HIT_BYTES, NODE_BYTES, TRI_BYTES = 32, 8, 32, 36
 
 
@@ -61,35 +75,8 @@ class Prepared:
         self.h, self.w = vp[2] - vp[0], vp[3] - vp[1]
         self.img = torch.zeros(self.h, self.w, 3, device=device)
         self.d_img = torch.ones(self.h, self.w, 3, device=device)      # d(sum(img))/d(img)
-        fp = lambda t: rd.float_ptr(t.data_ptr() if t is not None else 0)   # noqa: E731
-        self.grads = []
-
-        def z(i):
-            if i < 0:
-                return None
-            g = torch.zeros(self.tensors[i].shape, dtype=torch.float32, device=device)
-            self.grads.append(g)
-            return g
-
-        cm = self.meta['camera']
-        look = cm['cam_to_world'] < 0
-        d_cam = rd.DCamera(fp(z(cm['position']) if look else None), fp(z(cm['look_at']) if look else None),
-                           fp(z(cm['up']) if look else None), fp(None if look else z(cm['cam_to_world'])),
-                           fp(None if look else z(cm['world_to_cam'])), fp(z(cm['intrinsic_mat_inv'])),
-                           fp(z(cm['intrinsic_mat'])), fp(None))
-        d_shapes = [rd.DShape(fp(z(s['vertices'])), fp(z(s['uvs'])), fp(z(s['normals'])), fp(z(s['colors'])))
-                    for s in self.meta['shapes']]
-
-        def d_tex(cls, tm):
-            lv = z(tm['levels'][0])
-            return cls([fp(lv)], [0], [0], int(lv.shape[0]), fp(z(tm['uv_scale'])))
-
-        d_mats = [rd.DMaterial(d_tex(rd.Texture3, m['diffuse_reflectance']), d_tex(rd.Texture3, m['specular_reflectance']),
-                               d_tex(rd.Texture1, m['roughness']), rd.TextureN([], [], [], 0, rd.float_ptr(0)),
-                               rd.Texture3([], [], [], 0, rd.float_ptr(0))) for m in self.meta['materials']]
-        d_lights = [rd.DAreaLight(fp(z(l['intensity']))) for l in self.meta['lights']]
-        idx = device.index if device.index is not None else 0
-        self.d_scene = rd.DScene(d_cam, d_shapes, d_mats, d_lights, None, device.type == 'cuda', idx)
+        self.d_scene, grads = RenderFunction.create_gradient_buffers(self.meta, self.tensors)
+        self.grads = [g for g in grads if g is not None]
         self.seed = seed
 
     def step(self, i):
@@ -115,16 +102,22 @@ def trace_stats(reset=False):
     return st
 
 
-def cpu_baseline(max_bounces):
+def build_scene(a, device, res):
+    import scenes
+    if a.workload == 'living_room_standin':
+        return scenes.living_room_standin(device, resolution=(res, res))
+    return scenes.bunny_box(device, resolution=(res, res))
+
+
+def cpu_baseline(a):
     """The reference's C++ core (oracle/_ref) on the host cores, bounded sample of the workload."""
     import oracle_util
-    import scenes
     if not oracle_util.oracle_available():
         return None
     ref = oracle_util.load_oracle()
     res, spp = 256, 4
     cpu = torch.device('cpu')
-    p = Prepared(ref, scenes.bunny_box(cpu, resolution=(res, res)), spp, spp, 0, max_bounces, cpu)
+    p = Prepared(ref, build_scene(a, cpu, res), spp, spp, 0, a.max_bounces, cpu)
     p.step(0)                                   # warm-up (thread pool, page faults)
     t0 = time.time()
     reps = 0
@@ -134,9 +127,9 @@ def cpu_baseline(max_bounces):
     dt = time.time() - t0
     return {'value': res * res * spp * reps / dt / 1e6, 'unit': 'Msamples/s', 'cores': os.cpu_count(),
             'kind': 'reference',
-            'sample': 'bunny_box %dx%d, %d spp fwd+bwd, max_bounces %d, Sobol, %d repetitions in %.1f s; '
+            'sample': '%s %dx%d, %d spp fwd+bwd, max_bounces %d, Sobol, %d repetitions in %.1f s; '
                       'reference C++ core (oracle/_ref) with the BVH Embree stand-in, all host threads'
-                      % (res, res, spp, max_bounces, reps, dt)}
+                      % (a.workload, res, res, spp, a.max_bounces, reps, dt)}
 
 
 def alone_leg(st, alg_bytes_launch):
@@ -147,17 +140,124 @@ def alone_leg(st, alg_bytes_launch):
             'note': 'untimed extra step with every stage on one stream'}
 
 
-def measured_traffic(a):
-    """HBM bytes per closest-hit launch from the PMC passes (rocprofv3 cannot run inside this process): the
-    committed measurement in profiles/r1_traffic.json, valid for the default workload only, else None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_traffic.json')
-    if a.res != 1024 or a.max_bounces != 4 or not os.path.exists(path):
+# ---- hardware counters, collected from inside the run ------------------------------------------------------------------
+PROFILE_KERNELS = collections.OrderedDict([       # short name -> substring of the rocprofv3 kernel name
+    ('trace_closest', 'trace_kernel<false, false'), ('trace_any', 'trace_kernel<true, false'),
+    ('SecEdgePickH', 'SecEdgePickH'), ('SecEdgeGatherN', 'SecEdgeGatherN'), ('AdjBounceScatter', 'AdjBounceScatter'),
+    ('AdjBounceNee', 'AdjBounceNee'), ('BounceContrib', 'BounceContrib'), ('BounceSample', 'BounceSample'),
+    ('AdjPrimary', 'AdjPrimary')])
+SQ_COUNTERS = ['SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU', 'SQ_THREAD_CYCLES_VALU']
+
+
+def _rocprof(extra, a, out_dir, env=None):
+    """One rocprofv3 pass over `bench.py --inner` (2 spp, one forward+backward).  Returns the output directory or None."""
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
         return None
+    cmd = [exe] + extra + ['--kernel-trace', '--output-format', 'csv', '-d', out_dir, '--', sys.executable,
+                           os.path.join(ROOT, 'bench.py'), '--inner', '--res', str(a.res), '--max-bounces', str(a.max_bounces),
+                           '--workload', a.workload]
+    e = dict(os.environ)
+    e.update(env or {})
+    e['TMPDIR'] = '/tmp'
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        e.pop(k, None)
     try:
-        with open(path) as f:
-            return float(json.load(f)['hbm_bytes_per_launch'])
+        subprocess.run(cmd, cwd='/tmp', env=e, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
     except Exception:
         return None
+    return out_dir
+
+
+def _kernel_key(name):
+    for short, pat in PROFILE_KERNELS.items():
+        if pat in name:
+            return short
+    return None
+
+
+def _read_counters(out_dir):
+    fs = glob.glob(os.path.join(out_dir, '*', '*_counter_collection.csv'))
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(set)
+    if not fs:
+        return agg, launches
+    for r in csv.DictReader(open(fs[0])):
+        k = _kernel_key(r['Kernel_Name'])
+        if k is None:
+            continue
+        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+        launches[k].add(r['Dispatch_Id'])
+    return agg, launches
+
+
+def _read_durations(out_dir):
+    """kernel-trace csv -> {short: (launches, mean ms)}"""
+    fs = glob.glob(os.path.join(out_dir, '*', '*_kernel_trace.csv'))
+    tot, n = collections.defaultdict(float), collections.defaultdict(int)
+    if not fs:
+        return {}
+    for r in csv.DictReader(open(fs[0])):
+        k = _kernel_key(r['Kernel_Name'])
+        if k is None:
+            continue
+        tot[k] += (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-6
+        n[k] += 1
+    return {k: (n[k], tot[k] / n[k]) for k in n}
+
+
+def profile_kernels(a):
+    """Four rocprofv3 passes on a 2-spp forward+backward of the same workload: kernel durations (stages overlapped as in
+    the benchmark, and each kernel on its own with RDR_NO_OVERLAP=1), SQ counters, FETCH_SIZE, WRITE_SIZE (separate passes,
+    MI355X_MICROARCH.md "HBM": gfx950 FETCH_SIZE counts 64 B per 128-B request, hence x2).  Returns {kernel: {...}}."""
+    base = tempfile.mkdtemp(prefix='rdr_prof_', dir='/tmp')
+    out = {}
+    try:
+        d_over = _rocprof([], a, os.path.join(base, 'over'))
+        d_alone = _rocprof([], a, os.path.join(base, 'alone'), {'RDR_NO_OVERLAP': '1'})
+        d_sq = _rocprof(['--pmc'] + SQ_COUNTERS, a, os.path.join(base, 'sq'), {'RDR_NO_OVERLAP': '1'})
+        d_f = _rocprof(['--pmc', 'FETCH_SIZE'], a, os.path.join(base, 'fetch'), {'RDR_NO_OVERLAP': '1'})
+        d_w = _rocprof(['--pmc', 'WRITE_SIZE'], a, os.path.join(base, 'write'), {'RDR_NO_OVERLAP': '1'})
+        if not (d_over and d_alone and d_sq and d_f and d_w):
+            return None
+        dur_over, dur_alone = _read_durations(d_over), _read_durations(d_alone)
+        sq, sq_n = _read_counters(d_sq)
+        fe, fe_n = _read_counters(d_f)
+        wr, wr_n = _read_counters(d_w)
+        for k in PROFILE_KERNELS:
+            if k not in dur_alone or k not in sq:
+                continue
+            n, ms = dur_alone[k]
+            v = sq[k]
+            nl = max(len(sq_n[k]), 1)
+            lane_ops = v['SQ_THREAD_CYCLES_VALU'] / nl                  # sum over vector instructions of their active lanes, per launch
+            lane_util = v['SQ_THREAD_CYCLES_VALU'] / (64.0 * v['SQ_ACTIVE_INST_VALU']) if v['SQ_ACTIVE_INST_VALU'] else 0.0
+            hbm = (fe[k]['FETCH_SIZE'] * 2.0 / max(len(fe_n[k]), 1) + wr[k]['WRITE_SIZE'] / max(len(wr_n[k]), 1)) * 1024.0
+            out[k] = {
+                'launches_per_sample': n / 2.0,      # the inner run renders 2 spp
+                'mean_launch_ms_alone': ms,
+                'mean_launch_ms_overlapped': dur_over.get(k, (0, None))[1],
+                'valu_lane_util': lane_util,
+                'valu_lane_ops_per_launch': lane_ops,
+                'valu_frac_of_peak': lane_ops / (ms * 1e-3) / VALU_LANE_OPS_PEAK if ms > 0 else None,
+                'wave_cycles_waiting_frac': v['SQ_WAIT_ANY'] / v['SQ_WAVE_CYCLES'] if v['SQ_WAVE_CYCLES'] else None,
+                'hbm_bytes_per_launch': hbm,
+                'hbm_GBs': hbm / (ms * 1e-3) / 1e9 if ms > 0 else None,
+                'hbm_frac_of_peak': hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
+            }
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    return out or None
+
+
+def inner_run(a):
+    """Body of the rocprofv3 passes: one forward+backward of 2 spp, nothing printed."""
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(0)
+    from redner_amd import redner
+    prep = Prepared(redner, build_scene(a, dev, a.res), 2, 2, 0, a.max_bounces, dev)
+    prep.step(0)
+    torch.cuda.synchronize(dev)
 
 
 def main():
@@ -165,29 +265,36 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--spp', type=int, default=32, help='samples per pixel per GPU per step')
+    ap.add_argument('--spp', type=int, default=256, help='samples per pixel of the whole job (sharded over the GPUs)')
     ap.add_argument('--res', type=int, default=1024)
-    ap.add_argument('--max-bounces', type=int, default=4)
+    ap.add_argument('--max-bounces', type=int, default=None)
+    ap.add_argument('--workload', default='bunny_box', choices=['bunny_box', 'living_room_standin'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-alone-leg', action='store_true', help='skip the extra single-stream step behind roofline.alone (profiling runs)')
+    ap.add_argument('--no-alone-leg', action='store_true', help='skip the extra single-stream step behind roofline.alone')
+    ap.add_argument('--no-profile', action='store_true', help='skip the rocprofv3 counter passes behind roofline.kernels')
+    ap.add_argument('--inner', action='store_true', help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.max_bounces is None:
+        a.max_bounces = 6 if a.workload == 'living_room_standin' else 4
+    if a.inner:
+        return inner_run(a)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
-    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % a.gpus
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda:%d' % local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+        assert dist.get_world_size() == world
+    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE is %d)' % (a.gpus, world)
+    assert a.spp % world == 0, '--spp must be divisible by the number of GPUs'
+    spp_rank = a.spp // world
 
     from redner_amd import redner
-    import scenes
-    total_spp = a.spp * world
-    prep = Prepared(redner, scenes.bunny_box(dev, resolution=(a.res, a.res)), a.spp, total_spp, rank * a.spp,
-                    a.max_bounces, dev)
+    prep = Prepared(redner, build_scene(a, dev, a.res), spp_rank, a.spp, rank * spp_rank, a.max_bounces, dev)
     reduce_bufs = [prep.img] + [g for g in prep.grads]
 
     def reduce_all():
@@ -221,60 +328,79 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    samples = world * a.res * a.res * a.spp * a.steps
+    samples = a.res * a.res * a.spp * a.steps
     value = samples / dt / 1e6
 
-    # untimed pass with the instrumented traversal variant: node / triangle records per launch
+    # everything below is untimed and works on a short job (the counters do not depend on the sample count)
+    short = Prepared(redner, build_scene(a, dev, a.res), min(spp_rank, 8), min(spp_rank, 8), 0, a.max_bounces, dev)
+    # instrumented traversal variant: node / triangle records per launch
     lib.rdr_trace_stats_enable(0, 1)
     trace_stats(reset=True)
-    prep.step(a.warmup)                      # same seed as the first timed step -> same rays
+    short.step(a.warmup)
     torch.cuda.synchronize(dev)
     cnt = trace_stats()
     lib.rdr_trace_stats_enable(0, 0)
 
-    # untimed pass on ONE stream: the traversal kernel's launch duration without a neighbour on the GPU (in the timed
-    # region the shadow-ray launch of the same bounce runs beside every closest-hit launch)
+    # ONE stream: the traversal kernel's launch duration without a neighbour on the GPU (in the timed region the
+    # shadow-ray launch of the same bounce runs beside every closest-hit launch)
     alone = None
     if not a.no_alone_leg:
         os.environ['RDR_NO_OVERLAP'] = '1'
         lib.rdr_trace_stats_enable(1, 0)
         trace_stats(reset=True)
-        prep.step(a.warmup)
+        short.step(a.warmup)
         torch.cuda.synchronize(dev)
         alone = trace_stats()
         lib.rdr_trace_stats_enable(0, 0)
         del os.environ['RDR_NO_OVERLAP']
+    del short
 
     out = None
     if rank == 0:
-        per_step_launches = cnt.closest_launches
         rays = cnt.closest_rays
-        alg_bytes_step = rays * (RAY_BYTES + HIT_BYTES) + cnt.closest_nodes * NODE_BYTES + cnt.closest_tris * TRI_BYTES
+        alg_bytes = rays * (RAY_BYTES + HIT_BYTES) + cnt.closest_nodes * NODE_BYTES + cnt.closest_tris * TRI_BYTES
+        alg_bytes_launch = alg_bytes / max(cnt.closest_launches, 1)
         mean_launch_ms = st.closest_ms / max(st.closest_launches, 1)
-        alg_bytes_launch = alg_bytes_step / max(per_step_launches, 1)
         achieved = alg_bytes_launch / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
+        rays_per_launch = rays / max(cnt.closest_launches, 1)
+        prof = None
+        if world == 1 and not a.no_profile:
+            try:
+                prof = profile_kernels(a)
+            except Exception as e:      # the counters must never take the throughput number down with them
+                prof = {'error': repr(e)}
+        tc = (prof or {}).get('trace_closest') if isinstance(prof, dict) else None
         out = {
             'metric': 'Msamples/s fwd+bwd', 'value': value, 'unit': 'Msamples/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'bunny_box %dx%d, max_bounces %d, Sobol, %d spp per GPU per step fwd+bwd '
-                                   '(vertex gradients, primary+secondary edge sampling); %d GPUs = %d spp sharded by '
-                                   'sample index' % (a.res, a.res, a.max_bounces, a.spp, world, total_spp),
-                       'resolution': [a.res, a.res], 'spp_per_gpu': a.spp, 'max_bounces': a.max_bounces,
-                       'parallelism': 'sample-sharded x%d' % world},
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%s %dx%d, max_bounces %d, Sobol, %d spp fwd+bwd per step (%s gradients, primary+secondary '
+                                   'edge sampling), sharded by sample index over %d GPU(s): %d spp per GPU'
+                                   % (a.workload, a.res, a.res, a.max_bounces, a.spp,
+                                      'camera-pose' if a.workload == 'living_room_standin' else 'vertex', world, spp_rank),
+                       'resolution': [a.res, a.res], 'spp': a.spp, 'spp_per_gpu': spp_rank, 'max_bounces': a.max_bounces,
+                       'parallelism': 'sample-sharded x%d' % world, 'world_size': world},
             'scene_build_ms': prep.scene_build_s * 1e3,
             'roofline': {'kernel': 'trace_kernel<closest-hit>', 'bound': 'hbm', 'achieved': achieved,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': measured_traffic(a),
-                         'mean_launch_ms': mean_launch_ms, 'launches_per_step': per_step_launches,
-                         'rays_per_step': rays, 'nodes_per_ray': cnt.closest_nodes / max(rays, 1),
-                         'tris_per_ray': cnt.closest_tris / max(rays, 1),
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': tc['hbm_bytes_per_launch'] if tc else None,
+                         'mean_launch_ms': mean_launch_ms, 'launches_per_step': st.closest_launches / max(a.steps, 1),
+                         'rays_per_launch': rays_per_launch,
+                         'rays_per_s': rays_per_launch / (mean_launch_ms * 1e-3) if mean_launch_ms > 0 else None,
+                         'nodes_per_ray': cnt.closest_nodes / max(rays, 1), 'tris_per_ray': cnt.closest_tris / max(rays, 1),
                          'algorithmic_bytes_per_launch': alg_bytes_launch,
+                         'hbm_frac_measured': tc['hbm_frac_of_peak'] if tc else None,
+                         'valu_lane_util': tc['valu_lane_util'] if tc else None,
                          'traversal_share_of_step': (st.closest_ms + st.any_ms) / (dt * 1e3),
-                         'alone': alone_leg(alone, alg_bytes_launch) if alone is not None else None},
+                         'alone': alone_leg(alone, alg_bytes_launch) if alone is not None else None,
+                         'kernels': prof,
+                         'note': 'frac = algorithmic bytes (SURVEY.md 8d) over launch time: the 1 MB hierarchy is L2-resident, '
+                                 'so this is an L2-served rate; hbm_frac_measured is what reaches HBM (counters), and the '
+                                 'kernels are bound by vector-ALU issue at valu_lane_util (DESIGN.md section 3)'},
         }
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out['cpu_baseline'] = cpu_baseline(a.max_bounces)
+                out['cpu_baseline'] = cpu_baseline(a)
             except Exception as e:   # the baseline must never take the GPU number down with it
                 out['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(out), flush=True)

@@ -108,16 +108,26 @@ bool scene_is_lean(const Scene &scene, const ChannelsD &ch) {
            !scene.has_mipmaps && !scene.has_textures && !scene.has_vertex_colors;
 }
 
-// Launch `f`, or its lean specialisation when the scene allows it (see LeanStage in stages_fwd.h).
-template <class F> void launch_v(bool lean, int n, const F &f) {
-    if (lean) exec::launch(n, LeanStage<F>{f}); else exec::launch(n, f);
+// Which specialisation of the stages a scene can use (stages_fwd.h): kLean / kMid / kGeneral.
+constexpr int kGeneral = 0, kLean = 1, kMid = 2;
+int scene_kind(const Scene &scene, const ChannelsD &ch) {
+    if (scene_is_lean(scene, ch)) return kLean;
+    const CameraD &c = scene.d.cam;
+    if (scene.d.envmap == nullptr && c.kind == kCamPerspective && !c.distortion.defined && ch.radiance_only) return kMid;
+    return kGeneral;
+}
+// Launch `f`, or the specialisation of it that the scene allows (see LeanStage / MidStage in stages_fwd.h).
+template <class F> void launch_v(int kind, int n, const F &f) {
+    if (kind == kLean) exec::launch(n, LeanStage<F>{f});
+    else if (kind == kMid) exec::launch(n, MidStage<F>{f});
+    else exec::launch(n, f);
 }
 
 // One NEE + BSDF bounce over the live lanes of `v`; fills `vn` and the next live-lane list.
 int run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng_shift,
                const int *active, int num_active, const VSlice &v, const VSlice &vn,
                const Queues &q, const Sink &sink, int *next_active) {
-    const bool lean = scene_is_lean(scene, sink.ch);
+    const int lean = scene_kind(scene, sink.ch);
     launch_v(lean, num_active, BounceSample{scene.d, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
     // the shadow-ray and the continuation-ray queue are traced side by side: both kernels wait on dependent loads
     // with a fraction of their lanes active (profiles/r1_notes.md), so they fill each other's gaps
@@ -287,7 +297,7 @@ struct Backward {
     AdjState adj;
 
     ChannelsD ch;
-    bool lean = false;                 // the scene qualifies for the lean stage specialisations
+    int lean = kGeneral;               // which stage specialisation the scene qualifies for (kLean / kMid / kGeneral)
     uint64_t *pcg_edge = nullptr;      // PCG edge sampler: one state per slot (src/pathtracer.cpp:221-222)
     double *multipliers = nullptr;     // [2P x nd], primary-edge channel weights (non-radiance channels only)
 
@@ -295,7 +305,7 @@ struct Backward {
              const float *d_image_, float *screen_grad_, double weight_, int nd_, int radiance_dim_, const ChannelsD &ch_)
         : scene(scene_), opt(opt_), P(P_), B(B_), d_image(d_image_), screen_grad(screen_grad_), weight(weight_),
           nd(nd_), radiance_dim(radiance_dim_), grads(grads_), ch(ch_) {
-        lean = scene_is_lean(scene, ch);
+        lean = scene_kind(scene, ch);
         adj.n = P; adj.plain = 0;
         adj.thr = arena.get<double>((size_t)3 * P);
         adj.ray_dir = arena.get<double>((size_t)3 * P);
@@ -360,7 +370,7 @@ struct Backward {
     }
     SamplerD edge_rng_at(const SamplerD &rng_edge, int edim) const { SamplerD r = rng_edge; r.pcg_base = edim; return r; }
 
-    template <bool LEAN> void launch_pick_n(int need, int nN, const SecEdgeArgs &sa) {
+    template <int LEAN> void launch_pick_n(int need, int nN, const SecEdgeArgs &sa) {
         // order-free gather over the billboard hierarchy (SecEdgeGatherN), then the reference-order walk for the slots it
         // marked kPickOverflow (none in practice); RDR_PICKN_WALK=1 walks every slot instead (A/B measurements)
         static const bool walk_all = std::getenv("RDR_PICKN_WALK") != nullptr;
@@ -381,7 +391,8 @@ struct Backward {
         }
         const int only_overflow = gather ? 1 : 0;
         auto go = [&](auto walk) {
-            if (LEAN) exec::launch_persistent(nN, LeanWalk<decltype(walk)>{walk});
+            if (LEAN == kLean) exec::launch_persistent(nN, LeanWalk<decltype(walk)>{walk});
+            else if (LEAN == kMid) exec::launch_persistent(nN, MidWalk<decltype(walk)>{walk});
             else exec::launch_persistent(nN, walk);
         };
         if (need <= 24) go(SecEdgePickNWalk<24>{sa, nee_slots, sec_picks, only_overflow});
@@ -455,8 +466,9 @@ struct Backward {
                     if (side) setup_done.after(main_stream);
                     exec::StreamScope on(side ? exec::side_stream(1) : main_stream);
                     if (side) setup_done.gate(exec::ctx().stream);
-                    if (lean) launch_pick_n<true>(need, nN, sa);
-                    else launch_pick_n<false>(need, nN, sa);
+                    if (lean == kLean) launch_pick_n<kLean>(need, nN, sa);
+                    else if (lean == kMid) launch_pick_n<kMid>(need, nN, sa);
+                    else launch_pick_n<kGeneral>(need, nN, sa);
                     if (side) walk_done.after(exec::ctx().stream);
                 }
                 static const bool pickh_fused = std::getenv("RDR_PICKH_FUSED") != nullptr;     // A/B: the one-loop form
@@ -568,7 +580,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         pcg_main = arena.get<uint64_t>(P);
         exec::launch(P, PcgInit{pcg_main, pcg_stream_seed(opt)});
     }
-    const bool lean = scene_is_lean(scene, lay.ch);
+    const int lean = scene_kind(scene, lay.ch);
 
     // Everything one sample needs between its camera rays and its last gradient add.
     struct Worker {
@@ -626,7 +638,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     // needs its fp32 adds in sample order and stays on one stream.
     int workers = 1;
     // (the camera-vertex adjoint adds to the screen-gradient image with plain read-modify-writes: one worker then)
-    if (d_image != nullptr && image == nullptr && screen_gradient_image == nullptr && lean &&
+    if (d_image != nullptr && image == nullptr && screen_gradient_image == nullptr && lean == kLean &&
         opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on)
         workers = std::max(1, std::min(exec::sample_workers(P), opt.num_samples));
     Worker w0;

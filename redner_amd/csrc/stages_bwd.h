@@ -73,6 +73,7 @@ struct AdjBounceArgs {
 struct AdjBounceScatter {
     AdjBounceArgs a;
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; a.adj.plain = 1; }
+    RDR_FN void make_mid() { mid_scene(a.sc); a.nd = 3; a.radiance_dim = 0; }
     RDR_FN void operator()(int idx) const {
         const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v, &vn = a.vn; const AdjState &adj = a.adj;
         int p = a.active[idx];
@@ -184,6 +185,7 @@ RDR_FN void adj_record_add(const AdjState &adj, int p, V3 thr_bar, V3 in_dir_bar
 struct AdjBounceNee {
     AdjBounceArgs a;
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; a.adj.plain = 1; }
+    RDR_FN void make_mid() { mid_scene(a.sc); a.nd = 3; a.radiance_dim = 0; }
     // next-event estimation towards the environment light (src/path_contribution.cpp:295-338)
     RDR_FN void envmap_nee(int p, const LightDraw &ld) const {
         const SceneD &sc = a.sc; const GScene &g = a.g; const VSlice &v = a.v;
@@ -339,6 +341,7 @@ struct AdjPrimary {
     VSlice v0; const float *d_image; int nd, radiance_dim; double weight;
     AdjState adj; float *screen_grad; ChannelsD ch;
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v0); lean_channels(ch); nd = 3; radiance_dim = 0; adj.plain = 1; }
+    RDR_FN void make_mid() { mid_scene(sc); lean_channels(ch); nd = 3; radiance_dim = 0; }
     RDR_FN void operator()(int p) const {
         TriGrad tg = trigrad_zero();          // gradient of the first-hit triangle, scattered by the whole wave at the end
         int tg_shape = -1, tg_tri = -1;

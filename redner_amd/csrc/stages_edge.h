@@ -83,6 +83,7 @@ struct RecordHits {
 struct ShadeRecorded {
     SceneD sc; const int *active; VSlice v; Sink sink;
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); lean_channels(sink.ch); sink.multipliers = nullptr; }
+    RDR_FN void make_mid() { mid_scene(sc); lean_channels(sink.ch); sink.multipliers = nullptr; }
     RDR_FN void operator()(int idx) const {
         int p = active[idx];
         shade_first_hit(sc, sink, v, p, v.shape[p], v.tri[p]);
@@ -116,6 +117,7 @@ struct SamplePrimaryEdges {
     PrimaryEdgeRec *recs; VSlice v;       // lanes 2*slot, 2*slot+1
     double *multipliers;                  // [2P x nd] per-channel weights of the two rays, or null
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); multipliers = nullptr; nd = 3; radiance_dim = 0; }
+    RDR_FN void make_mid() { mid_scene(sc); multipliers = nullptr; nd = 3; radiance_dim = 0; }
     RDR_FN void operator()(int slot) const {
         int l0 = 2 * slot, l1 = 2 * slot + 1;
         if (multipliers) for (int d = 0; d < 2 * nd; ++d) multipliers[(size_t)nd * l0 + d] = 0;
@@ -210,6 +212,7 @@ struct SamplePrimaryEdges {
 struct PrimaryEdgeDerivatives {
     SceneD sc; GScene g; const PrimaryEdgeRec *recs; const double *edge_contrib; float *screen_grad;
     RDR_FN void make_lean() { lean_scene(sc); }
+    RDR_FN void make_mid() { mid_scene(sc); }
     RDR_FN void operator()(int slot) const {
         const PrimaryEdgeRec &rec = recs[slot];
         if (rec.edge.shape_id < 0) return;
@@ -755,6 +758,7 @@ constexpr int kDenseShapeTriangles = 512;
 struct SecEdgeSetup {
     SecEdgeArgs a; unsigned char *mode; SecondaryEdgeRec *recs; SecPick *picks; VSlice ev; double *edge_tmin;
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(ev); }
+    RDR_FN void make_mid() { mid_scene(a.sc); }
     RDR_FN void operator()(int idx) const {
         int p = a.active[idx];
         int l0 = 2 * idx, l1 = 2 * idx + 1;
@@ -788,6 +792,7 @@ struct KeepMode {
 struct SecEdgePickH {
     SecEdgeArgs a; const int *slots; SecPick *picks;
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void make_mid() { mid_scene(a.sc); }
     RDR_FN void operator()(int i) const {
         int idx = slots[i];
         SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
@@ -799,6 +804,7 @@ struct SecEdgePickH {
 template <bool PRELOAD> struct SecEdgePickH2 {        // the hierarchical pick with deferred leaf evaluation (pick_edge_hierarchical_deferred)
     SecEdgeArgs a; const int *slots; SecPick *picks; HLeaf *leaves, *spill; int n;      // leaves: kHSamples x n, spill: (kHSamples - kHStackLds) x n
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void make_mid() { mid_scene(a.sc); }
     RDR_FN void operator()(int i) const {
         int idx = slots[i];
         SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
@@ -854,6 +860,7 @@ template <int NS> struct SecEdgePickNWalk {
         RDR_WALK_STACK_MEMBER(int, stack, NS)
     };
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void make_mid() { mid_scene(a.sc); }
     RDR_DEV_FN bool begin(int i, State &st) const {
         st.idx = slots[i];
         if (only_overflow && picks[st.idx].eid != kPickOverflow) { st.idx = -1; st.sp = 0; st.selected = -1; return false; }
@@ -1047,6 +1054,7 @@ template <int NS> struct SecEdgeGatherN {
     SecEdgeArgs a; const int *slots; SecPick *picks; GatherCand *cands;     // cands: kGatherCands per list position
     GatherShared sh; int budget;                                            // budget: kGatherBudget (RDR_GATHER_BUDGET overrides)
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void make_mid() { mid_scene(a.sc); }
     RDR_FN void operator()(int i) const {
         const SceneD &sc = a.sc; const EdgeSceneD &es = a.es;
         const int idx = slots[i];
@@ -1094,6 +1102,7 @@ template <int NS> struct SecEdgeGatherN {
 template <int NS> struct SecEdgeGatherSub {
     SecEdgeArgs a; const int *slots; GatherShared sh;
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void make_mid() { mid_scene(a.sc); }
     RDR_FN void operator()(int j) const {
         const int n_work = sh.book->work_count < kGatherWorkCap ? sh.book->work_count : kGatherWorkCap;
         if (j >= n_work) return;
@@ -1111,6 +1120,7 @@ template <int NS> struct SecEdgeGatherSub {
 struct SecEdgeGatherReplay {
     SecEdgeArgs a; const int *slots; SecPick *picks; GatherShared sh;
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void make_mid() { mid_scene(a.sc); }
     RDR_FN void operator()(int h) const {
         const int n_heavy = sh.book->heavy_count < kGatherHeavyCap ? sh.book->heavy_count : kGatherHeavyCap;
         if (h >= n_heavy) return;
@@ -1127,6 +1137,7 @@ struct SecEdgeFinish {
     const float *d_image; int nd, radiance_dim;
     SecondaryEdgeRec *recs; VSlice ev; double *edge_tmin;
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(ev); nd = 3; radiance_dim = 0; }
+    RDR_FN void make_mid() { mid_scene(a.sc); nd = 3; radiance_dim = 0; }
     RDR_FN void operator()(int idx) const {
         if (mode[idx] == 0) return;
         SecPick pkd = picks[idx];
@@ -1221,6 +1232,7 @@ RDR_FN V3 isect_jacobian(V3 org, V3 dir, V3 p, V3 n, V3 l) {
 struct SecondaryEdgeWeights {
     SceneD sc; const SecondaryEdgeRec *recs; VSlice ev; double *hit_pos;   // hit_pos: 3 x n, stride ev.n
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(ev); }
+    RDR_FN void make_mid() { mid_scene(sc); }
     RDR_FN void scale_lane(const SecondaryEdgeRec &rec, int l) const {
         if (ev.shape[l] < 0) {
             if (sc.envmap != nullptr) {

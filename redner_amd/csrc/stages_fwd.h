@@ -103,10 +103,19 @@ struct Sink {
 // G-buffer channels -- and with them the registers (and scratch) those paths would pin.
 RDR_FN void lean_scene(SceneD &sc) { sc.envmap = nullptr; sc.cam.kind = kCamPerspective; sc.cam.distortion.defined = 0; sc.no_diffs = 1; sc.plain_materials = 1; }
 RDR_FN void lean_slice(VSlice &v) { v.rdiff = nullptr; v.erd = nullptr; }
+// "Mid" specialisation: pinhole camera without lens distortion, no environment light, radiance-only output -- but image
+// textures, mip levels (hence ray differentials), normal maps and vertex colours are all live.  What a textured scene lit by
+// area lights renders (BASELINE config 5's stand-in); the general stages carry three more camera models, the environment
+// estimators and the G-buffer code and need every register plus AGPR spills for it.
+RDR_FN void mid_scene(SceneD &sc) { sc.envmap = nullptr; sc.cam.kind = kCamPerspective; sc.cam.distortion.defined = 0; }
 RDR_FN void lean_channels(ChannelsD &ch) { ch.n = 1; ch.radiance_only = 1; ch.radiance_dim = 0; ch.radiance_off = 0; ch.nd = 3; }
 template <class Stage> struct LeanStage {
     Stage f;
     RDR_FN void operator()(int i) const { Stage g = f; g.make_lean(); RDR_INLINE_CALL g(i); }
+};
+template <class Stage> struct MidStage {
+    Stage f;
+    RDR_FN void operator()(int i) const { Stage g = f; g.make_mid(); RDR_INLINE_CALL g(i); }
 };
 // The same for resumable walks (exec::launch_persistent).
 template <class Walk> struct LeanWalk {
@@ -115,6 +124,13 @@ template <class Walk> struct LeanWalk {
     RDR_DEV_FN bool begin(int i, State &st) const { Walk g = w; g.make_lean(); return g.begin(i, st); }
     RDR_DEV_FN bool step(State &st) const { Walk g = w; g.make_lean(); return g.step(st); }
     RDR_DEV_FN void finish(State &st) const { Walk g = w; g.make_lean(); g.finish(st); }
+};
+template <class Walk> struct MidWalk {
+    Walk w;
+    using State = typename Walk::State;
+    RDR_DEV_FN bool begin(int i, State &st) const { Walk g = w; g.make_mid(); return g.begin(i, st); }
+    RDR_DEV_FN bool step(State &st) const { Walk g = w; g.make_mid(); return g.step(st); }
+    RDR_DEV_FN void finish(State &st) const { Walk g = w; g.make_mid(); g.finish(st); }
 };
 
 struct LightDraw { double light_sel, tri_sel; V2 uv; };
@@ -127,6 +143,7 @@ struct GenPrimary {
     SceneD sc; SamplerD rng; int sample_center;
     VSlice v0; rt::RayRec *q;
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v0); }
+    RDR_FN void make_mid() { mid_scene(sc); }
     RDR_FN void operator()(int p) const {
         V2 s = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
         RayDiff rd = raydiff_zero();
@@ -262,6 +279,7 @@ RDR_FN void shade_first_hit(const SceneD &sc, const Sink &sink, const VSlice &v,
 struct ShadePrimary {
     SceneD sc; const int *active; VSlice v; const rt::HitRec *hits; Sink sink;
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); lean_channels(sink.ch); sink.multipliers = nullptr; }
+    RDR_FN void make_mid() { mid_scene(sc); lean_channels(sink.ch); sink.multipliers = nullptr; }
     RDR_FN void operator()(int idx) const {
         int p = active ? active[idx] : idx;
         rt::HitRec h = hits[idx];
@@ -292,6 +310,7 @@ RDR_FN VertexCtx load_vertex(const SceneD &sc, const VSlice &v, int p) {
 struct BounceSample {
     SceneD sc; SamplerD rng; int dim, rng_shift;
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); lean_slice(vn); }
+    RDR_FN void make_mid() { mid_scene(sc); }
     const int *active; VSlice v, vn;
     rt::RayRec *q_nee, *q_bsdf;
     RDR_FN void operator()(int idx) const {
@@ -435,6 +454,7 @@ struct BounceContrib {
     const rt::HitRec *h_nee, *h_bsdf;
     Sink sink;
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); lean_slice(vn); lean_channels(sink.ch); }
+    RDR_FN void make_mid() { mid_scene(sc); lean_channels(sink.ch); }
     RDR_FN void operator()(int idx) const {
         int p = active[idx];
         int slot = p >> rng_shift;

@@ -114,6 +114,10 @@ CASES = {
     'textured_sphere_generic_48x48x4': ('textured_sphere', 48, 4, 1,
                                         ['radiance', 'barycentric_coordinates', 'generic_texture'],
                                         {'use_primary_edge_sampling': False, 'use_secondary_edge_sampling': False}),
+    # BASELINE config 5 stand-in (tests/scenes.py: living_room_standin) at parity-test size: textured two-sided bunny_box,
+    # max_bounces 6, camera-pose gradients; and its environment-map + SVBRDF-texture variant
+    'living_room_standin_40x40x2': ('living_room_standin', 40, 2, 6),
+    'living_room_standin_envmap_32x32x2': ('living_room_standin_envmap', 32, 2, 6),
     # render_albedo/render_g_buffer style: no radiance, no bounces (pyredner/render_utils.py)
     'textured_sphere_albedo_48x48x4': ('textured_sphere', 48, 4, 0,
                                        ['depth', 'shading_normal', 'diffuse_reflectance', 'uv']),

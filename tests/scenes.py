@@ -258,3 +258,50 @@ def misc_features(device, resolution=(40, 56), viewport=None):
 
 def misc_features_viewport(device, resolution=(40, 56)):
     return misc_features(device, resolution, viewport=(6, 10, 30, 44))
+
+
+def living_room_standin(device, resolution=(1024, 1024), envmap_variant=False):
+    """BASELINE config 5 stand-in.  tests/test_living_room.py downloads its meshes and textures at
+    run time and only tests/scenes/living-room-3-scene.xml is in the reference tree (area-lit, two-sided diffuse BSDFs
+    with bitmap textures), so the real scene cannot be built offline.  Stand-in, labelled as such everywhere: the
+    bunny_box geometry with every material two-sided and a seeded 512 x 512 procedural diffuse texture (8 x 8 box-blurred
+    noise in [0.1, 0.8], mip-mapped, uv_scale (2, 2)) on the walls and the bunny, the same rectangle area light,
+    max_bounces 6, gradients with respect to the camera pose (position / look_at / up), as the reference script optimises
+    (tests/test_living_room.py:30-34,45-47,72-75).  envmap_variant=True adds what BASELINE.json's wording asks for: a
+    256 x 512 environment map (vertical gradient + a 4 x 4-texel sun) and seeded specular / roughness textures."""
+    sc = bunny_box(device, resolution, vertex_grad=False)
+    z = np.load(os.path.join(GOLDEN, 'bunny_box_scene.npz'))
+    gen = torch.Generator().manual_seed(20240924)
+
+    def noise_tex(channels, lo, hi, size=512):
+        t = torch.rand(size, size, channels, generator=gen)
+        t = torch.nn.functional.avg_pool2d(t.permute(2, 0, 1)[None], 8, stride=1, padding=4)[0, :, :size, :size].permute(1, 2, 0)
+        t = (t - t.min()) / (t.max() - t.min())
+        return (lo + (hi - lo) * t).contiguous()
+
+    light_mat = sc.shapes[int(z['light0_shape_id'])].material_id
+    for i, m in enumerate(sc.materials):
+        m.two_sided = True
+        if i == light_mat:
+            continue
+        levels = [l.to(device) for l in _mip_chain(noise_tex(3, 0.1, 0.8))[:8]]      # the reference keeps at most 8 levels (src/texture.h:11)
+        m.diffuse_reflectance = Texture(levels, uv_scale=_t([2.0, 2.0], device))
+        if envmap_variant:
+            m.specular_reflectance = Texture([l.to(device) for l in _mip_chain(noise_tex(3, 0.0, 0.3))[:8]], uv_scale=_t([2.0, 2.0], device))
+            m.roughness = Texture([l.to(device) for l in _mip_chain(noise_tex(1, 0.05, 0.6))[:8]], uv_scale=_t([2.0, 2.0], device))
+    cam = sc.camera
+    for t in (cam.position, cam.look_at, cam.up):
+        t.requires_grad_(True)
+    if envmap_variant:
+        from redner_amd.render_pytorch import EnvironmentMap
+        h, w = 256, 512
+        yy = (torch.arange(h, dtype=torch.float32) + 0.5) / h
+        img = (0.2 + 1.3 * (1 - yy))[:, None, None].expand(h, w, 3).clone()
+        img[40:44, 300:304] = 4e4
+        env = EnvironmentMap(Texture([l.to(device) for l in _mip_chain(img)[:8]]))
+        sc = Scene(cam, sc.shapes, sc.materials, sc.area_lights, envmap=env)
+    return sc
+
+
+def living_room_standin_envmap(device, resolution=(1024, 1024)):
+    return living_room_standin(device, resolution, envmap_variant=True)
