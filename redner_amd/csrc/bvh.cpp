@@ -178,6 +178,30 @@ BvhHost build_box_bvh(const float *boxes, int n) {
     return bd.out;
 }
 
+// Node records in breadth-first order (siblings stay adjacent, the root stays 0): the first K records are then the top
+// levels of the hierarchy, which the traversal kernels stage into LDS.  Leaf slots (tris / ids) are untouched.
+static void reorder_breadth_first(BvhHost &h) {
+    const int n = (int)h.nodes.size();
+    if (n <= 1) return;
+    std::vector<Node> out((size_t)n);
+    std::vector<int> queue;           // old indices of inner nodes, in the order their children get their new places
+    queue.reserve((size_t)n / 2);
+    out[0] = h.nodes[0];
+    int next = 1;
+    std::vector<int> new_of_queue;    // new index of each queued node
+    if (h.nodes[0].b == 0) { queue.push_back(0); new_of_queue.push_back(0); }
+    for (size_t q = 0; q < queue.size(); ++q) {
+        const Node &old = h.nodes[queue[q]];
+        const int l = old.a, r = old.a + 1;
+        out[new_of_queue[q]].a = next;
+        out[next] = h.nodes[l]; out[next + 1] = h.nodes[r];
+        if (h.nodes[l].b == 0) { queue.push_back(l); new_of_queue.push_back(next); }
+        if (h.nodes[r].b == 0) { queue.push_back(r); new_of_queue.push_back(next + 1); }
+        next += 2;
+    }
+    h.nodes.swap(out);
+}
+
 BvhHost build_bvh(const std::vector<MeshView> &meshes) {
     Builder bd;
     std::vector<Prim> prims;
@@ -203,6 +227,7 @@ BvhHost build_bvh(const std::vector<MeshView> &meshes) {
     bd.prims = prims.data();
     bd.build_top(0, (int)prims.size(), 0);
     if (bd.out.depth + 2 > kTraverseStack) throw std::runtime_error("triangle hierarchy deeper than the traversal stack");
+    reorder_breadth_first(bd.out);
     return bd.out;
 }
 

@@ -44,20 +44,28 @@ static_assert(sizeof(RayRec) == 32 && sizeof(HitRec) == 8, "queue record sizes")
 // an LDS tile on the GPU); the builder rejects hierarchies deeper than that.
 constexpr int kTraverseStack = 40;
 // IDX: the stack's element type -- unsigned short when the hierarchy has < 65536 nodes (halves the LDS column).
-template <bool ANY, class IDX = int>
-RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], float tnear, float tfar,
-                          IDX *stack, int stride, Counters *cnt = nullptr) {
+// `fetch(i)` returns node record i by value.  The GPU kernels pass a functor that serves the first records from LDS (they
+// are in breadth-first order, so those are the upper levels of the hierarchy, staged once per workgroup: every ray starts
+// there and spends about half of its steps there) and the rest from global memory; the default reads bvh.nodes.
+struct FetchGlobal {
+    const Node *nodes;
+    RT_HD Node operator()(int i) const { return nodes[i]; }
+};
+template <bool ANY, class IDX, class Fetch>
+RT_HD inline Hit traverse_with(const BvhD &bvh, const float o[3], const float d[3], float tnear, float tfar,
+                               IDX *stack, int stride, Counters *cnt, const Fetch &fetch) {
     Hit best{tfar, -1, -1};
     if (bvh.num_nodes == 0) return best;
+#define RT_NODE_AT(i) fetch(i)
     const float inv[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};
     int sp = 0;
     float tn;
     unsigned long long nn = 1, nt = 0;
-    const Node &root = bvh.nodes[0];
+    const Node root = RT_NODE_AT(0);
     if (!ray_box(o, inv, tnear, tfar, root.lo, root.hi, &tn)) { if (cnt) { cnt->nodes += nn; } return best; }
     int cur = 0;
     for (;;) {
-        const Node &n = bvh.nodes[cur];
+        const Node n = RT_NODE_AT(cur);
         if (n.b > 0) {
             for (int k = 0; k < n.b; ++k) {
                 int slot = n.a + k;
@@ -71,7 +79,7 @@ RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], f
                 }
             }
         } else {
-            const Node &l = bvh.nodes[n.a], &r = bvh.nodes[n.a + 1];
+            const Node l = RT_NODE_AT(n.a), r = RT_NODE_AT(n.a + 1);
             nn += 2;
             // keep the window closed at best.t so equal-t candidates are still visited (tie-break)
             float lim = best.shape < 0 ? tfar : best.t * 1.0000004f + 1e-30f;
@@ -95,6 +103,12 @@ RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], f
     }
     if (cnt) { cnt->nodes += nn; cnt->tris += nt; }
     return best;
+#undef RT_NODE_AT
+}
+template <bool ANY, class IDX = int>
+RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], float tnear, float tfar,
+                          IDX *stack, int stride, Counters *cnt = nullptr) {
+    return traverse_with<ANY, IDX>(bvh, o, d, tnear, tfar, stack, stride, cnt, FetchGlobal{bvh.nodes});
 }
 
 } // namespace rt

@@ -177,12 +177,35 @@ CompactScratch &compact_scratch(int nblocks) {
 // STACK: entries of the per-lane LDS stack column.  The kernel waits on node fetches about two thirds of the
 // time (profiles/r1_notes.md), so waves per SIMD matter: 40 entries allow 4, 24 allow 6, 16 allow 8.  The host
 // picks the smallest instantiation that covers the scene's hierarchy depth.
-template <bool ANY, bool COUNT, int STACK, class IDX>
+constexpr int kTopNodes = 255;          // root + 127 sibling pairs (pairs start at odd indices, so none straddles): 8 KiB of LDS
+// node record i: from the workgroup's LDS copy of the top levels, else from global memory.  The LDS pointer keeps its address
+// space in its type: with two generic pointers the compiler merges the paths into a select + flat_load.
+typedef const __attribute__((address_space(3))) float *LdsFloats;
+struct FetchStaged {
+    const rt::Node *nodes; LdsFloats top; int ntop;
+    __device__ rt::Node operator()(int i) const {
+        rt::Node n;
+        if (i < ntop) {
+            LdsFloats p = top + 8 * i;
+            n.lo[0] = p[0]; n.lo[1] = p[1]; n.lo[2] = p[2]; n.a = __float_as_int(p[3]);
+            n.hi[0] = p[4]; n.hi[1] = p[5]; n.hi[2] = p[6]; n.b = __float_as_int(p[7]);
+        } else n = nodes[i];
+        return n;
+    }
+};
+template <bool ANY, bool COUNT, int STACK, class IDX, bool TOP>
 __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays,
                                                     rt::HitRec *__restrict__ hits, int n,
                                                     unsigned long long *counters) {
     __shared__ IDX stack_tile[STACK * 256];                   // per-lane stack columns (16-bit when the node count allows)
     IDX *stack = stack_tile + threadIdx.x;
+    // the top of the hierarchy (breadth-first order: the first records are its upper levels), staged once per workgroup
+    __shared__ rt::Node top[kTopNodes + 1];
+    const int ntop = TOP ? (bvh.num_nodes < kTopNodes ? bvh.num_nodes : kTopNodes) : 0;
+    if (TOP) {
+        if ((int)threadIdx.x < ntop) top[threadIdx.x] = bvh.nodes[threadIdx.x];
+        __syncthreads();
+    }
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     rt::RayRec r = rays[i];
@@ -191,11 +214,13 @@ __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayR
         float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
         if (COUNT) {
             rt::Counters c{0, 0};
-            h = rt::traverse<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, &c);
+            h = TOP ? rt::traverse_with<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, &c, FetchStaged{bvh.nodes, (LdsFloats)(const float *)top, ntop})
+                    : rt::traverse<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, &c);
             atomicAdd(&counters[0], c.nodes);
             atomicAdd(&counters[1], c.tris);
         } else {
-            h = rt::traverse<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, nullptr);
+            h = TOP ? rt::traverse_with<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, (rt::Counters *)nullptr, FetchStaged{bvh.nodes, (LdsFloats)(const float *)top, ntop})
+                    : rt::traverse<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, nullptr);
         }
     }
     hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};
@@ -276,12 +301,17 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n,
         p.any = any;
         check(hipEventRecord(p.a, s), "hipEventRecord");
     }
+    static const bool stage_top = std::getenv("RDR_TRACE_NO_LDS_TOP") == nullptr;        // A/B: node records from L1/L2 only
 #define RDR_TRACE_LAUNCH(ANY_, COUNT_, STACK_, ctr)                                                                          \
     do {                                                                                                                     \
-        if (bvh.num_nodes < 65536)                                                                                           \
-            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, unsigned short>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr); \
+        if (bvh.num_nodes < 65536 && stage_top)                                                                              \
+            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, unsigned short, true>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr); \
+        else if (bvh.num_nodes < 65536)                                                                                      \
+            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, unsigned short, false>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr); \
+        else if (stage_top)                                                                                                  \
+            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, int, true>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr);            \
         else                                                                                                                 \
-            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, int>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr);            \
+            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, int, false>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr);            \
     } while (0)
 #define RDR_TRACE_BY_STACK(ANY_, COUNT_, ctr)                                  \
     do {                                                                       \
