@@ -221,9 +221,20 @@ inline void set_replicas(size_t stride_doubles, int replicas) {
     check(hipStreamSynchronize(ctx().stream), "set_replicas sync");
 }
 
+// How many items a launch covers: `upper` is what the host knows (an upper bound, or the exact number when `dev` is null);
+// `dev` points at the exact number in device memory, written by the compaction that produced the list.  The per-depth
+// live-lane counts never come back to the host (src/pathtracer.cpp:292,590,833 read them after every stage): grids are sized by
+// the bound and every kernel trims itself.
+struct Count {
+    const int *dev; int upper;
+    Count(int n) : dev(nullptr), upper(n) {}
+    Count(const int *d, int u) : dev(d), upper(u) {}
+};
+
 template <class F>
-__global__ void __launch_bounds__(256) stage_kernel(F f, int n) {
+__global__ void __launch_bounds__(256) stage_kernel(F f, int n, const int *count) {
     int i = blockIdx.x * 256 + threadIdx.x;
+    if (count) { const int c = *count; n = c < n ? c : n; }
     // a stage body that is instantiated twice (plain + LeanStage) must still be inlined into each kernel:
     // an out-of-line call would pass the whole functor through scratch
     if (i < n) { RDR_INLINE_CALL f(i); }
@@ -239,7 +250,8 @@ __global__ void __launch_bounds__(256) stage_kernel(F f, int n) {
 constexpr int kRefillIdle = 16;
 constexpr int kWalkSteps = 16;
 template <class W>
-__global__ void __launch_bounds__(256) persistent_kernel(W w, int n, int *next_item) {
+__global__ void __launch_bounds__(256) persistent_kernel(W w, int n, const int *count, int *next_item) {
+    if (count) { const int c = *count; n = c < n ? c : n; }
     typename W::State st;
     bool busy = false;
     const int lane = threadIdx.x & 63;
@@ -268,18 +280,18 @@ __global__ void __launch_bounds__(256) persistent_kernel(W w, int n, int *next_i
 }
 int *persistent_counter();          // trace.hip: ring of zeroed ints, one per launch
 template <class W>
-inline void launch_persistent(int n, const W &w) {
-    if (n <= 0) return;
-    int blocks = std::min((n + 255) / 256, 256 * 8);
-    hipLaunchKernelGGL(persistent_kernel<W>, dim3(blocks), dim3(256), 0, ctx().stream, w, n, persistent_counter());
+inline void launch_persistent(Count n, const W &w) {
+    if (n.upper <= 0) return;
+    int blocks = std::min((n.upper + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(persistent_kernel<W>, dim3(blocks), dim3(256), 0, ctx().stream, w, n.upper, n.dev, persistent_counter());
     check(hipGetLastError(), "persistent launch");
 }
 
 template <class F>
-inline void launch(int n, const F &f) {
-    if (n <= 0) return;
-    int blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(stage_kernel<F>, dim3(blocks), dim3(256), 0, ctx().stream, f, n);
+inline void launch(Count n, const F &f) {
+    if (n.upper <= 0) return;
+    int blocks = (n.upper + 255) / 256;
+    hipLaunchKernelGGL(stage_kernel<F>, dim3(blocks), dim3(256), 0, ctx().stream, f, n.upper, n.dev);
     check(hipGetLastError(), "stage launch");
 }
 
@@ -306,8 +318,9 @@ __device__ inline int lane_prefix(unsigned long long ballot) {
 }
 
 template <class P>
-__global__ void __launch_bounds__(256) compact_count(const int *in, int n, P pred, int *block_counts) {
+__global__ void __launch_bounds__(256) compact_count(const int *in, int n, const int *count, P pred, int *block_counts) {
     __shared__ int wave_tot[4];
+    if (count) { const int c = *count; n = c < n ? c : n; }
     int base = blockIdx.x * kCompactTile;
     int cnt = 0;
     for (int it = 0; it < kCompactItems; ++it) {
@@ -322,8 +335,12 @@ __global__ void __launch_bounds__(256) compact_count(const int *in, int n, P pre
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
 }
 
-// exclusive scan of up to 256*16 workgroup counts by one workgroup
-static __global__ void __launch_bounds__(256) compact_scan(int *block_counts, int nblocks, int *total, int ticket) {
+// exclusive scan of up to 256*16 workgroup counts by one workgroup.  Publishes the number kept in `total_dev` (device memory,
+// for the kernels that consume the list; `base` is added: the list may continue an earlier one) and in `total` (mapped host
+// memory + ticket, for the rare host read).  `dyn` (optional): the edge sampler's dimension counter advances by `inc` when this
+// compaction closes a bounce that had lanes to run (src/pathtracer.cpp:590-706: `used += 7` per executed iteration).
+static __global__ void __launch_bounds__(256) compact_scan(int *block_counts, int nblocks, int *total, int ticket, int *total_dev,
+                                                           const int *base, int n_in, const int *count_in, int *dyn, int inc) {
     __shared__ int part[256];
     int per = (nblocks + 255) / 256;
     int beg = threadIdx.x * per, end = min(beg + per, nblocks);
@@ -334,7 +351,13 @@ static __global__ void __launch_bounds__(256) compact_scan(int *block_counts, in
     if (threadIdx.x == 0) {
         int run = 0;
         for (int i = 0; i < 256; ++i) { int t = part[i]; part[i] = run; run += t; }
-        total[0] = run;
+        const int all = run + (base ? *base : 0);
+        if (total_dev) *total_dev = all;
+        if (dyn) {
+            if (count_in) { const int c = *count_in; n_in = c < n_in ? c : n_in; }
+            if (n_in > 0) *dyn += inc;
+        }
+        total[0] = all;
         // the host spins on the ticket (mapped pinned memory): release at system scope publishes the count first
         __hip_atomic_store(total + 1, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -344,8 +367,11 @@ static __global__ void __launch_bounds__(256) compact_scan(int *block_counts, in
 }
 
 template <class P>
-__global__ void __launch_bounds__(256) compact_scatter(const int *in, int n, P pred, const int *block_offsets, int *out) {
+__global__ void __launch_bounds__(256) compact_scatter(const int *in, int n, const int *count, P pred, const int *block_offsets, int *out,
+                                                        const int *out_base) {
     __shared__ int wave_tot[kCompactItems][4];
+    if (count) { const int c = *count; n = c < n ? c : n; }
+    if (out_base) out += *out_base;
     int base = blockIdx.x * kCompactTile;
     int wave = threadIdx.x >> 6;
     int val[kCompactItems]; bool keep[kCompactItems]; int rank[kCompactItems];
@@ -373,23 +399,38 @@ __global__ void __launch_bounds__(256) compact_scatter(const int *in, int n, P p
 struct CompactScratch { int *block_counts = nullptr; int *total = nullptr; volatile int *total_host = nullptr; int capacity = 0; int ticket = 0; };
 CompactScratch &compact_scratch(int nblocks);
 
-// `out` must not alias `in`: a workgroup may scatter into a tile that an earlier-numbered
-// workgroup has not read yet.
+// `out` must not alias `in`: a workgroup may scatter into a tile that an earlier-numbered workgroup has not read yet.
+// compact_dev: nothing comes back to the host.  The kept items go to out[*append_at ...] (append_at null: out[0 ...]) and
+// the returned Count says how many items `out` now holds (in device memory) and what the host can bound it by.
+int *new_count();                    // trace.hip: a device int from a per-thread ring, for one compaction's result
 template <class P>
-inline int compact(const int *in, int n, int *out, const P &pred) {
-    if (n <= 0) return 0;
-    int nblocks = (n + kCompactTile - 1) / kCompactTile;
+inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const Count *append_at = nullptr, int *dyn = nullptr, int inc = 0) {
+    const int base_upper = append_at ? append_at->upper : 0;
+    if (n.upper <= 0) return append_at ? *append_at : Count(0);
+    int nblocks = (n.upper + kCompactTile - 1) / kCompactTile;
     if (nblocks > 256 * 4096) throw std::runtime_error("compact: input too large");
     CompactScratch &sc = compact_scratch(nblocks);
     hipStream_t st = ctx().stream;
-    hipLaunchKernelGGL(compact_count<P>, dim3(nblocks), dim3(256), 0, st, in, n, pred, sc.block_counts);
+    int *result = new_count();
+    const int *base = append_at ? append_at->dev : nullptr;
+    if (append_at && !append_at->dev) throw std::runtime_error("compact: append position must live on the device");
+    hipLaunchKernelGGL(compact_count<P>, dim3(nblocks), dim3(256), 0, st, in, n.upper, n.dev, pred, sc.block_counts);
     const int ticket = ++sc.ticket;
-    hipLaunchKernelGGL(compact_scan, dim3(1), dim3(256), 0, st, sc.block_counts, nblocks, sc.total, ticket);
-    hipLaunchKernelGGL(compact_scatter<P>, dim3(nblocks), dim3(256), 0, st, in, n, pred, sc.block_counts, out);
+    hipLaunchKernelGGL(compact_scan, dim3(1), dim3(256), 0, st, sc.block_counts, nblocks, sc.total, ticket, result, base, n.upper, n.dev, dyn, inc);
+    hipLaunchKernelGGL(compact_scatter<P>, dim3(nblocks), dim3(256), 0, st, in, n.upper, n.dev, pred, sc.block_counts, out, base);
     check(hipGetLastError(), "compact launch");
-    // The count is needed on the host (loop control, launch sizes).  Spinning on the ticket the scan kernel publishes
-    // costs a few microseconds; hipStreamSynchronize wakes the thread ~20 us after the stream drains and also waits
-    // for the scatter kernel, which the next launch is ordered behind anyway.
+    return Count(result, n.upper + base_upper);
+}
+// The host-visible form (loop decisions the host has to take itself): the same kernels, then a spin on the ticket the scan
+// kernel publishes in mapped pinned memory -- a few microseconds; hipStreamSynchronize wakes the thread ~20 us after the
+// stream drains and also waits for the scatter kernel, which the next launch is ordered behind anyway.
+template <class P>
+inline int compact(const int *in, int n, int *out, const P &pred) {
+    if (n <= 0) return 0;
+    CompactScratch &sc = compact_scratch((n + kCompactTile - 1) / kCompactTile);
+    (void)compact_dev(in, Count(n), out, pred);
+    hipStream_t st = ctx().stream;
+    const int ticket = sc.ticket;
     for (long spins = 0; sc.total_host[1] != ticket; ++spins) {
         __builtin_ia32_pause();
         if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(st) != hipErrorNotReady) {   // finished or failed without publishing
@@ -400,6 +441,24 @@ inline int compact(const int *in, int n, int *out, const P &pred) {
     std::atomic_thread_fence(std::memory_order_acquire);
     return sc.total_host[0];
 }
+// k times a device-side count (the two lanes per slot of an edge pass), as a new device-side count.
+static __global__ void scale_count_kernel(const int *src, int upper, int k, int *dst) {
+    const int c = *src;
+    *dst = k * (c < upper ? c : upper);
+}
+inline Count scaled_count(Count c, int k) {
+    if (!c.dev) return Count(k * c.upper);
+    int *dst = new_count();
+    hipLaunchKernelGGL(scale_count_kernel, dim3(1), dim3(1), 0, ctx().stream, c.dev, c.upper, k, dst);
+    return Count(dst, k * c.upper);
+}
+// A count the host needs after all (a skip decision, a debug dump): synchronise and read it.
+inline int read_count(Count c) {
+    if (!c.dev) return c.upper;
+    int v = 0;
+    download(&v, c.dev, sizeof(int));
+    return v < c.upper ? v : c.upper;
+}
 
 // ---- traversal kernels (trace.hip) --------------------------------------------------------------
 struct TraceStats {
@@ -409,7 +468,7 @@ struct TraceStats {
 };
 TraceStats &trace_stats();
 void trace_stats_collect();     // folds pending hipEvent pairs / device counters into trace_stats()
-void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n, bool any);
+void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count n, bool any);
 // Host threads render() may drive samples from (RDR_WORKERS=1 turns the second one off).
 inline int sample_workers(int lanes) {
     static const int forced = [] { const char *e = std::getenv("RDR_WORKERS"); return e ? std::min(1 + kMaxHelpers, std::max(1, std::atoi(e))) : 0; }();

@@ -195,8 +195,10 @@ struct FetchStaged {
 };
 template <bool ANY, bool COUNT, int STACK, class IDX, bool TOP>
 __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays,
-                                                    rt::HitRec *__restrict__ hits, int n,
+                                                    rt::HitRec *__restrict__ hits, int n, const int *count,
                                                     unsigned long long *counters) {
+    if (count) { const int c = *count; n = c < n ? c : n; }
+    if ((int)(blockIdx.x * 256) >= n) return;                 // the whole workgroup lies beyond the queue (grids are sized by an upper bound)
     __shared__ IDX stack_tile[STACK * 256];                   // per-lane stack columns (16-bit when the node count allows)
     IDX *stack = stack_tile + threadIdx.x;
     // the top of the hierarchy (breadth-first order: the first records are its upper levels), staged once per workgroup
@@ -210,6 +212,7 @@ __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayR
     if (i >= n) return;
     rt::RayRec r = rays[i];
     rt::Hit h{0.f, -1, -1};
+    if (COUNT) atomicAdd(&counters[ANY ? 3 : 4], 1ull);        // queue slots (base is g_counters, +2 for any-hit): [4] / [5]
     if (!(r.tmax < 0.f)) {
         float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
         if (COUNT) {
@@ -233,6 +236,20 @@ hipStream_t side_stream(int k) {
     hipStream_t &s = streams[dev & 15][k & 1];
     if (!s) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
     return s;
+}
+
+int *new_count() {
+    static thread_local int *rings[16] = {};
+    static thread_local int slots[16] = {};
+    constexpr int kRing = 8192;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int *&ring = rings[dev & 15];
+    int &slot = slots[dev & 15];
+    if (!ring) ring = (int *)dmalloc(sizeof(int) * kRing);
+    int *p = ring + slot;
+    slot = (slot + 1) % kRing;
+    return p;
 }
 
 int *persistent_counter() {
@@ -282,15 +299,18 @@ void trace_stats_collect() {           // call between render() calls: every wor
         g_pending.clear();
     }
     if (g_counters) {
-        unsigned long long c[4] = {0, 0, 0, 0};
+        unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
         download(c, g_counters, sizeof(c));
         st.nodes[0] += c[0]; st.tris[0] += c[1]; st.nodes[1] += c[2]; st.tris[1] += c[3];
+        st.closest_rays += c[4]; st.any_rays += c[5];          // queue lengths live on the device: the counting kernels tally them
         zero(g_counters, sizeof(c));
         sync();
     }
 }
 
-void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n, bool any) {
+void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count cnt, bool any) {
+    const int n = cnt.upper;
+    const int *n_dev = cnt.dev;
     if (n <= 0) return;
     TraceStats &st = trace_stats();
     hipStream_t s = ctx().stream;
@@ -301,17 +321,20 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n,
         p.any = any;
         check(hipEventRecord(p.a, s), "hipEventRecord");
     }
-    static const bool stage_top = std::getenv("RDR_TRACE_NO_LDS_TOP") == nullptr;        // A/B: node records from L1/L2 only
+    // Staging pays on big queues (closest-hit 0.330 -> 0.321 ms per 956 k rays); on a 256 x 256 frame the 8 KiB copy + barrier per
+    // 256 rays costs more than the L1-hot top levels save (optimisation-loop iteration +2 ms).  RDR_TRACE_NO_LDS_TOP=1: never.
+    static const bool stage_allowed = std::getenv("RDR_TRACE_NO_LDS_TOP") == nullptr;
+    const bool stage_top = stage_allowed && n >= (1 << 18);
 #define RDR_TRACE_LAUNCH(ANY_, COUNT_, STACK_, ctr)                                                                          \
     do {                                                                                                                     \
         if (bvh.num_nodes < 65536 && stage_top)                                                                              \
-            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, unsigned short, true>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr); \
+            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, unsigned short, true>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, ctr); \
         else if (bvh.num_nodes < 65536)                                                                                      \
-            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, unsigned short, false>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr); \
+            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, unsigned short, false>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, ctr); \
         else if (stage_top)                                                                                                  \
-            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, int, true>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr);            \
+            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, int, true>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, ctr);            \
         else                                                                                                                 \
-            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, int, false>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, ctr);            \
+            hipLaunchKernelGGL((trace_kernel<ANY_, COUNT_, STACK_, int, false>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, ctr);            \
     } while (0)
 #define RDR_TRACE_BY_STACK(ANY_, COUNT_, ctr)                                  \
     do {                                                                       \
@@ -324,10 +347,11 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n,
         {
             std::lock_guard<std::mutex> lk(g_stats_lock);
             if (!g_counters) {
-                g_counters = (unsigned long long *)dmalloc(32);
-                check(hipMemset(g_counters, 0, 32), "hipMemset");        // synchronous: another worker's launch may be next
+                g_counters = (unsigned long long *)dmalloc(48);
+                check(hipMemset(g_counters, 0, 48), "hipMemset");        // synchronous: another worker's launch may be next
             }
         }
+        // counters: {nodes, tris} of this query type at [0, 1], its ray tally at [4] (closest) / [3] relative to base + 2 (any)
         if (any) RDR_TRACE_BY_STACK(true, true, g_counters + 2);
         else RDR_TRACE_BY_STACK(false, true, g_counters);
     } else {
@@ -343,7 +367,7 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n,
     std::lock_guard<std::mutex> lk(g_stats_lock);
     if (st.timing) g_pending.push_back(p);
     (any ? st.any_launches : st.closest_launches)++;
-    (any ? st.any_rays : st.closest_rays) += (uint64_t)n;
+    if (!st.counting) (any ? st.any_rays : st.closest_rays) += (uint64_t)n;     // an upper bound; exact tallies come from the counting kernels
 }
 
 } // namespace exec

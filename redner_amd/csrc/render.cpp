@@ -117,16 +117,17 @@ int scene_kind(const Scene &scene, const ChannelsD &ch) {
     return kGeneral;
 }
 // Launch `f`, or the specialisation of it that the scene allows (see LeanStage / MidStage in stages_fwd.h).
-template <class F> void launch_v(int kind, int n, const F &f) {
+template <class F> void launch_v(int kind, exec::Count n, const F &f) {
     if (kind == kLean) exec::launch(n, LeanStage<F>{f});
     else if (kind == kMid) exec::launch(n, MidStage<F>{f});
     else exec::launch(n, f);
 }
 
-// One NEE + BSDF bounce over the live lanes of `v`; fills `vn` and the next live-lane list.
-int run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng_shift,
-               const int *active, int num_active, const VSlice &v, const VSlice &vn,
-               const Queues &q, const Sink &sink, int *next_active) {
+// One NEE + BSDF bounce over the live lanes of `v`; fills `vn` and the next live-lane list.  The lane count stays on the
+// device (exec::Count); `dyn` / `dyn_inc`: the dimension counter that advances if this bounce had lanes to run.
+exec::Count run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng_shift,
+                       const int *active, exec::Count num_active, const VSlice &v, const VSlice &vn,
+                       const Queues &q, const Sink &sink, int *next_active, int *dyn = nullptr, int dyn_inc = 0) {
     const int lean = scene_kind(scene, sink.ch);
     launch_v(lean, num_active, BounceSample{scene.d, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
     // the shadow-ray and the continuation-ray queue are traced side by side: both kernels wait on dependent loads
@@ -152,7 +153,7 @@ int run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng_shift,
         exec::trace(scene.bvh, q.bsdf, q.h_bsdf, num_active, false);
     }
     launch_v(lean, num_active, BounceContrib{scene.d, rng, dim, rng_shift, active, v, vn, q.h_nee, q.h_bsdf, sink});
-    return exec::compact(active, num_active, next_active, KeepHit{vn.shape});
+    return exec::compact_dev(active, num_active, next_active, KeepHit{vn.shape}, nullptr, dyn, dyn_inc);
 }
 
 // ---- gradient accumulators ------------------------------------------------------------------------
@@ -299,6 +300,7 @@ struct Backward {
     ChannelsD ch;
     int lean = kGeneral;               // which stage specialisation the scene qualifies for (kLean / kMid / kGeneral)
     uint64_t *pcg_edge = nullptr;      // PCG edge sampler: one state per slot (src/pathtracer.cpp:221-222)
+    int *edge_dyn = nullptr;           // device-side part of the edge sampler's dimension counter (see run_sample)
     double *multipliers = nullptr;     // [2P x nd], primary-edge channel weights (non-radiance channels only)
 
     Backward(const Scene &scene_, const rdr_render_options &opt_, GradStore &grads_, int P_, int B_,
@@ -313,6 +315,7 @@ struct Backward {
         const bool edges_on = scene.edges && scene.edges->d.num_edges > 0 &&
                               (scene.use_primary_edges || scene.use_secondary_edges);
         if (edges_on) {
+            edge_dyn = arena.get<int>(1);
             const int L = 2 * P;                      // edge lanes: two rays per sample slot
             ea = make_slice(arena, L, false);
             eb = make_slice(arena, L, false);
@@ -362,15 +365,16 @@ struct Backward {
     SecPick *sec_picks = nullptr;
     unsigned char *sec_mode = nullptr;
 
-    // Path-trace the live edge lanes to the end, starting with `n_act` lanes listed in elist[1]
-    // whose current vertex is in `ea`.  Returns the number of Sobol' dimensions consumed.
-    // PCG edge sampler: the states of slots [0, n) move on by `count` numbers (one next_*_samples call group)
-    void edge_rng_consumed(int n, int count) {
-        if (pcg_edge) exec::launch(n, PcgAdvance{pcg_edge, count});
+    // PCG edge sampler: the states of slots [0, n) move on by `count` numbers (one next_*_samples call group); `gate`: only
+    // if that device-side lane count is positive (a bounce without lanes draws nothing)
+    void edge_rng_consumed(exec::Count n, int count, const int *gate = nullptr) {
+        if (pcg_edge) exec::launch(n, PcgAdvance{pcg_edge, count, nullptr, gate});
     }
-    SamplerD edge_rng_at(const SamplerD &rng_edge, int edim) const { SamplerD r = rng_edge; r.pcg_base = edim; return r; }
+    void edge_rng_consumed_n(exec::Count n, int count) { edge_rng_consumed(n, count, nullptr); }
+    // The edge sampler at dimension `edim` + what the device-side counter holds (see SamplerD::dyn)
+    SamplerD edge_rng_at(const SamplerD &rng_edge, int edim) const { SamplerD r = rng_edge; r.pcg_base = edim; r.dyn = edge_dyn; return r; }
 
-    template <int LEAN> void launch_pick_n(int need, int nN, const SecEdgeArgs &sa) {
+    template <int LEAN> void launch_pick_n(int need, exec::Count nN, const SecEdgeArgs &sa) {
         // order-free gather over the billboard hierarchy (SecEdgeGatherN), then the reference-order walk for the slots it
         // marked kPickOverflow (none in practice); RDR_PICKN_WALK=1 walks every slot instead (A/B measurements)
         static const bool walk_all = std::getenv("RDR_PICKN_WALK") != nullptr;
@@ -401,41 +405,55 @@ struct Backward {
         else go(SecEdgePickNWalk<64>{sa, nee_slots, sec_picks, only_overflow});
     }
 
-    int trace_edge_paths(const SamplerD &rng_edge, int edim, int n_act, int n_slots, int first_depth, const Queues &q,
-                         const Sink &sink, bool need_lights) {
-        int used = 0;
+    // Path-trace the live edge lanes to the end, starting with `n_act` lanes listed in elist[1] whose current vertex is in
+    // `ea`.  The reference runs a bounce while lanes are left and advances the edge sampler by 7 dimensions per bounce it ran
+    // (src/pathtracer.cpp:590-706); here every bounce up to max_bounces is queued -- one without lanes does nothing -- and the
+    // device-side counter advances in the compaction that closes a bounce which had lanes (`edim` is the host-known part).
+    void trace_edge_paths(const SamplerD &rng_edge, int edim, exec::Count n_act, exec::Count n_slots, int first_depth, const Queues &q,
+                          const Sink &sink, bool need_lights) {
         const bool has_lights = scene.d.num_lights > 0;
+        if (need_lights && !has_lights) return;
         int cur = 1;
-        for (int depth = first_depth, k = 0; depth < B && n_act > 0 && (!need_lights || has_lights); ++depth, ++k) {
+        for (int depth = first_depth, k = 0; depth < B && n_act.upper > 0; ++depth, ++k) {
             const VSlice &m = (k % 2 == 0) ? ea : eb;
             const VSlice &nx = (k % 2 == 0) ? eb : ea;
             int nxt = (cur == 1) ? 2 : 1;
-            n_act = run_bounce(scene, edge_rng_at(rng_edge, edim + used), edim + used, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt]);
-            edge_rng_consumed(n_slots, 7);
+            exec::Count next = run_bounce(scene, edge_rng_at(rng_edge, edim), edim, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt], edge_dyn, 7);
+            edge_rng_consumed(n_slots, 7, n_act.dev);
+            n_act = next;
             cur = nxt;
-            used += 7;
         }
-        return used;
     }
 
-    void run_sample(int sample_id, const SamplerD &main_rng, std::vector<VSlice> &vs, int *active, std::vector<int> &num_active, const Queues &q) {
+    void run_sample(int sample_id, const SamplerD &main_rng, std::vector<VSlice> &vs, int *active, std::vector<exec::Count> &num_active, const Queues &q) {
         SamplerD rng = main_rng;
         SamplerD rng_edge{scene.sobol_table, opt.seed + 131071U, sample_id, pcg_edge, 0};   // src/pathtracer.cpp:221-227
         const bool has_lights = scene.d.num_lights > 0;
         const bool edges_on = prim_recs != nullptr;
         Sink esink{nullptr, edge_contrib, nd, radiance_dim, weight, ch, nullptr};
         Sink psink{nullptr, edge_contrib, nd, radiance_dim, weight, ch, multipliers};
+        // Edge-sampler dimension = edim (what the host can count: 4 per secondary pass, 2 for the primary pass) + *edge_dyn
+        // (7 per bounce of an edge sub-path that had lanes to run -- a device-side count, see trace_edge_paths)
         int edim = 0;
+        if (edge_dyn) exec::zero(edge_dyn, sizeof(int));
         exec::zero(adj.thr, sizeof(double) * 3 * P);
         exec::zero(adj.ray_dir, sizeof(double) * 3 * P);
         exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * P);
         const int dim0 = opt.sample_pixel_center ? 0 : 2;
         for (int d = B - 1; d >= 0 && has_lights; --d) {
-            const int nA = num_active[d];
-            if (nA <= 0) continue;
+            const exec::Count nA = num_active[d];
+            if (nA.upper <= 0) continue;
             const int *act = active + (size_t)d * P;
             AdjBounceArgs ba{scene.d, grads.g, rng, dim0 + 7 * d, act, vs[d], vs[d + 1], d_image, nd, radiance_dim, weight, adj};
-            const bool with_edges = edges_on && scene.use_secondary_edges;
+            bool with_edges = edges_on && scene.use_secondary_edges;
+            if (with_edges && d > 0 && scene.diffuse_only) {
+                // Every material is purely diffuse: a path that has left its first vertex carries min_roughness 1 (src/material.h:750-752)
+                // and the sampler returns at once for every slot (src/edge.cpp:1396-1401).  Nothing of the pass remains but its
+                // sampler bookkeeping: four numbers drawn per slot.
+                with_edges = false;
+                edim += 4;
+                edge_rng_consumed_n(nA, 4);
+            }
             // The bounce adjoint of this depth, the hierarchical edge pick and the NEE-mode edge-pick walk do not depend on
             // each other (the edge pass touches the adjoint records only in SecondaryEdgeDerivatives); each of them keeps a
             // fraction of the lanes busy, so they run on three streams and are joined before the records are needed.
@@ -455,14 +473,14 @@ struct Backward {
             if (with_edges) {
                 // ---- secondary (shadow / inter-reflection) edges at this vertex, :500-706 ----
                 const EdgeSceneD &es = scene.edges->d;
-                const int lanes = 2 * nA;
+                const exec::Count lanes = exec::scaled_count(nA, 2);
                 SecEdgeArgs sa{scene.d, es, rng, dim0 + 7 * d, edge_rng_at(rng_edge, edim), edim, act, vs[d]};
                 launch_v(lean, nA, SecEdgeSetup{sa, sec_mode, sec_recs, sec_picks, ea, edge_tmin});
-                int nH = exec::compact((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 1});
-                int nN = exec::compact((const int *)nullptr, nA, nee_slots, KeepMode{sec_mode, 2});
-                nN += exec::compact((const int *)nullptr, nA, nee_slots + nN, KeepMode{sec_mode, 3});     // dense-shape slots after the others
+                const exec::Count nH = exec::compact_dev((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 1});
+                const exec::Count nN2 = exec::compact_dev((const int *)nullptr, nA, nee_slots, KeepMode{sec_mode, 2});
+                const exec::Count nN = exec::compact_dev((const int *)nullptr, nA, nee_slots, KeepMode{sec_mode, 3}, &nN2);   // dense-shape slots after the others
                 const int need = es.max_stack;
-                {   // NEE-mode pick: persistent waves (walk lengths: median 20, p95 640 steps)
+                {   // NEE-mode pick beside the hierarchical pick
                     if (side) setup_done.after(main_stream);
                     exec::StreamScope on(side ? exec::side_stream(1) : main_stream);
                     if (side) setup_done.gate(exec::ctx().stream);
@@ -475,34 +493,26 @@ struct Backward {
                 if (pickh_fused) launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
                 else {
                     static const bool lazy = std::getenv("RDR_PICKH_LAZY") != nullptr;     // A/B: per-field node loads
-                    if (lazy) launch_v(lean, nH, SecEdgePickH2<false>{sa, elist[0], sec_picks, h_leaves, h_spill, nH});
-                    else launch_v(lean, nH, SecEdgePickH2<true>{sa, elist[0], sec_picks, h_leaves, h_spill, nH});
+                    if (lazy) launch_v(lean, nH, SecEdgePickH2<false>{sa, elist[0], sec_picks, h_leaves, h_spill, nH.upper});
+                    else launch_v(lean, nH, SecEdgePickH2<true>{sa, elist[0], sec_picks, h_leaves, h_spill, nH.upper});
                 }
                 if (side) walk_done.gate(main_stream);
-                if (nH == 0 && nN == 0) {
-                    // no slot samples an edge here (typically: every path already passed a diffuse vertex,
-                    // src/edge.cpp:1396-1401); only the sampler bookkeeping of the skipped stages remains
-                    edim += 4;
-                    edge_rng_consumed(nA, 4);
-                    if (side) adjoint_done.gate(main_stream);
-                    continue;
-                }
-                debug_dump("sec_mode", sample_id, d, sec_mode, (size_t)nA);
-                debug_dump("sec_picks", sample_id, d, sec_picks, sizeof(SecPick) * (size_t)nA);
+                debug_dump("sec_mode", sample_id, d, sec_mode, (size_t)nA.upper);
+                debug_dump("sec_picks", sample_id, d, sec_picks, sizeof(SecPick) * (size_t)nA.upper);
                 launch_v(lean, nA, SecEdgeFinish{sa, sec_mode, sec_picks, d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});
-                debug_dump("sec_recs", sample_id, d, sec_recs, sizeof(SecondaryEdgeRec) * (size_t)nA);
+                debug_dump("sec_recs", sample_id, d, sec_recs, sizeof(SecondaryEdgeRec) * (size_t)nA.upper);
                 edim += 4;
-                edge_rng_consumed(nA, 4);
-                int n0 = exec::compact((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
+                edge_rng_consumed_n(nA, 4);
+                const exec::Count n0 = exec::compact_dev((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
                 exec::launch(n0, QueueRays{elist[0], ea, edge_tmin, q.bsdf});
                 exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
                 exec::launch(n0, RecordHits{elist[0], ea, q.h_bsdf});
                 if (ea.erd) exec::launch(n0, MirrorSurfDiff{scene.d, elist[0], ea});
                 launch_v(lean, nA, SecondaryEdgeWeights{scene.d, sec_recs, ea, hit_pos});
-                exec::zero(edge_contrib, sizeof(double) * lanes);
+                exec::zero(edge_contrib, sizeof(double) * lanes.upper);
                 launch_v(lean, n0, ShadeRecorded{scene.d, elist[0], ea, esink});
-                int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
-                edim += trace_edge_paths(rng_edge, edim, n1, nA, d + 1, q, esink, false);
+                const exec::Count n1 = exec::compact_dev(elist[0], n0, elist[1], KeepHit{ea.shape});
+                trace_edge_paths(rng_edge, edim, n1, nA, d + 1, q, esink, false);
                 if (side) adjoint_done.gate(main_stream);          // the only stage of the edge pass that touches the adjoint records
                 exec::launch(nA, SecondaryEdgeDerivatives{scene.d, grads.g, act, sec_recs, hit_pos, ea.n, edge_contrib, adj});
             }
@@ -528,15 +538,15 @@ struct Backward {
             exec::zero(edge_contrib, sizeof(double) * lanes);
             launch_v(lean, P, SamplePrimaryEdges{scene.d, es, edge_rng_at(rng_edge, edim), edim, d_image, nd, radiance_dim, prim_recs, ea, multipliers});
             edim += 2;
-            edge_rng_consumed(P, 2);
-            int n0 = exec::compact((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
+            edge_rng_consumed_n(P, 2);
+            const exec::Count n0 = exec::compact_dev((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
             if (ea.erd) exec::launch(n0, LoadLaneDiff{elist[0], ea});
             exec::launch(n0, QueueRays{elist[0], ea, nullptr, q.bsdf});
             exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
             launch_v(lean, n0, ShadePrimary{scene.d, elist[0], ea, q.h_bsdf, psink});
             if (ea.erd) exec::launch(n0, MirrorSurfDiff{scene.d, elist[0], ea});
-            int n1 = exec::compact(elist[0], n0, elist[1], KeepHit{ea.shape});
-            edim += trace_edge_paths(rng_edge, edim, n1, P, 0, q, esink, true);
+            const exec::Count n1 = exec::compact_dev(elist[0], n0, elist[1], KeepHit{ea.shape});
+            trace_edge_paths(rng_edge, edim, n1, P, 0, q, esink, true);
             launch_v(lean, P, PrimaryEdgeDerivatives{scene.d, grads.g, prim_recs, edge_contrib, screen_grad});
         }
         if (adj_primary_aside) adjoint_done.gate(exec::ctx().stream);      // the next sample clears the adjoint records
@@ -588,7 +598,8 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         std::vector<VSlice> vs;
         int *active = nullptr;
         Queues q;
-        std::vector<int> num_active;
+        std::vector<exec::Count> num_active;   // live lanes per depth: device-side counts (upper bound P)
+        int *main_dyn = nullptr;               // PCG only: 7 x (bounces that had lanes), counted on the device
         std::unique_ptr<Backward> bwd;
     };
     auto make_worker = [&](Worker &w) {
@@ -597,7 +608,8 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         w.active = w.arena.get<int>((size_t)(B + 1) * P);
         w.q.nee = w.arena.get<rt::RayRec>((size_t)2 * P); w.q.bsdf = w.arena.get<rt::RayRec>((size_t)2 * P);
         w.q.h_nee = w.arena.get<rt::HitRec>((size_t)2 * P); w.q.h_bsdf = w.arena.get<rt::HitRec>((size_t)2 * P);
-        w.num_active.assign(B + 2, 0);
+        w.num_active.assign(B + 2, exec::Count(0));
+        if (pcg_main) w.main_dyn = w.arena.get<int>(1);
         if (d_image) w.bwd.reset(new Backward(scene, opt, *grads, P, B, d_image, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch));
     };
     // samples first, first + stride, ... on the calling thread's stream
@@ -605,7 +617,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         std::vector<VSlice> &vs = w.vs;
         int *active = w.active;
         const Queues &q = w.q;
-        std::vector<int> &num_active = w.num_active;
+        std::vector<exec::Count> &num_active = w.num_active;
         for (int s = first; s < opt.num_samples; s += stride) {
             const int sample_id = opt.sample_offset + s;
             SamplerD rng{scene.sobol_table, opt.seed, sample_id, pcg_main, 0};
@@ -615,19 +627,23 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
             launch_v(lean, P, GenPrimary{scene.d, rng, opt.sample_pixel_center, vs[0], q.bsdf});
             exec::trace(scene.bvh, q.bsdf, q.h_bsdf, P, false);
             launch_v(lean, P, ShadePrimary{scene.d, nullptr, vs[0], q.h_bsdf, sink});
-            std::fill(num_active.begin(), num_active.end(), 0);
-            num_active[0] = exec::compact((const int *)nullptr, P, active, KeepHit{vs[0].shape});
+            std::fill(num_active.begin(), num_active.end(), exec::Count(0));
+            num_active[0] = exec::compact_dev((const int *)nullptr, P, active, KeepHit{vs[0].shape});
+            if (w.main_dyn) exec::zero(w.main_dyn, sizeof(int));
 
-            // ---- bounces (src/pathtracer.cpp:292-390) ----
+            // ---- bounces (src/pathtracer.cpp:292-390).  The reference stops when no lane is left; here every bounce is
+            // queued and one without lanes does nothing (the live-lane counts stay on the device, exec::Count) ----
             int dim = opt.sample_pixel_center ? 0 : 2;
-            for (int d = 0; d < B && num_active[d] > 0 && has_lights; ++d) {
+            const int dim_first = dim;
+            for (int d = 0; d < B && num_active[d].upper > 0 && has_lights; ++d) {
                 num_active[d + 1] = run_bounce(scene, rng, dim, 0, active + (size_t)d * P, num_active[d],
-                                               vs[d], vs[d + 1], q, sink, active + (size_t)(d + 1) * P);
+                                               vs[d], vs[d + 1], q, sink, active + (size_t)(d + 1) * P, w.main_dyn, 7);
                 dim += 7;
             }
 
             if (w.bwd) w.bwd->run_sample(sample_id, rng, vs, active, num_active, q);
-            if (pcg_main) exec::launch(P, PcgAdvance{pcg_main, dim});     // every slot drew `dim` numbers this sample
+            // every slot drew dim_first + 7 x (bounces that ran) numbers this sample
+            if (pcg_main) exec::launch(P, PcgAdvance{pcg_main, dim_first, w.main_dyn, nullptr});
         }
     };
 

@@ -173,6 +173,29 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         if (o.generic.num_levels > 0)
             s.max_generic_texture_dimension = std::max(s.max_generic_texture_dimension, o.generic.channels);
     }
+    {   // Can a path that has bounced once still be specular enough for secondary edge sampling (min_roughness <= 0.01,
+        // src/edge.cpp:1396-1401)?  Not if every material has a constant specular reflectance of exactly zero (the sampler then
+        // always takes the Lambert lobe, which sets min_roughness to 1) and a constant roughness well above the threshold (for the
+        // black-material corner where it takes the other branch, src/material.h:704-811).
+        std::vector<float> vals((size_t)4 * num_materials, 1.f);
+        std::vector<exec::DownloadItem> items;
+        bool candidate = num_materials > 0;
+        for (int i = 0; i < num_materials && candidate; ++i) {
+            const MaterialD &m = s.materials[i];
+            auto constant = [](const TexD &t) { return t.num_levels >= 1 && t.width[0] <= 0 && t.height[0] <= 0 && t.texels[0] != nullptr; };
+            if (!constant(m.roughness) || !(m.use_vertex_color || constant(m.specular))) { candidate = false; break; }
+            if (!m.use_vertex_color) items.push_back(exec::DownloadItem{&vals[4 * (size_t)i], m.specular.texels[0], 3 * sizeof(float)});
+            else vals[4 * (size_t)i] = vals[4 * (size_t)i + 1] = vals[4 * (size_t)i + 2] = 0.f;
+            items.push_back(exec::DownloadItem{&vals[4 * (size_t)i + 3], m.roughness.texels[0], sizeof(float)});
+        }
+        if (candidate) {
+            exec::download_batch(items.data(), (int)items.size());
+            for (int i = 0; i < num_materials; ++i)
+                candidate = candidate && vals[4 * (size_t)i] == 0.f && vals[4 * (size_t)i + 1] == 0.f && vals[4 * (size_t)i + 2] == 0.f &&
+                            vals[4 * (size_t)i + 3] > 0.02f;
+        }
+        s.diffuse_only = candidate;
+    }
     s.lights.resize(num_area_lights);
     for (int i = 0; i < num_area_lights; ++i) {
         const rdr_area_light_desc &in = area_lights[i];

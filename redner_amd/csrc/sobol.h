@@ -70,15 +70,19 @@ RDR_FN double pcg_output_double(uint64_t oldstate) {
 
 // One sampler "view".  Sobol': which table, which sample of the sequence, which seed.  PCG (pcg_state != null):
 // per-slot states valid for dimension `pcg_base`; draw(slot, dim) is the (dim - pcg_base)-th number after it.
+// `dyn` (optional, device memory): the part of the dimension counter the host does not know -- the edge sampler advances by
+// 7 per EXECUTED bounce of an edge sub-path, and how many are executed depends on live-lane counts that stay on the device
+// (render.cpp).  A draw's dimension is `dim + *dyn`; PCG draws are relative to the draw group's start, so they ignore it.
 struct SamplerD {
     const uint64_t *matrices;
     uint64_t seed;
     int sample_id;
     const uint64_t *pcg_state;
     int pcg_base;
+    const int *dyn = nullptr;
     RDR_FN double draw(int slot, int dim) const {
         if (pcg_state) return pcg_output_double(pcg_advance(pcg_state[slot], pcg_inc(slot), (uint32_t)(dim - pcg_base)));
-        return sobol_value(matrices, (uint64_t)sample_id, (uint32_t)dim, sobol_scramble(seed, slot));
+        return sobol_value(matrices, (uint64_t)sample_id, (uint32_t)(dim + (dyn ? *dyn : 0)), sobol_scramble(seed, slot));
     }
 };
 
@@ -87,9 +91,15 @@ struct PcgInit {
     uint64_t *state; uint64_t seed;
     RDR_FN void operator()(int slot) const { state[slot] = pcg_seed_state(seed, slot); }
 };
+// `count` numbers, plus `*extra` more (device memory, optional); only if `*gate > 0` when a gate is given (a draw group of a
+// bounce that had no lanes to run was never drawn).
 struct PcgAdvance {
     uint64_t *state; int count;
-    RDR_FN void operator()(int slot) const { state[slot] = pcg_advance(state[slot], pcg_inc(slot), (uint32_t)count); }
+    const int *extra = nullptr, *gate = nullptr;
+    RDR_FN void operator()(int slot) const {
+        if (gate && *gate <= 0) return;
+        state[slot] = pcg_advance(state[slot], pcg_inc(slot), (uint32_t)(count + (extra ? *extra : 0)));
+    }
 };
 
 } // namespace rdr

@@ -58,11 +58,21 @@ struct SecondThread {          // never used: sample_workers() == 1
     template <class F> void start(F) {}
     void wait() {}
 };
+struct Count {                 // see hip/exec.h: `dev` is host memory here
+    const int *dev; int upper;
+    Count(int n) : dev(nullptr), upper(n) {}
+    Count(const int *d, int u) : dev(d), upper(u) {}
+    int value() const { return dev ? (*dev < upper ? *dev : upper) : upper; }
+};
+inline int *new_count() { static int ring[8192]; static int at = 0; at = (at + 1) % 8192; return ring + at; }
+inline int read_count(Count c) { return c.value(); }
+inline Count scaled_count(Count c, int k) { if (!c.dev) return Count(k * c.upper); int *d = new_count(); *d = k * c.value(); return Count(d, k * c.upper); }
 template <class F>
-inline void launch(int n, const F &f) { for (int i = 0; i < n; ++i) f(i); }
+inline void launch(Count c, const F &f) { const int n = c.value(); for (int i = 0; i < n; ++i) f(i); }
 inline int *persistent_counter() { static int ring[64]; static int at = 0; at = (at + 1) % 64; ring[at] = 0; return ring + at; }
 template <class W>
-inline void launch_persistent(int n, const W &w) {          // see hip/exec.h: begin / step... / finish per item
+inline void launch_persistent(Count c, const W &w) {          // see hip/exec.h: begin / step... / finish per item
+    const int n = c.value();
     for (int i = 0; i < n; ++i) {
         typename W::State st;
         if (w.begin(i, st)) { while (!w.step(st)) {} }
@@ -82,9 +92,19 @@ inline int compact(const int *in, int n, int *out, const P &pred) {
     for (int i = 0; i < n; ++i) { int p = in ? in[i] : i; if (pred(p)) out[c++] = p; }
     return c;
 }
+template <class P>
+inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const Count *append_at = nullptr, int *dyn = nullptr, int inc = 0) {
+    const int n_in = n.value();
+    const int base = append_at ? append_at->value() : 0;
+    int *result = new_count();
+    *result = base + compact(in, n_in, out + base, pred);
+    if (dyn && n_in > 0) *dyn += inc;
+    return Count(result, n.upper + (append_at ? append_at->upper : 0));
+}
 struct TraceStats { double closest_ms = 0, any_ms = 0; uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes[2] = {0, 0}, tris[2] = {0, 0}; bool timing = false, counting = false; };
 inline TraceStats &trace_stats() { static TraceStats s; return s; }
-inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, int n, bool any) {
+inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count cnt_n, bool any) {
+    const int n = cnt_n.value();
     TraceStats &st = trace_stats();
     rt::Counters cnt{0, 0};
     static const bool sim = std::getenv("RDR_TRACE_SIM") != nullptr;
