@@ -285,7 +285,8 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda:%d' % local_rank)
-    if world > 1:
+    under_launcher = 'RANK' in os.environ and 'MASTER_PORT' in os.environ      # torch.distributed.run, also with one rank
+    if world > 1 or under_launcher:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
         assert dist.get_world_size() == world
@@ -295,15 +296,14 @@ def main():
 
     from redner_amd import redner
     prep = Prepared(redner, build_scene(a, dev, a.res), spp_rank, a.spp, rank * spp_rank, a.max_bounces, dev)
-    reduce_bufs = [prep.img] + [g for g in prep.grads]
-
     def reduce_all():
-        # image + every gradient tensor: all_gather + fixed-order sum (bit-reproducible), see distributed.py
+        # the image, and every gradient tensor in one bucket: all_gather + fixed-order sum (bit-reproducible), see distributed.py
         if world == 1:
             return
-        from redner_amd.distributed import _all_gather_sum
-        for t in reduce_bufs:
-            t.copy_(_all_gather_sum(t, dist.group.WORLD))
+        from redner_amd.distributed import _all_gather_sum, _all_gather_sum_many
+        prep.img.copy_(_all_gather_sum(prep.img, dist.group.WORLD))
+        for t, r in zip(prep.grads, _all_gather_sum_many(prep.grads, dist.group.WORLD)):
+            t.copy_(r)
 
     from redner_amd import _capi
     lib = _capi.lib()
@@ -404,7 +404,8 @@ def main():
             except Exception as e:   # the baseline must never take the GPU number down with it
                 out['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

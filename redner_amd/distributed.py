@@ -35,6 +35,23 @@ def _all_gather_sum(t, group):
     return _ordered_sum(parts)
 
 
+def _all_gather_sum_many(tensors, group):
+    """The same for a list of tensors in ONE collective: the gradient tensors of a render are many and small (bunny_box:
+    ~20 tensors, < 0.1 MB together), and over xGMI a collective this size costs its latency, not its bytes -- so they are
+    packed into one flat bucket, gathered once, summed in fixed rank order and unpacked."""
+    world = dist.get_world_size(group)
+    if world == 1 or not tensors:
+        return list(tensors)
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    red = _all_gather_sum(flat, group)
+    out, at = [], 0
+    for t in tensors:
+        n = t.numel()
+        out.append(red[at:at + n].reshape(t.shape))
+        at += n
+    return out
+
+
 def shard_args(args, rank, world, spp_fwd, spp_bwd):
     """Copy of a serialized argument list restricted to this rank's sample block."""
     meta = dict(args[0])
@@ -58,14 +75,10 @@ class DistributedRenderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_img):
         grads = RenderFunction.backward(ctx, grad_img)
-        out = []
-        for g in grads[2:]:
-            if g is None:
-                out.append(None)
-                continue
-            dev = ctx.meta['device']
-            red = _all_gather_sum(g.to(dev), ctx.group)
-            out.append(red.to(g.device))
+        dev = ctx.meta['device']
+        live = [g for g in grads[2:] if g is not None]
+        reduced = iter(_all_gather_sum_many([g.to(dev) for g in live], ctx.group))      # one bucket, one collective
+        out = [None if g is None else next(reduced).to(g.device) for g in grads[2:]]
         return (None, None, None) + tuple(out)
 
 
