@@ -199,6 +199,13 @@ void rdr_trace_stats_get(rdr_trace_stats *out);
  * traversal parity tests and micro-benchmarks. */
 int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, int num_rays, int any_hit);
 
+/* Test hook: how often the library has gone to the runtime for device memory (hipMalloc calls made by its caching allocator)
+ * and how often the host has read a live-lane count back from the device, since the library was loaded.  A steady-state
+ * rdr_render() adds nothing to either (the reference allocates its PathBuffer per call, src/pathtracer.cpp:36-152, and
+ * reads a count after every stage, :292,590,833). */
+typedef struct rdr_debug_counters { uint64_t device_mallocs, host_count_reads; } rdr_debug_counters;
+void rdr_debug_counters_get(rdr_debug_counters *out);
+
 /* Test hook: writes the edge list and both edge hierarchies (links, edge ids, weights, costs) as
  * text, for the build-order parity test against the reference (tests/test_edge_build.py). */
 int rdr_debug_dump_edges(const rdr_scene *scene, const char *path);

@@ -106,9 +106,14 @@ class TraceStats(C.Structure):
                 ('any_nodes', C.c_uint64), ('any_tris', C.c_uint64)]
 
 
+class DebugCounters(C.Structure):
+    _fields_ = [('device_mallocs', C.c_uint64), ('host_count_reads', C.c_uint64)]
+
+
 EXPORTS = ('rdr_scene_create', 'rdr_scene_destroy', 'rdr_scene_max_generic_texture_dimension',
            'rdr_render', 'rdr_compute_num_channels', 'rdr_last_error',
-           'rdr_trace_stats_enable', 'rdr_trace_stats_reset', 'rdr_trace_stats_get', 'rdr_scene_trace')
+           'rdr_trace_stats_enable', 'rdr_trace_stats_reset', 'rdr_trace_stats_get', 'rdr_scene_trace',
+           'rdr_debug_counters_get')
 
 _lib = None
 _lib_path = None
@@ -145,6 +150,8 @@ def load(path=None):
     lib.rdr_trace_stats_enable.restype = None
     lib.rdr_trace_stats_enable.argtypes = [C.c_int, C.c_int]
     lib.rdr_trace_stats_reset.restype = None
+    lib.rdr_debug_counters_get.restype = None
+    lib.rdr_debug_counters_get.argtypes = [C.POINTER(DebugCounters)]
     lib.rdr_trace_stats_get.restype = None
     lib.rdr_trace_stats_get.argtypes = [C.POINTER(TraceStats)]
     lib.rdr_scene_trace.restype = C.c_int

@@ -87,6 +87,11 @@ void rdr_trace_stats_get(rdr_trace_stats *out) {
     out->any_nodes = s.nodes[1]; out->any_tris = s.tris[1];
 }
 
+void rdr_debug_counters_get(rdr_debug_counters *out) {
+    out->device_mallocs = exec::pool_device_mallocs();
+    out->host_count_reads = exec::host_count_reads();
+}
+
 int rdr_debug_dump_edges(const rdr_scene *scene, const char *path) {
     const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
     FILE *f = fopen(path, "w");

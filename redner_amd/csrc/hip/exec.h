@@ -118,6 +118,8 @@ void *pool_alloc(size_t bytes);
 void pool_free(void *p);
 void pool_trim();
 size_t pool_device_mallocs();          // number of hipMalloc calls made by the pool so far (tests: steady state adds none)
+inline std::atomic<size_t> &host_count_reads_ref() { static std::atomic<size_t> n{0}; return n; }
+inline size_t host_count_reads() { return host_count_reads_ref().load(); }     // live-lane counts read back by the host so far
 inline void zero(void *p, size_t bytes) { if (bytes) check(hipMemsetAsync(p, 0, bytes, ctx().stream), "hipMemsetAsync"); }
 inline void upload(void *dst, const void *src, size_t bytes) {
     if (bytes) check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().stream), "upload");
@@ -427,6 +429,7 @@ inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const 
 template <class P>
 inline int compact(const int *in, int n, int *out, const P &pred) {
     if (n <= 0) return 0;
+    host_count_reads_ref()++;
     CompactScratch &sc = compact_scratch((n + kCompactTile - 1) / kCompactTile);
     (void)compact_dev(in, Count(n), out, pred);
     hipStream_t st = ctx().stream;
@@ -455,6 +458,7 @@ inline Count scaled_count(Count c, int k) {
 // A count the host needs after all (a skip decision, a debug dump): synchronise and read it.
 inline int read_count(Count c) {
     if (!c.dev) return c.upper;
+    host_count_reads_ref()++;
     int v = 0;
     download(&v, c.dev, sizeof(int));
     return v < c.upper ? v : c.upper;

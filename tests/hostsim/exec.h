@@ -34,6 +34,7 @@ inline void *pool_alloc(size_t bytes) { return dmalloc(bytes); }
 inline void pool_free(void *p) { free(p); }
 inline void pool_trim() {}
 inline size_t pool_device_mallocs() { return 0; }
+inline size_t host_count_reads() { return 0; }
 inline void zero(void *p, size_t bytes) { memset(p, 0, bytes); }
 inline void upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void download(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }

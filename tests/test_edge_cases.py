@@ -74,3 +74,29 @@ def test_empty_scene_hostsim(hostsim_backend):
                                           device=torch.device('cpu'), backend=hostsim_backend)
     img = RenderFunction.apply(1, *args)
     assert img.shape == (16, 16, 3) and not img.numpy().any()
+
+
+@pytest.mark.gpu
+def test_steady_state_render_allocates_nothing_and_reads_no_counts(gpu_backend):
+    """After a first forward+backward call has sized the caching allocator, further calls on the same shapes make no
+    hipMalloc (the reference allocates its PathBuffer per call, src/pathtracer.cpp:36-152) and the host reads no live-lane
+    count back (the reference reads one after every stage, :292,590,833) -- also when a new Scene is built per call, as
+    pyredner does (render_pytorch.py:609)."""
+    import ctypes
+    from redner_amd import _capi
+    from golden.make_golden import render_case
+    dev = torch.device('cuda:0')
+
+    def counters():
+        c = _capi.DebugCounters()
+        _capi.lib().rdr_debug_counters_get(ctypes.byref(c))
+        return int(c.device_mallocs), int(c.host_count_reads)
+
+    for _ in range(2):                                            # warm the pool (two calls: both sample workers' buffers)
+        render_case(gpu_backend, 'bunny_box', 96, 8, 4, device=dev)
+    mallocs0, reads0 = counters()
+    for _ in range(3):
+        render_case(gpu_backend, 'bunny_box', 96, 8, 4, device=dev)
+    mallocs1, reads1 = counters()
+    assert mallocs1 == mallocs0, (mallocs0, mallocs1)
+    assert reads1 == reads0, (reads0, reads1)
