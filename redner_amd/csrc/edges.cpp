@@ -674,6 +674,9 @@ EdgeData *build_edge_data(Scene &scene) {
             ed->gather = gather_job.get();
             if (ed->gather.depth + 2 > 64) throw std::runtime_error("edge gather hierarchy deeper than the traversal stack (64)");
             const size_t slots = ed->gather.ids.size() / 2;
+            // stack entries of the gather pack a leaf as (count << 24 | first slot) under bit 30 (stages_edge.h: gather_entry)
+            if (slots >= ((size_t)1 << 24) || ed->gather.nodes.size() >= ((size_t)1 << 30))
+                throw std::runtime_error("edge gather hierarchy: more than 2^24 edges are not supported");
             ed->gleaf.resize(slots);
             for (size_t sl = 0; sl < slots; ++sl) {
                 const int eid = ed->gather.ids[2 * sl + 1];

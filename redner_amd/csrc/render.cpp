@@ -331,6 +331,14 @@ struct Backward {
             gshared.heavy_slot = arena.get<int>(kGatherHeavyCap);
             gshared.work = arena.get<GatherWork>(kGatherWorkCap);
             gshared.cands_big = arena.get<GatherCand>((size_t)kGatherCandsBig * kGatherHeavyCap);
+            gshared.heavy_cap = kGatherHeavyCap; gshared.work_cap = kGatherWorkCap;
+            if (const char *e = std::getenv("RDR_GATHER_CAPS")) {          // tests: small lists, so that the overflow paths run
+                int h = 0, w = 0;
+                if (std::sscanf(e, "%d,%d", &h, &w) == 2) {
+                    gshared.heavy_cap = std::max(0, std::min(h, kGatherHeavyCap));
+                    gshared.work_cap = std::max(0, std::min(w, kGatherWorkCap));
+                }
+            }
             h_leaves = arena.get<HLeaf>((size_t)kHSamples * P);
             h_spill = arena.get<HLeaf>((size_t)(kHSamples - kHStackLds) * P);
             edge_contrib = arena.get<double>(L);
@@ -354,7 +362,7 @@ struct Backward {
     VSlice ea, eb;                 // ping-pong vertex slices of the edge sub-paths (2P lanes each)
     int *elist[3] = {nullptr, nullptr, nullptr};
     HLeaf *h_leaves = nullptr, *h_spill = nullptr;   // hierarchical pick: recorded leaves / spilled stack entries per list position
-    GatherShared gshared{nullptr, nullptr, nullptr, nullptr};     // heavy slots of the gather: big candidate lists, subtree work items
+    GatherShared gshared{nullptr, nullptr, nullptr, nullptr, 0, 0};     // heavy slots of the gather: big candidate lists, subtree work items
     GatherCand *gather_cands = nullptr;        // positive leaves found by the NEE-mode gather, kGatherCands per list position
     int *nee_slots = nullptr;                  // slots of the NEE-mode edge pick (its walk runs beside the hierarchical pick)
     exec::Fence depth_begin, adjoint_done, setup_done, walk_done;

@@ -973,7 +973,9 @@ struct GatherBook {                 // zeroed before every SecEdgeGatherN launch
     int heavy_count, work_count;
     int cand_count[kGatherHeavyCap];
 };
-struct GatherShared { GatherBook *book; int *heavy_slot; GatherWork *work; GatherCand *cands_big; };
+// heavy_cap / work_cap: how much of the (kGatherHeavyCap / kGatherWorkCap sized) lists may be used -- the full size, or less
+// when RDR_GATHER_CAPS=h,w asks for it, which is how the tests reach the overflow paths.
+struct GatherShared { GatherBook *book; int *heavy_slot; GatherWork *work; GatherCand *cands_big; int heavy_cap, work_cap; };
 
 struct GatherCtx { LtcCtx lc; Ray nee; bool nee_valid; V3 inv_dir; SilQuery q_pos, q_nee; double resample; };
 RDR_FN GatherCtx gather_ctx(const SecEdgeArgs &a, int idx) {
@@ -985,7 +987,7 @@ RDR_FN GatherCtx gather_ctx(const SecEdgeArgs &a, int idx) {
     return c;
 }
 RDR_FN void gather_append_big(const GatherShared &sh, int heavy, const GatherCand &cd) {
-    if (heavy < 0 || heavy >= kGatherHeavyCap) return;
+    if (heavy < 0 || heavy >= sh.heavy_cap) return;
     const int k = atomic_fetch_add(&sh.book->cand_count[heavy], 1);
     if (k >= 0 && k < kGatherCandsBig) sh.cands_big[(size_t)heavy * kGatherCandsBig + k] = cd;
 }
@@ -1072,7 +1074,7 @@ template <int NS> struct SecEdgeGatherN {
         }
         auto promote = [&]() {              // this slot continues in the big lists
             heavy = atomic_fetch_add(&sh.book->heavy_count, 1);
-            if (heavy < kGatherHeavyCap) sh.heavy_slot[heavy] = i;
+            if (heavy < sh.heavy_cap) sh.heavy_slot[heavy] = i;
             for (int k = 0; k < ncand; ++k) gather_append_big(sh, heavy, mine[k]);
         };
         auto emit = [&](const GatherCand &cd) {
@@ -1084,13 +1086,13 @@ template <int NS> struct SecEdgeGatherN {
         while (sp > 0 && h_nodes < budget) { h_nodes++; gather_pop<NS>(sc, es, c, stk, sp, emit, h_edges); }
         if (sp > 0) {                        // budget spent: every entry left is a subtree for SecEdgeGatherSub
             if (heavy < 0) promote();
-            bool lost = heavy >= kGatherHeavyCap;
+            bool lost = heavy >= sh.heavy_cap;
             for (int k = 0; k < sp && !lost; ++k) {
                 const int w = atomic_fetch_add(&sh.book->work_count, 1);
-                if (w < kGatherWorkCap) sh.work[w] = GatherWork{heavy, RDR_STACK_AT(stk, k)};
+                if (w < sh.work_cap) sh.work[w] = GatherWork{heavy, RDR_STACK_AT(stk, k)};
                 else lost = true;
             }
-            if (lost && heavy < kGatherHeavyCap) atomic_fetch_add(&sh.book->cand_count[heavy], kGatherPoison);
+            if (lost && heavy < sh.heavy_cap) atomic_fetch_add(&sh.book->cand_count[heavy], kGatherPoison);
         }
 #ifdef RDR_HOSTSIM
         gather_stats_add(h_nodes, h_edges % 1000000, ncand, (int)(h_edges / 1000000));
@@ -1104,7 +1106,7 @@ template <int NS> struct SecEdgeGatherSub {
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
     RDR_FN void make_mid() { mid_scene(a.sc); }
     RDR_FN void operator()(int j) const {
-        const int n_work = sh.book->work_count < kGatherWorkCap ? sh.book->work_count : kGatherWorkCap;
+        const int n_work = sh.book->work_count < sh.work_cap ? sh.book->work_count : sh.work_cap;
         if (j >= n_work) return;
         const GatherWork wk = sh.work[j];
         const int idx = slots[sh.heavy_slot[wk.heavy]];
@@ -1122,7 +1124,7 @@ struct SecEdgeGatherReplay {
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
     RDR_FN void make_mid() { mid_scene(a.sc); }
     RDR_FN void operator()(int h) const {
-        const int n_heavy = sh.book->heavy_count < kGatherHeavyCap ? sh.book->heavy_count : kGatherHeavyCap;
+        const int n_heavy = sh.book->heavy_count < sh.heavy_cap ? sh.book->heavy_count : sh.heavy_cap;
         if (h >= n_heavy) return;
         const int n = sh.book->cand_count[h];
         if (n < 0 || n > kGatherCandsBig) return;          // stays kPickOverflow: SecEdgePickNWalk takes it
