@@ -340,7 +340,14 @@ struct TreeBuilder {
         }
     }
 
-    // ---- Karras-style treelet restructuring with <= 7 leaves (src/edge_tree.cpp:464-711) ----
+    // ---- treelet restructuring with <= 7 leaves (behaviour: src/edge_tree.cpp:464-711; Karras & Aila 2013, Algorithm 2) ----
+    // The result must equal the reference's tree link for link (tests/test_edge_build.py): which inner node lands where is
+    // fixed by (i) the order the treelet's leaves are collected in, (ii) the first minimal partition in the reference's
+    // enumeration order and (iii) the order the freed inner nodes are handed out.  Inside those constraints the formulation is
+    // ours: subset bounds are built incrementally (one merge per subset instead of up to six; unions are exact, so the areas
+    // are the same doubles), the dynamic programme runs over subsets in increasing numeric order (every proper subset of s is
+    // smaller than s, hence final -- no popcount sweeps), and the treelet is rebuilt by a recursion that refreshes bounds,
+    // weights and costs in post-order on its way out (the reference climbs from every leaf re-checking its ancestors).
     void refresh(int node) {
         EdgeNode &nd = nodes[node];
         merge_children(nd, nodes[nd.child0], nodes[nd.child1]);
@@ -348,105 +355,86 @@ struct TreeBuilder {
         nd.cost = area(nd) + nodes[nd.child0].cost + nodes[nd.child1].cost;
     }
 
-    void propagate_cost(int root, const int *leaves, int nl) {
-        for (int i = 0; i < nl; ++i) {
-            int cur = leaves[i];
-            while (cur != root) {
-                EdgeNode &nd = nodes[cur];
-                if (nd.cost < 0) {
-                    if (nodes[nd.child0].cost >= 0 && nodes[nd.child1].cost >= 0) refresh(cur);
-                    else break;
-                }
-                cur = nodes[cur].parent;
-            }
-        }
-        refresh(root);
-    }
+    struct Treelet {
+        int leaves[7], inner[5];
+        int nl = 0, ni = 0, next_inner = 0;
+        uint8_t best_left[128];
+    };
 
-    void restruct(int child_index, int root, const int *leaves, const int *inner, uint8_t partition,
-                  const uint8_t *optimal, int &index, int nl) {
-        struct Entry { uint8_t part, child; int parent; };
-        Entry stack[8];
-        int sp = 0;
-        stack[sp++] = Entry{partition, (uint8_t)child_index, root};
-        while (sp > 0) {
-            Entry e = stack[--sp];
-            if (__builtin_popcount(e.part) == 1) {
-                int leaf = leaves[__builtin_ffs(e.part) - 1];
-                if (e.child == 0) nodes[e.parent].child0 = leaf; else nodes[e.parent].child1 = leaf;
-                nodes[leaf].parent = e.parent;
-            } else {
-                int node = inner[index++];
-                nodes[node].cost = -1;
-                if (e.child == 0) nodes[e.parent].child0 = node; else nodes[e.parent].child1 = node;
-                nodes[node].parent = e.parent;
-                uint8_t left = optimal[e.part];
-                uint8_t right = (uint8_t)((~left) & e.part);
-                stack[sp++] = Entry{left, 0, node};
-                stack[sp++] = Entry{right, 1, node};
-            }
+    // Subtree for the leaf subset `part`, hung under `parent` as child `side`.  Inner nodes are taken from t.inner in the
+    // reference's hand-out order: a node first, then everything under its RIGHT half, then its left half.
+    void hang(Treelet &t, uint8_t part, int side, int parent) {
+        int node;
+        if ((part & (part - 1)) == 0) {
+            node = t.leaves[__builtin_ctz(part)];
+        } else {
+            node = t.inner[t.next_inner++];
+            const uint8_t left = t.best_left[part], right = (uint8_t)(part & ~left);
+            hang(t, right, 1, node);
+            hang(t, left, 0, node);
+            refresh(node);
         }
-        propagate_cost(root, leaves, nl);
+        if (side == 0) nodes[parent].child0 = node; else nodes[parent].child1 = node;
+        nodes[node].parent = parent;
     }
 
     void treelet_optimize(int root) {
         if (nodes[root].edge_id != -1) return;
-        int leaves[7], inner[5];
-        int nl = 0, ni = 0;
-        leaves[nl++] = nodes[root].child0;
-        leaves[nl++] = nodes[root].child1;
-        int max_idx = 0;
-        while (nl < 7 && max_idx != -1) {
-            max_idx = -1;
-            double max_area = -1;
-            for (int i = 0; i < nl; ++i) {
-                if (nodes[leaves[i]].edge_id == -1) {
-                    double a = area(nodes[leaves[i]]);
-                    if (a > max_area) { max_area = a; max_idx = i; }
-                }
+        Treelet t;
+        // grow the treelet: repeatedly open the inner leaf with the largest box; it is replaced by the last leaf, its children
+        // go to the end (this fixes the leaf numbering the partitions are expressed in)
+        t.leaves[t.nl++] = nodes[root].child0;
+        t.leaves[t.nl++] = nodes[root].child1;
+        while (t.nl < 7) {
+            int widest = -1;
+            double widest_area = -1;
+            for (int i = 0; i < t.nl; ++i) {
+                if (nodes[t.leaves[i]].edge_id != -1) continue;
+                const double ar = area(nodes[t.leaves[i]]);
+                if (ar > widest_area) { widest_area = ar; widest = i; }
             }
-            if (max_idx != -1) {
-                int tmp = leaves[max_idx];
-                inner[ni++] = tmp;
-                leaves[max_idx] = leaves[nl - 1];
-                leaves[nl - 1] = nodes[tmp].child0;
-                leaves[nl] = nodes[tmp].child1;
-                nl++;
-            }
+            if (widest < 0) break;
+            const int opened = t.leaves[widest];
+            t.inner[t.ni++] = opened;
+            t.leaves[widest] = t.leaves[t.nl - 1];
+            t.leaves[t.nl - 1] = nodes[opened].child0;
+            t.leaves[t.nl++] = nodes[opened].child1;
         }
-        // optimal partitioning of every subset (Karras & Aila 2013, Algorithm 2)
-        uint8_t optimal[128];
-        double a[128], c_opt[128];
-        int num_subsets = (1 << nl) - 1;
-        for (int s = 1; s <= num_subsets; ++s) {
-            EdgeNode acc = nodes[leaves[0]];
-            for (int i = 1; i < nl; ++i)
-                if ((s >> i) & 1) { EdgeNode t = acc; merge_children(acc, t, nodes[leaves[i]]); }
-            a[s] = area(acc);
+        const int full = (1 << t.nl) - 1;
+        // Surface area of every leaf subset.  [quirk] the reference starts every subset's union from leaf 0's box whether or
+        // not leaf 0 is in the subset (src/edge_tree.cpp:560-568), so the area it prices subset s with is that of s | 1: those
+        // are built incrementally (one merge each, from the subset without its lowest leaf other than leaf 0) and shared.
+        EdgeNode box[128];
+        double sa[128], best_cost[128];
+        box[1] = nodes[t.leaves[0]];
+        sa[1] = area(box[1]);
+        for (int s = 3; s <= full; s += 2) {
+            const int low = __builtin_ctz(s & ~1), rest = s & ~(1 << low);
+            box[s] = box[rest];
+            merge_children(box[s], box[rest], nodes[t.leaves[low]]);
+            sa[s] = area(box[s]);
         }
-        for (int i = 0; i < nl; ++i) c_opt[1 << i] = nodes[leaves[i]].cost;
-        for (int k = 2; k <= nl; ++k) {
-            for (uint32_t s = 1; s <= (uint32_t)num_subsets; ++s) {
-                if (__builtin_popcount(s) != k) continue;
-                double c_s = std::numeric_limits<double>::infinity();
-                uint32_t p_s = 0;
-                uint32_t d = (s - 1u) & s;
-                uint32_t p = (-d) & s;
-                do {
-                    double c = c_opt[p] + c_opt[s ^ p];
-                    if (c < c_s) { c_s = c; p_s = p; }
-                    p = (p - d) & s;
-                } while (p != 0);
-                c_opt[s] = a[s] + c_s;
-                optimal[s] = (uint8_t)p_s;
-            }
+        for (int s = 2; s <= full; s += 2) sa[s] = sa[s | 1];
+        for (int i = 0; i < t.nl; ++i) best_cost[1 << i] = nodes[t.leaves[i]].cost;
+        // cheapest split of every subset with >= 2 leaves; ties go to the first split in the order p = (p - d) & s
+        for (int s = 3; s <= full; ++s) {
+            if ((s & (s - 1)) == 0) continue;
+            double cheapest = std::numeric_limits<double>::infinity();
+            uint32_t arg = 0;
+            const uint32_t d = ((uint32_t)s - 1u) & (uint32_t)s;
+            uint32_t p = (0u - d) & (uint32_t)s;
+            do {
+                const double c = best_cost[p] + best_cost[(uint32_t)s ^ p];
+                if (c < cheapest) { cheapest = c; arg = p; }
+                p = (p - d) & (uint32_t)s;
+            } while (p != 0);
+            best_cost[s] = sa[s] + cheapest;
+            t.best_left[s] = (uint8_t)arg;
         }
-        uint8_t mask = (uint8_t)((1u << nl) - 1);
-        int index = 0;
-        uint8_t left = optimal[mask];
-        restruct(0, root, leaves, inner, left, optimal, index, nl);
-        uint8_t right = (uint8_t)((~left) & mask);
-        restruct(1, root, leaves, inner, right, optimal, index, nl);
+        const uint8_t left = t.best_left[full], right = (uint8_t)(full & ~left);
+        // the reference rebuilds the left half completely before the right half (the other way round below the root)
+        hang(t, left, 0, root);
+        hang(t, right, 1, root);
         refresh(root);
     }
 };
