@@ -2,10 +2,10 @@
 // Runs once per Scene (the reference rebuilds its Embree/OptiX scene per Scene object too,
 // src/scene.cpp:128-154); GPU-side build/refit is SURVEY.md section 8f row 1.
 #include "bvh.h"
+#include "hostpool.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
-#include <future>
 #include <limits>
 #include <stdexcept>
 
@@ -131,9 +131,9 @@ struct Builder {
         if (!inner) { make_leaf(0, first, count); return; }
         Builder L, R;
         L.prims = R.prims = prims; L.kBins = R.kBins = kBins; L.kTravCost = R.kTravCost = kTravCost;
-        auto left_job = std::async(std::launch::async, [&] { L.build_top(first, mid - first, depth + 1); });
+        auto left_job = hostpool::run([&] { L.build_top(first, mid - first, depth + 1); });
         R.build_top(mid, first + count - mid, depth + 1);
-        left_job.get();
+        left_job.wait();
         const int nl = (int)L.out.nodes.size(), nr = (int)R.out.nodes.size();
         const int tl = (int)L.out.ids.size() / 2;
         out.nodes.resize(1 + nl + nr);

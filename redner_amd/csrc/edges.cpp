@@ -1,6 +1,7 @@
 // edges.cpp -- host-side construction of the edge list, the primary-edge PMF/CDF and the two edge
 // hierarchies (see edges.h for the behavioural spec and why the build is order-exact).
 #include "edges.h"
+#include "hostpool.h"
 #include "camera.h"
 #include "scene.h"
 #include <chrono>
@@ -9,7 +10,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <future>
 #include <limits>
 #include <memory>
 
@@ -45,9 +45,9 @@ void merge_sort_rec(T *first, T *last, T *scratch, Cmp comp, int par_levels) {
     T *mid = first + n / 2;
     if (par_levels > 0 && n >= 4096) {
         std::vector<T> other((size_t)(n / 2 / 2 + 2));
-        auto job = std::async(std::launch::async, [&] { merge_sort_rec(first, mid, other.data(), comp, par_levels - 1); });
+        auto job = hostpool::run([&] { merge_sort_rec(first, mid, other.data(), comp, par_levels - 1); });
         merge_sort_rec(mid, last, scratch, comp, par_levels - 1);
-        job.get();
+        job.wait();
     } else {
         merge_sort_rec(first, mid, scratch, comp, 0);
         merge_sort_rec(mid, last, scratch, comp, 0);
@@ -140,18 +140,7 @@ double unit_coord(double v, double lo, double hi) {
 int clz64(uint64_t x) { return x == 0 ? 64 : __builtin_clzll(x); }
 
 // f(begin, end) over [0, n) in up to 16 contiguous chunks on separate threads (iterations must be independent).
-template <class F>
-void parallel_chunks(int n, int grain, F f) {
-    int chunks = std::min(16, (n + grain - 1) / grain);
-    if (chunks <= 1) { f(0, n); return; }
-    std::vector<std::future<void>> jobs;
-    for (int c = 1; c < chunks; ++c) {
-        int b = (int)((long long)n * c / chunks), e = (int)((long long)n * (c + 1) / chunks);
-        jobs.push_back(std::async(std::launch::async, [=] { f(b, e); }));
-    }
-    f(0, (int)((long long)n / chunks));
-    for (auto &j : jobs) j.get();
-}
+using hostpool::parallel_chunks;
 
 // ---- one hierarchy ------------------------------------------------------------------------------
 struct TreeBuilder {
@@ -312,9 +301,9 @@ struct TreeBuilder {
         if (nodes[node].edge_id != -1) return;
         const int c0 = nodes[node].child0, c1 = nodes[node].child1;
         if (depth < 6 && leaves_below[node] >= 2048) {
-            auto job = std::async(std::launch::async, [&] { optimize_subtree(c0, depth + 1, leaves_below); });
+            auto job = hostpool::run([&] { optimize_subtree(c0, depth + 1, leaves_below); });
             optimize_subtree(c1, depth + 1, leaves_below);
-            job.get();
+            job.wait();
         } else {
             optimize_sequential(c0);
             optimize_sequential(c1);
@@ -601,7 +590,8 @@ EdgeData *build_edge_data(Scene &scene) {
         // The billboard hierarchy of the NEE-mode gather (stages_edge.h: SecEdgeGatherN) needs only the edge bounds and
         // the billboard half-width: it is built on another thread while this one builds the two reference hierarchies.
         // Boxes: each edge's own spatial bounds grown by the half-width (rounded outwards; the builder pads on top).
-        std::future<rt::BvhHost> gather_job = std::async(std::launch::async, [&bounds, ne, e = ed->edge_bounds_expand] {
+        rt::BvhHost gather_built;
+        auto gather_job = hostpool::run([&gather_built, &bounds, ne, e = ed->edge_bounds_expand] {
             std::vector<float> boxes((size_t)6 * ne);
             for (int i = 0; i < ne; ++i) {
                 const double lo[3] = {bounds[i].p_min.x - e, bounds[i].p_min.y - e, bounds[i].p_min.z - e};
@@ -611,14 +601,13 @@ EdgeData *build_edge_data(Scene &scene) {
                     boxes[6 * (size_t)i + 3 + k] = std::nextafterf((float)hi[k], std::numeric_limits<float>::infinity());
                 }
             }
-            return rt::build_box_bvh(boxes.data(), ne);
+            gather_built = rt::build_box_bvh(boxes.data(), ne);
         });
-        struct JoinGather { std::future<rt::BvhHost> &f; ~JoinGather() { if (f.valid()) f.wait(); } } join_gather{gather_job};
         TreeBuilder cs(true, shapes, edges, bounds), ncs(false, shapes, edges, bounds);
         {   // the two hierarchies are independent
-            auto cs_job = std::async(std::launch::async, [&] { cs.build(cs_ids); });
+            auto cs_job = hostpool::run([&] { cs.build(cs_ids); });
             ncs.build(ncs_ids);
-            cs_job.get();
+            cs_job.wait();
         }
         timer.lap("3-D and 6-D trees");
         ed->cs_nodes.swap(cs.nodes); ed->cs_leaves = cs.n;
@@ -650,8 +639,11 @@ EdgeData *build_edge_data(Scene &scene) {
             return max_depth;
         };
         // the 6-D tree is walked first, so the 3-D tree's ranks start after its leaves
-        auto cs_depth = std::async(std::launch::async, [&] { return walk_tree(ed->cs_nodes, false, ed->ncs_leaves); });
-        const int depths[2] = {walk_tree(ed->ncs_nodes, true, 0), cs_depth.get()};
+        int cs_depth_value = 0;
+        auto cs_depth = hostpool::run([&] { cs_depth_value = walk_tree(ed->cs_nodes, false, ed->ncs_leaves); });
+        const int ncs_depth_value = walk_tree(ed->ncs_nodes, true, 0);
+        cs_depth.wait();
+        const int depths[2] = {ncs_depth_value, cs_depth_value};
         for (int max_depth : depths) {
             if (max_depth == 0) continue;
             if (max_depth + 2 > 64) throw std::runtime_error("edge hierarchy deeper than the traversal stack (64)");
@@ -659,7 +651,8 @@ EdgeData *build_edge_data(Scene &scene) {
         }
         timer.lap("depth, leaf order");
         {
-            ed->gather = gather_job.get();
+            gather_job.wait();
+            ed->gather = std::move(gather_built);
             if (ed->gather.depth + 2 > 64) throw std::runtime_error("edge gather hierarchy deeper than the traversal stack (64)");
             const size_t slots = ed->gather.ids.size() / 2;
             // stack entries of the gather pack a leaf as (count << 24 | first slot) under bit 30 (stages_edge.h: gather_entry)

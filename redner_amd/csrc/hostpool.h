@@ -1,0 +1,127 @@
+// hostpool.h -- worker threads for the host-side Scene build (triangle hierarchy, edge list, edge hierarchies).
+//
+// The build is a tree of short jobs (tens of microseconds to a millisecond); std::async(std::launch::async) starts an OS
+// thread per job, ~50 us each and started one after the other: several milliseconds per Scene went into thread creation.
+// This pool keeps its threads; run() returns a handle whose wait() HELPS -- it executes queued jobs while its own is not
+// finished -- so jobs may spawn and wait for jobs (the recursive builders do) without starving the pool.
+// The reference builds its structures with Thrust on the CPU thread pool it starts per call (src/parallel.cpp:228-255).
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace hostpool {
+
+class Pool {
+public:
+    struct State {
+        std::function<void()> fn;
+        std::atomic<bool> done{false};
+        std::exception_ptr error;
+    };
+    class Job {
+    public:
+        Job() = default;
+        Job(Pool *p, std::shared_ptr<State> s) : pool_(p), st_(std::move(s)) {}
+        Job(Job &&) = default;
+        Job &operator=(Job &&) = default;
+        ~Job() { if (st_) { try { wait(); } catch (...) {} } }       // a job never outlives what it refers to
+        void wait() {
+            if (!st_) return;
+            std::shared_ptr<State> s = std::move(st_);
+            pool_->help_until(*s);
+            if (s->error) std::rethrow_exception(s->error);
+        }
+    private:
+        Pool *pool_ = nullptr;
+        std::shared_ptr<State> st_;
+    };
+
+    static Pool &get() { static Pool *p = new Pool(); return *p; }      // never destroyed: jobs may run during exit
+
+    template <class F> Job run(F f) {
+        auto s = std::make_shared<State>();
+        s->fn = std::move(f);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            q_.push_back(s);
+        }
+        cv_.notify_one();
+        return Job(this, std::move(s));
+    }
+    int threads() const { return (int)workers_.size(); }
+
+private:
+    Pool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = (int)(hw ? hw : 8) - 1;
+        n = n < 1 ? 1 : (n > 31 ? 31 : n);
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); }), workers_.back().detach();
+    }
+    static void execute(State &s) {
+        try { s.fn(); } catch (...) { s.error = std::current_exception(); }
+        s.fn = nullptr;
+        s.done.store(true, std::memory_order_release);
+    }
+    bool try_one() {
+        std::shared_ptr<State> s;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (q_.empty()) return false;
+            s = std::move(q_.back());          // newest first: the job a waiter needs was queued last
+            q_.pop_back();
+        }
+        execute(*s);
+        done_cv_.notify_all();
+        return true;
+    }
+    void help_until(State &want) {
+        while (!want.done.load(std::memory_order_acquire)) {
+            if (try_one()) continue;
+            std::unique_lock<std::mutex> lk(m_);
+            done_cv_.wait_for(lk, std::chrono::microseconds(50), [&] { return want.done.load(std::memory_order_acquire) || !q_.empty(); });
+        }
+    }
+    void loop() {
+        for (;;) {
+            std::shared_ptr<State> s;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return !q_.empty(); });
+                s = std::move(q_.front());
+                q_.pop_front();
+            }
+            execute(*s);
+            done_cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_cv_;
+    std::deque<std::shared_ptr<State>> q_;
+    std::vector<std::thread> workers_;
+};
+
+template <class F> inline Pool::Job run(F f) { return Pool::get().run(std::move(f)); }
+
+// f(begin, end) over [0, n) in up to 16 chunks of at least `grain` items; the caller takes the first chunk.
+template <class F> inline void parallel_chunks(int n, int grain, F f) {
+    int chunks = (n + grain - 1) / grain;
+    if (chunks > 16) chunks = 16;
+    if (chunks <= 1) { if (n > 0) f(0, n); return; }
+    std::vector<Pool::Job> jobs;
+    jobs.reserve((size_t)chunks - 1);
+    for (int c = 1; c < chunks; ++c) {
+        int b = (int)((long long)n * c / chunks), e = (int)((long long)n * (c + 1) / chunks);
+        jobs.push_back(run([=] { f(b, e); }));
+    }
+    f(0, (int)((long long)n / chunks));
+    for (auto &j : jobs) j.wait();
+}
+
+} // namespace hostpool

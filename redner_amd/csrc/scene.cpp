@@ -1,5 +1,6 @@
 // scene.cpp -- Scene construction (see scene.h).
 #include "scene.h"
+#include "hostpool.h"
 #include "surface.h"
 #include "sobol.h"
 #include <memory>
@@ -7,7 +8,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include <future>
 #include <limits>
 #include <stdexcept>
 
@@ -267,8 +267,8 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     std::vector<rt::MeshView> meshes(num_shapes);
     for (int i = 0; i < num_shapes; ++i)
         meshes[i] = rt::MeshView{s.h_vertices[i].data(), s.h_indices[i].data(), s.shapes[i].num_triangles};
-    std::future<rt::BvhHost> bvh_job = std::async(std::launch::async, [&meshes] { return rt::build_bvh(meshes); });
-    struct JoinOnExit { std::future<rt::BvhHost> &f; ~JoinOnExit() { if (f.valid()) f.wait(); } } join_bvh{bvh_job};
+    rt::BvhHost bvh_built;
+    auto bvh_job = hostpool::run([&meshes, &bvh_built] { bvh_built = rt::build_bvh(meshes); });     // (joins in its destructor on an early exit)
 
     // ---- device copies of the flat tables ----
     // ---- gathered per-triangle records (scene_data.h: TriGeomD) ----
@@ -346,7 +346,8 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     if (s.use_primary_edges || s.use_secondary_edges) s.edges = build_edge_data(s);
     timer.lap("edge structures");
     {
-        s.bvh_host = bvh_job.get();
+        bvh_job.wait();
+        s.bvh_host = std::move(bvh_built);
         s.bvh.num_nodes = (int)s.bvh_host.nodes.size();
         s.bvh.num_tris = (int)s.bvh_host.ids.size() / 2;
         s.bvh.stack_need = s.bvh_host.depth + 2;
