@@ -156,6 +156,8 @@ struct Builder {
 
 } // namespace
 
+namespace { double inner_half_area(const BvhHost &h); }
+
 // Hierarchy over axis-aligned boxes (6 floats each: lo.xyz, hi.xyz) with the same builder: leaves list box indices in
 // `ids` ({0, box index} per slot), `tris` stays empty.  Node bounds are padded unions of the given boxes, so a query that
 // is monotone in box inclusion can cull with the nodes and decide exactly at the leaves (the NEE-mode edge gather).
@@ -175,6 +177,7 @@ BvhHost build_box_bvh(const float *boxes, int n) {
     bd.prims = prims.data();
     bd.build_top(0, n, 0);
     bd.out.tris.clear();
+    bd.out.inner_area = inner_half_area(bd.out);
     return bd.out;
 }
 
@@ -200,6 +203,61 @@ static void reorder_breadth_first(BvhHost &h) {
         next += 2;
     }
     h.nodes.swap(out);
+}
+
+namespace {
+double inner_half_area(const BvhHost &h) {
+    double a = 0;
+    for (const Node &n : h.nodes) {
+        if (n.b > 0) continue;
+        const double dx = (double)n.hi[0] - n.lo[0], dy = (double)n.hi[1] - n.lo[1], dz = (double)n.hi[2] - n.lo[2];
+        a += dx * dy + dy * dz + dz * dx;
+    }
+    return a;
+}
+// leaf_box(slot, lo, hi): box of the primitive in leaf slot `slot`
+template <class LeafBox> double refit_sweep(BvhHost &h, LeafBox leaf_box) {
+    for (int i = (int)h.nodes.size() - 1; i >= 0; --i) {
+        Node &n = h.nodes[i];
+        Box b;
+        if (n.b > 0) {
+            for (int k = 0; k < n.b; ++k) { float lo[3], hi[3]; leaf_box(n.a + k, lo, hi); b.grow(lo, hi); }
+            for (int k = 0; k < 3; ++k) { n.lo[k] = b.lo[k]; n.hi[k] = b.hi[k]; }
+            pad_box(n.lo, n.hi);
+        } else {                       // children are padded already; their union covers everything below
+            const Node &l = h.nodes[n.a], &r = h.nodes[n.a + 1];
+            for (int k = 0; k < 3; ++k) { n.lo[k] = std::min(l.lo[k], r.lo[k]); n.hi[k] = std::max(l.hi[k], r.hi[k]); }
+        }
+    }
+    const double now = inner_half_area(h);
+    return h.inner_area > 0 ? now / h.inner_area : 1.0;
+}
+}
+
+double refit_bvh(BvhHost &h, const std::vector<MeshView> &meshes) {
+    const size_t slots = h.ids.size() / 2;
+    for (size_t sl = 0; sl < slots; ++sl) {
+        const MeshView &m = meshes[(size_t)h.ids[2 * sl]];
+        const int t = h.ids[2 * sl + 1];
+        for (int k = 0; k < 3; ++k) {
+            const int vi = m.indices[3 * t + k];
+            for (int a = 0; a < 3; ++a) h.tris[9 * sl + 3 * k + a] = m.vertices[3 * vi + a];
+        }
+    }
+    return refit_sweep(h, [&](int slot, float lo[3], float hi[3]) {
+        const float *v = h.tris.data() + 9 * (size_t)slot;
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(v[a], std::min(v[3 + a], v[6 + a]));
+            hi[a] = std::max(v[a], std::max(v[3 + a], v[6 + a]));
+        }
+    });
+}
+
+double refit_box_bvh(BvhHost &h, const float *boxes) {
+    return refit_sweep(h, [&](int slot, float lo[3], float hi[3]) {
+        const float *b = boxes + 6 * (size_t)h.ids[2 * (size_t)slot + 1];
+        for (int a = 0; a < 3; ++a) { lo[a] = b[a]; hi[a] = b[3 + a]; }
+    });
 }
 
 BvhHost build_bvh(const std::vector<MeshView> &meshes) {
@@ -228,6 +286,7 @@ BvhHost build_bvh(const std::vector<MeshView> &meshes) {
     bd.build_top(0, (int)prims.size(), 0);
     if (bd.out.depth + 2 > kTraverseStack) throw std::runtime_error("triangle hierarchy deeper than the traversal stack");
     reorder_breadth_first(bd.out);
+    bd.out.inner_area = inner_half_area(bd.out);
     return bd.out;
 }
 

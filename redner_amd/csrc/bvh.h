@@ -117,6 +117,7 @@ RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], f
 namespace rt {
 // Host-side build product.
 struct BvhHost {
+    double inner_area = 0;            // sum of the inner nodes' half-areas: what a refit compares its result with
     std::vector<Node> nodes;
     std::vector<float> tris;
     std::vector<int> ids;
@@ -127,4 +128,10 @@ struct MeshView { const float *vertices; const int *indices; int num_triangles; 
 BvhHost build_bvh(const std::vector<MeshView> &meshes);
 // Same builder over boxes (lo.xyz, hi.xyz per box); leaf slots hold {0, box index} in `ids`, no triangle records.
 BvhHost build_box_bvh(const float *boxes, int n);
+// Refit: the topology and the leaf assignment of `h` are kept, triangle records and every box are recomputed from the
+// current vertex positions / boxes (children carry larger indices than their parents, so one backward sweep does it).
+// Hits do not depend on the hierarchy (raytri.h), only the work per ray does: the return value is the sum of the inner
+// nodes' half-areas over what it was when the hierarchy was built -- the caller rebuilds when that ratio drifts.
+double refit_bvh(BvhHost &h, const std::vector<MeshView> &meshes);
+double refit_box_bvh(BvhHost &h, const float *boxes);
 }

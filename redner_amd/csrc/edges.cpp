@@ -447,9 +447,20 @@ EdgeData *build_edge_data(Scene &scene) {
     const ShapeD *shapes = hs.data();
 
     // ---- edge list (src/edge.cpp:233-297) ----
+    // The first half of the construction -- half-edges sorted by vertex ids, runs merged into edges -- depends on the index
+    // buffer only; a shape whose index buffer equals the one seen last at its position reuses it (an optimisation loop moves
+    // vertices, not connectivity).  Everything after it depends on positions and is redone.
+    struct MergedCache { std::vector<std::vector<int>> indices; std::vector<std::vector<EdgeD>> merged; };
+    static MergedCache *merged_cache = new MergedCache();            // guarded by the API lock (capi.cpp)
+    static const bool cache_allowed = std::getenv("RDR_NO_REFIT") == nullptr;
+    if ((int)merged_cache->indices.size() != ns) { merged_cache->indices.assign(ns, {}); merged_cache->merged.assign(ns, {}); }
     std::vector<EdgeD> &edges = ed->edges;
     for (int sid = 0; sid < ns; ++sid) {
         const ShapeD &sh = hs[sid];
+        std::vector<EdgeD> merged;
+        if (cache_allowed && sh.num_triangles >= 256 && merged_cache->indices[sid] == scene.h_indices[sid]) {
+            merged = merged_cache->merged[sid];
+        } else {
         std::vector<EdgeD> he(3 * (size_t)sh.num_triangles);
         for (int t = 0; t < sh.num_triangles; ++t) {
             int i0 = sh.indices[3 * t], i1 = sh.indices[3 * t + 1], i2 = sh.indices[3 * t + 2];
@@ -462,13 +473,14 @@ EdgeData *build_edge_data(Scene &scene) {
             return a.v0 < b.v0;
         });
         // merge runs of identical (v0, v1): f1 of the run = f0 of its last member
-        std::vector<EdgeD> merged;
         for (size_t i = 0; i < he.size();) {
             EdgeD cur = he[i];
             size_t j = i + 1;
             while (j < he.size() && he[j].v0 == cur.v0 && he[j].v1 == cur.v1) { cur.f1 = he[j].f0; ++j; }
             merged.push_back(cur);
             i = j;
+        }
+        if (cache_allowed && sh.num_triangles >= 256) { merged_cache->indices[sid] = scene.h_indices[sid]; merged_cache->merged[sid] = merged; }
         }
         // sort by endpoint positions so duplicated (e.g. UV-seam) edges become neighbours
         {
@@ -590,8 +602,12 @@ EdgeData *build_edge_data(Scene &scene) {
         // The billboard hierarchy of the NEE-mode gather (stages_edge.h: SecEdgeGatherN) needs only the edge bounds and
         // the billboard half-width: it is built on another thread while this one builds the two reference hierarchies.
         // Boxes: each edge's own spatial bounds grown by the half-width (rounded outwards; the builder pads on top).
+        // (the billboard hierarchy only has to be conservative: with the edge list of the previous Scene its topology is kept
+        //  and its boxes are refitted; rebuilt when the inner surface area has grown by more than 30 %)
+        struct GatherCache { std::vector<EdgeD> edges; rt::BvhHost bvh; };
+        static GatherCache *gather_cache = new GatherCache();            // guarded by the API lock (capi.cpp)
         rt::BvhHost gather_built;
-        auto gather_job = hostpool::run([&gather_built, &bounds, ne, e = ed->edge_bounds_expand] {
+        auto gather_job = hostpool::run([&gather_built, &bounds, &edges, ne, e = ed->edge_bounds_expand] {
             std::vector<float> boxes((size_t)6 * ne);
             for (int i = 0; i < ne; ++i) {
                 const double lo[3] = {bounds[i].p_min.x - e, bounds[i].p_min.y - e, bounds[i].p_min.z - e};
@@ -601,7 +617,15 @@ EdgeData *build_edge_data(Scene &scene) {
                     boxes[6 * (size_t)i + 3 + k] = std::nextafterf((float)hi[k], std::numeric_limits<float>::infinity());
                 }
             }
+            const bool same = cache_allowed && !gather_cache->bvh.nodes.empty() && gather_cache->edges.size() == edges.size() &&
+                              std::memcmp(gather_cache->edges.data(), edges.data(), sizeof(EdgeD) * edges.size()) == 0;
+            if (same) {
+                gather_built = gather_cache->bvh;
+                if (rt::refit_box_bvh(gather_built, boxes.data()) <= 1.3) return;
+            }
             gather_built = rt::build_box_bvh(boxes.data(), ne);
+            gather_cache->edges = edges;
+            gather_cache->bvh = gather_built;
         });
         TreeBuilder cs(true, shapes, edges, bounds), ncs(false, shapes, edges, bounds);
         {   // the two hierarchies are independent
@@ -659,7 +683,8 @@ EdgeData *build_edge_data(Scene &scene) {
             if (slots >= ((size_t)1 << 24) || ed->gather.nodes.size() >= ((size_t)1 << 30))
                 throw std::runtime_error("edge gather hierarchy: more than 2^24 edges are not supported");
             ed->gleaf.resize(slots);
-            for (size_t sl = 0; sl < slots; ++sl) {
+            parallel_chunks((int)slots, 2048, [&](int sl_begin, int sl_end) {
+            for (size_t sl = (size_t)sl_begin; sl < (size_t)sl_end; ++sl) {
                 const int eid = ed->gather.ids[2 * sl + 1];
                 GatherLeaf &gl = ed->gleaf[sl];
                 gl.dx_lo = leaf_dx[2 * (size_t)eid]; gl.dx_hi = leaf_dx[2 * (size_t)eid + 1];
@@ -672,6 +697,7 @@ EdgeData *build_edge_data(Scene &scene) {
                 gl.f0 = e.f0 == -1 ? -1 : 0; gl.f1 = e.f1 == -1 ? -1 : 0;
                 gl.has_normals = scene.shapes[e.shape_id].normals != nullptr;
             }
+            });
         }
         timer.lap("gather hierarchy");
     }

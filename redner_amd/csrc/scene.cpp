@@ -267,8 +267,24 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     std::vector<rt::MeshView> meshes(num_shapes);
     for (int i = 0; i < num_shapes; ++i)
         meshes[i] = rt::MeshView{s.h_vertices[i].data(), s.h_indices[i].data(), s.shapes[i].num_triangles};
+    // A Scene with the index buffers of the previous one (an optimisation loop moves vertices, pyredner builds a Scene per
+    // forward call, render_pytorch.py:609) keeps that hierarchy's topology and refits its boxes; hits do not depend on the
+    // hierarchy (raytri.h), and it is rebuilt once its inner surface area has grown by more than 30 %.  RDR_NO_REFIT=1: always build.
+    struct TopologyCache { std::vector<std::vector<int>> indices; rt::BvhHost bvh; };
+    static TopologyCache *topo_cache = new TopologyCache();          // guarded by the API lock (capi.cpp)
+    static const bool refit_allowed = std::getenv("RDR_NO_REFIT") == nullptr;
     rt::BvhHost bvh_built;
-    auto bvh_job = hostpool::run([&meshes, &bvh_built] { bvh_built = rt::build_bvh(meshes); });     // (joins in its destructor on an early exit)
+    auto bvh_job = hostpool::run([&meshes, &bvh_built, &s] {      // (joins in its destructor on an early exit)
+        bool same = refit_allowed && topo_cache->indices.size() == s.h_indices.size() && !topo_cache->bvh.nodes.empty();
+        for (size_t i = 0; same && i < s.h_indices.size(); ++i) same = topo_cache->indices[i] == s.h_indices[i];
+        if (same) {
+            bvh_built = topo_cache->bvh;
+            if (rt::refit_bvh(bvh_built, meshes) <= 1.3) return;
+        }
+        bvh_built = rt::build_bvh(meshes);
+        topo_cache->indices = s.h_indices;
+        topo_cache->bvh = bvh_built;
+    });
 
     // ---- device copies of the flat tables ----
     // ---- gathered per-triangle records (scene_data.h: TriGeomD) ----

@@ -1,6 +1,8 @@
 """Degenerate inputs the reference's drivers guard against (src/pathtracer.cpp:292-300: a sample with no live
 paths, a scene without lights; src/scene.cpp:197: no light tables at all): nothing may crash, hang or
 produce non-finite values, and where the oracle is available the results must equal it."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -100,3 +102,45 @@ def test_steady_state_render_allocates_nothing_and_reads_no_counts(gpu_backend):
     mallocs1, reads1 = counters()
     assert mallocs1 == mallocs0, (mallocs0, mallocs1)
     assert reads1 == reads0, (reads0, reads1)
+
+
+def test_refit_after_vertices_moved_equals_fresh_build(hostsim_backend, tmp_path):
+    """A Scene whose index buffers equal the previous Scene's reuses the triangle hierarchy's and the billboard hierarchy's
+    topology and the id-sorted half of the edge list, refitting boxes to the moved vertices (scene.cpp / edges.cpp).  Hits and
+    edge picks must not depend on that: the result equals a process that builds everything from scratch (RDR_NO_REFIT=1), bit
+    for bit on the image and to fp32-atomics noise on the gradients."""
+    import subprocess
+    import sys
+    from conftest import HOSTSIM_LIB, ROOT
+    code = r'''
+import os, sys
+sys.path[:0] = [%r, %r + '/tests']
+import numpy as np, torch
+from redner_amd import _capi
+_capi.load(%r)
+from redner_amd import redner
+from redner_amd.render_pytorch import RenderFunction
+import scenes
+def run(shift):
+    sc = scenes.bunny_box(torch.device('cpu'), (40, 40))
+    v = sc.shapes[6].vertices.detach()
+    g = torch.Generator().manual_seed(7)
+    moved = (v * (1.0 + 0.15 * shift) + shift * torch.tensor([0.12, 0.05, -0.2]) + 0.01 * shift * torch.randn(v.shape, generator=g)).requires_grad_(True)
+    sc.shapes[6].vertices = moved
+    args = RenderFunction.serialize_scene(sc, 4, 3, sampler_type=redner.SamplerType.sobol, device=torch.device('cpu'), backend=redner)
+    img = RenderFunction.apply(1, *args)
+    img.sum().backward()
+    return img.detach().numpy(), moved.grad.numpy()
+run(0.0)                       # the Scene whose topology the next one inherits (unless RDR_NO_REFIT)
+img, grad = run(1.0)
+np.savez(sys.argv[1], image=img, grad=grad)
+''' % (ROOT, ROOT, HOSTSIM_LIB)
+    outs = {}
+    for tag, env in (('refit', {}), ('fresh', {'RDR_NO_REFIT': '1'})):
+        out = str(tmp_path / (tag + '.npz'))
+        subprocess.check_call([sys.executable, '-c', code, out], env=dict(os.environ, **env), timeout=900)
+        outs[tag] = np.load(out)
+    assert np.array_equal(outs['refit']['image'], outs['fresh']['image'])
+    a, b = outs['refit']['grad'].astype(np.float64), outs['fresh']['grad'].astype(np.float64)
+    assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b)
+    assert np.abs(b).sum() > 0
