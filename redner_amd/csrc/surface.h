@@ -493,11 +493,12 @@ RDR_FN void scatter_trigrad(const ShapeD &sh, const GShape &gs, int tri, const T
     int ui[3] = {at.ui0, at.ui1, at.ui2};
     int ni[3] = {at.ni0, at.ni1, at.ni2};
 #pragma unroll
+    // (lanes that share a triangle were summed by the caller, scatter_trigrad_wave; what is left rarely shares an address)
     for (int k = 0; k < 3; ++k) {       // must unroll: dynamic indexing would push the TriGrad into scratch
-        accum3(gs.vertices + 3 * vi[k], g.p[k]);
-        if (!plain && sh.uvs && gs.uvs) { accum(gs.uvs + 2 * ui[k], g.uv[k].x); accum(gs.uvs + 2 * ui[k] + 1, g.uv[k].y); }
-        if (sh.normals && gs.normals) accum3(gs.normals + 3 * ni[k], g.n[k]);
-        if (!plain && sh.colors && gs.colors) accum3(gs.colors + 3 * vi[k], g.c[k]);
+        accum3_plain(gs.vertices + 3 * vi[k], g.p[k]);
+        if (!plain && sh.uvs && gs.uvs) { accum_plain(gs.uvs + 2 * ui[k], g.uv[k].x); accum_plain(gs.uvs + 2 * ui[k] + 1, g.uv[k].y); }
+        if (sh.normals && gs.normals) accum3_plain(gs.normals + 3 * ni[k], g.n[k]);
+        if (!plain && sh.colors && gs.colors) accum3_plain(gs.colors + 3 * vi[k], g.c[k]);
     }
 }
 

@@ -24,6 +24,7 @@
 
 namespace rdr {
 inline void accum(double *p, double v) { *p += v; }
+inline void accum_plain(double *p, double v) { *p += v; }
 inline int atomic_fetch_add(int *p, int v) { int o = *p; *p += v; return o; }
 }
 
