@@ -241,8 +241,13 @@ struct Count {
     Count(const int *d, int u) : dev(d), upper(u) {}
 };
 
+// A stage may ask for a minimum number of workgroups per CU (registers are then capped, spilling if need be):
+// `static constexpr int kMinBlocksPerCU` in the functor; default: whatever the body needs.
+template <class F, class = void> struct MinBlocks { static constexpr int value = 1; };
+template <class F> struct MinBlocks<F, decltype((void)F::kMinBlocksPerCU)> { static constexpr int value = F::kMinBlocksPerCU; };
+
 template <class F>
-__global__ void __launch_bounds__(256) stage_kernel(F f, int n, const int *count) {
+__global__ void __launch_bounds__(256, MinBlocks<F>::value) stage_kernel(F f, int n, const int *count) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (count) { const int c = *count; n = c < n ? c : n; }
     // a stage body that is instantiated twice (plain + LeanStage) must still be inlined into each kernel:

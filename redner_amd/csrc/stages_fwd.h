@@ -113,7 +113,10 @@ template <class Stage> struct LeanStage {
     Stage f;
     RDR_FN void operator()(int i) const { Stage g = f; g.make_lean(); RDR_INLINE_CALL g(i); }
 };
+template <class Stage, class = void> struct MidBlocks { static constexpr int value = 1; };
+template <class Stage> struct MidBlocks<Stage, decltype((void)Stage::kMidBlocksPerCU)> { static constexpr int value = Stage::kMidBlocksPerCU; };
 template <class Stage> struct MidStage {
+    static constexpr int kMinBlocksPerCU = MidBlocks<Stage>::value;
     Stage f;
     RDR_FN void operator()(int i) const { Stage g = f; g.make_mid(); RDR_INLINE_CALL g(i); }
 };
