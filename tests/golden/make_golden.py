@@ -131,6 +131,9 @@ CONFIG_CASES = {
     'two_triangles_256x256x64': ('two_triangles', 256, 64, 1),
     'bunny_box_512x512x8': ('bunny_box', 512, 8, 4),
     'bunny_box_tile_512x512x128': ('bunny_box_tile', 512, 128, 4),
+    # BASELINE config 5's stand-in (tests/scenes.py) at a size where the mid-specialised kernels run with full waves,
+    # both sample-independent streams and mip-mapped texture gradients (texel tensors: 512 x 512 x 3 per material)
+    'living_room_standin_256x256x4': ('living_room_standin', 256, 4, 6),
 }
 
 # Cases whose backward pass can only be reproduced sample-for-sample by a build that shares the oracle's libm
