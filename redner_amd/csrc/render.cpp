@@ -365,7 +365,7 @@ struct Backward {
     GatherShared gshared{nullptr, nullptr, nullptr, nullptr, 0, 0};     // heavy slots of the gather: big candidate lists, subtree work items
     GatherCand *gather_cands = nullptr;        // positive leaves found by the NEE-mode gather, kGatherCands per list position
     int *nee_slots = nullptr;                  // slots of the NEE-mode edge pick (its walk runs beside the hierarchical pick)
-    exec::Fence depth_begin, adjoint_done, setup_done, walk_done;
+    exec::Fence depth_begin, adjoint_done, setup_done, walk_done, picks_begin, pickh_done;
     const bool overlap = g_overlap.load(std::memory_order_relaxed);
     double *edge_contrib = nullptr, *edge_tmin = nullptr, *hit_pos = nullptr;
     PrimaryEdgeRec *prim_recs = nullptr;
@@ -448,12 +448,92 @@ struct Backward {
         exec::zero(adj.ray_dir, sizeof(double) * 3 * P);
         exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * P);
         const int dim0 = opt.sample_pixel_center ? 0 : 2;
+        static const bool pickh_fused = std::getenv("RDR_PICKH_FUSED") != nullptr;     // A/B: the one-loop form
+        static const bool pickh_lazy = std::getenv("RDR_PICKH_LAZY") != nullptr;       // A/B: per-field node loads
+        // The two edge picks of a secondary pass: slot setup, the per-mode slot lists, the NEE-mode gather and the hierarchical
+        // pick.  `early`: everything off the calling stream (setup + lists + gather on side stream 1, hierarchical pick on side
+        // stream 0), so that the caller's stream is free for the bounce adjoints; otherwise setup, lists and the hierarchical pick
+        // run on the calling stream and the gather beside them.  Joined by join_picks().
+        struct PickPhase { bool running = false, early = false, side = false; };
+        PickPhase picks_phase;
+        auto start_picks = [&](int d, int edim_d, bool early, bool side) -> SecEdgeArgs {
+            const exec::Count nA = num_active[d];
+            const int *act = active + (size_t)d * P;
+            const EdgeSceneD &es = scene.edges->d;
+            SecEdgeArgs sa{scene.d, es, rng, dim0 + 7 * d, edge_rng_at(rng_edge, edim_d), edim_d, act, vs[d]};
+            hipStream_t main_stream = exec::ctx().stream;
+            const int need = es.max_stack;
+            exec::Count nH(0), nN(0);
+            auto lists = [&] {
+                launch_v(lean, nA, SecEdgeSetup{sa, sec_mode, sec_recs, sec_picks, ea, edge_tmin});
+                nH = exec::compact_dev((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 1});
+                const exec::Count nN2 = exec::compact_dev((const int *)nullptr, nA, nee_slots, KeepMode{sec_mode, 2});
+                nN = exec::compact_dev((const int *)nullptr, nA, nee_slots, KeepMode{sec_mode, 3}, &nN2);   // dense-shape slots after the others
+            };
+            auto gather = [&] {
+                if (lean == kLean) launch_pick_n<kLean>(need, nN, sa);
+                else if (lean == kMid) launch_pick_n<kMid>(need, nN, sa);
+                else launch_pick_n<kGeneral>(need, nN, sa);
+            };
+            auto hierarchical = [&] {
+                if (pickh_fused) launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
+                else if (pickh_lazy) launch_v(lean, nH, SecEdgePickH2<false>{sa, elist[0], sec_picks, h_leaves, h_spill, nH.upper});
+                else launch_v(lean, nH, SecEdgePickH2<true>{sa, elist[0], sec_picks, h_leaves, h_spill, nH.upper});
+            };
+            if (early) {
+                picks_begin.after(main_stream);
+                {
+                    exec::StreamScope on(exec::side_stream(1));
+                    picks_begin.gate(exec::ctx().stream);
+                    lists();
+                    setup_done.after(exec::ctx().stream);
+                    gather();
+                    walk_done.after(exec::ctx().stream);
+                }
+                {
+                    exec::StreamScope on(exec::side_stream(0));
+                    setup_done.gate(exec::ctx().stream);
+                    hierarchical();
+                    pickh_done.after(exec::ctx().stream);
+                }
+            } else {
+                lists();
+                {
+                    if (side) setup_done.after(main_stream);
+                    exec::StreamScope on(side ? exec::side_stream(1) : main_stream);
+                    if (side) setup_done.gate(exec::ctx().stream);
+                    gather();
+                    if (side) walk_done.after(exec::ctx().stream);
+                }
+                hierarchical();
+            }
+            picks_phase = PickPhase{true, early, side};
+            return sa;
+        };
+        auto join_picks = [&] {
+            hipStream_t main_stream = exec::ctx().stream;
+            if (picks_phase.early) { walk_done.gate(main_stream); pickh_done.gate(main_stream); }
+            else if (picks_phase.side) walk_done.gate(main_stream);
+            picks_phase.running = false;
+        };
+        // In a purely diffuse scene (and with the stateless sampler) only the first vertex samples secondary edges, and its
+        // picks need nothing from the adjoint sweep: they start now, on the side streams, and run beside the bounce adjoints of
+        // ALL depths instead of the first vertex's alone (its static sampler dimension is 4 per deeper depth that runs).
+        const bool secondary_on = edges_on && scene.use_secondary_edges;
+        SecEdgeArgs early_sa{};
+        bool hoisted = false;
+        if (secondary_on && overlap && scene.diffuse_only && pcg_edge == nullptr && has_lights && B >= 2 && num_active[0].upper > 0) {
+            int edim0 = 0;
+            for (int d = B - 1; d >= 1; --d) if (num_active[d].upper > 0) edim0 += 4;
+            early_sa = start_picks(0, edim0, true, true);
+            hoisted = true;
+        }
         for (int d = B - 1; d >= 0 && has_lights; --d) {
             const exec::Count nA = num_active[d];
             if (nA.upper <= 0) continue;
             const int *act = active + (size_t)d * P;
             AdjBounceArgs ba{scene.d, grads.g, rng, dim0 + 7 * d, act, vs[d], vs[d + 1], d_image, nd, radiance_dim, weight, adj};
-            bool with_edges = edges_on && scene.use_secondary_edges;
+            bool with_edges = secondary_on;
             if (with_edges && d > 0 && scene.diffuse_only) {
                 // Every material is purely diffuse: a path that has left its first vertex carries min_roughness 1 (src/material.h:750-752)
                 // and the sampler returns at once for every slot (src/edge.cpp:1396-1401).  Nothing of the pass remains but its
@@ -462,11 +542,12 @@ struct Backward {
                 edim += 4;
                 edge_rng_consumed_n(nA, 4);
             }
-            // The bounce adjoint of this depth, the hierarchical edge pick and the NEE-mode edge-pick walk do not depend on
-            // each other (the edge pass touches the adjoint records only in SecondaryEdgeDerivatives); each of them keeps a
-            // fraction of the lanes busy, so they run on three streams and are joined before the records are needed.
+            // The bounce adjoint of this depth, the hierarchical edge pick and the NEE-mode gather do not depend on each other
+            // (the edge pass touches the adjoint records only in SecondaryEdgeDerivatives); each of them keeps a fraction of
+            // the lanes busy, so they run on three streams and are joined before the records are needed.
             hipStream_t main_stream = exec::ctx().stream;
-            const bool side = overlap && with_edges;
+            const bool early_here = hoisted && d == 0;
+            const bool side = overlap && with_edges && !early_here;
             if (side) {
                 depth_begin.after(main_stream);
                 exec::StreamScope on(exec::side_stream(0));
@@ -480,31 +561,9 @@ struct Backward {
             }
             if (with_edges) {
                 // ---- secondary (shadow / inter-reflection) edges at this vertex, :500-706 ----
-                const EdgeSceneD &es = scene.edges->d;
                 const exec::Count lanes = exec::scaled_count(nA, 2);
-                SecEdgeArgs sa{scene.d, es, rng, dim0 + 7 * d, edge_rng_at(rng_edge, edim), edim, act, vs[d]};
-                launch_v(lean, nA, SecEdgeSetup{sa, sec_mode, sec_recs, sec_picks, ea, edge_tmin});
-                const exec::Count nH = exec::compact_dev((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 1});
-                const exec::Count nN2 = exec::compact_dev((const int *)nullptr, nA, nee_slots, KeepMode{sec_mode, 2});
-                const exec::Count nN = exec::compact_dev((const int *)nullptr, nA, nee_slots, KeepMode{sec_mode, 3}, &nN2);   // dense-shape slots after the others
-                const int need = es.max_stack;
-                {   // NEE-mode pick beside the hierarchical pick
-                    if (side) setup_done.after(main_stream);
-                    exec::StreamScope on(side ? exec::side_stream(1) : main_stream);
-                    if (side) setup_done.gate(exec::ctx().stream);
-                    if (lean == kLean) launch_pick_n<kLean>(need, nN, sa);
-                    else if (lean == kMid) launch_pick_n<kMid>(need, nN, sa);
-                    else launch_pick_n<kGeneral>(need, nN, sa);
-                    if (side) walk_done.after(exec::ctx().stream);
-                }
-                static const bool pickh_fused = std::getenv("RDR_PICKH_FUSED") != nullptr;     // A/B: the one-loop form
-                if (pickh_fused) launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
-                else {
-                    static const bool lazy = std::getenv("RDR_PICKH_LAZY") != nullptr;     // A/B: per-field node loads
-                    if (lazy) launch_v(lean, nH, SecEdgePickH2<false>{sa, elist[0], sec_picks, h_leaves, h_spill, nH.upper});
-                    else launch_v(lean, nH, SecEdgePickH2<true>{sa, elist[0], sec_picks, h_leaves, h_spill, nH.upper});
-                }
-                if (side) walk_done.gate(main_stream);
+                const SecEdgeArgs sa = early_here ? early_sa : start_picks(d, edim, false, side);
+                join_picks();
                 debug_dump("sec_mode", sample_id, d, sec_mode, (size_t)nA.upper);
                 debug_dump("sec_picks", sample_id, d, sec_picks, sizeof(SecPick) * (size_t)nA.upper);
                 launch_v(lean, nA, SecEdgeFinish{sa, sec_mode, sec_picks, d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});
