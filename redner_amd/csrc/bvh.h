@@ -84,8 +84,8 @@ RT_HD inline Hit traverse_with(const BvhD &bvh, const float o[3], const float d[
             // keep the window closed at best.t so equal-t candidates are still visited (tie-break)
             float lim = best.shape < 0 ? tfar : best.t * 1.0000004f + 1e-30f;
             float tl, tr;
-            bool hl = ray_box(o, inv, tnear, lim, l.lo, l.hi, &tl);
-            bool hr = ray_box(o, inv, tnear, lim, r.lo, r.hi, &tr);
+            bool hl = ray_box_once(o, inv, tnear, lim, l.lo, l.hi, &tl);
+            bool hr = ray_box_once(o, inv, tnear, lim, r.lo, r.hi, &tr);
             if (hl && hr) {
                 int near = n.a, far = n.a + 1;
                 if (tr < tl) { near = n.a + 1; far = n.a; }
