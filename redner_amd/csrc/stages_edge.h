@@ -993,34 +993,54 @@ RDR_FN void gather_append_big(const GatherShared &sh, int heavy, const GatherCan
 }
 // One pop of the gather: an inner entry tests its two children and pushes the ones the segment may reach, a leaf entry
 // applies the reference's own tests to its 1..4 edges and reports the positive ones through `emit`.
+// The walk of the gather, in two alternating phases so that the lanes of a wave run the same body: (A) pop inner entries,
+// test their two children, push inner children on the node stack and LEAF children on a small per-lane list; (B) when the list
+// is nearly full or the stack is empty, evaluate the listed leaves -- the reference's own tests on each of their 1..4 edges,
+// positive ones reported through `emit`.  (Interleaved, a wave executed both bodies in nearly every iteration with a fraction of
+// its lanes in each: lane utilisation 0.22.)  Stops with entries left on the stack when `budget` pops are spent.
+constexpr int kGatherLeafBatch = 16;
 template <int NS, class Emit>
-RDR_DEV_FN void gather_pop(const SceneD &sc, const EdgeSceneD &es, const GatherCtx &c, int *stk, int &sp, const Emit &emit, long &h_edges) {
+RDR_DEV_FN void gather_walk(const SceneD &sc, const EdgeSceneD &es, const GatherCtx &c, int *stk, int &sp, int *lst, int &nl,
+                            long budget, const Emit &emit, long &pops, long &h_edges) {
     const GatherQuad *quads = reinterpret_cast<const GatherQuad *>(es.gather.nodes);
-    --sp;
-    const int e = RDR_STACK_AT(stk, sp);
-    if (e & kGatherLeafBit) {
-        const int first = e & 0xffffff, count = (e >> 24) & 63;
-        for (int k = 0; k < count; ++k) {
-            const GatherLeaf gl = es.gleaf[first + k];
-            h_edges++;
-            // the edge's own leaf, tested like the reference tests it from its parent
-            bool ok = sphere_box_x(c.q_pos, gl.dx_lo, gl.dx_hi);
-            if (c.nee_valid) ok = ok && sphere_box_x(c.q_nee, gl.dx_lo, gl.dx_hi);
-            const V3 p0 = v3_of(gl.v0), p1 = v3_of(gl.v1);
-            const V3 blo = V3{dmin(p0.x, p1.x), dmin(p0.y, p1.y), dmin(p0.z, p1.z)}, bhi = V3{dmax(p0.x, p1.x), dmax(p0.y, p1.y), dmax(p0.z, p1.z)};
-            ok = ok && ray_box_all_axes(blo, bhi, c.nee, c.inv_dir, es.edge_bounds_expand);
-            if (!ok) continue;
-            h_edges += 1000000;          // (harness statistics: survivors of the cheap tests in the upper digits)
-            const double w = leaf_importance_gathered(gl, es.edge_bounds_expand, c.lc, c.nee, c.nee_valid);
-            if (w > 0) emit(GatherCand{gl.rank, gl.eid, w});
+    while (sp > 0 || nl > 0) {
+        while (sp > 0 && nl <= kGatherLeafBatch - 2 && pops < budget) {
+            --sp; ++pops;
+            const int e = RDR_STACK_AT(stk, sp);
+            const GatherQuad l_lo = quads[2 * e], l_hi = quads[2 * e + 1], r_lo = quads[2 * e + 2], r_hi = quads[2 * e + 3];
+            const int el = gather_entry(l_lo, l_hi), er = gather_entry(r_lo, r_hi);      // (before the tests: whole-record loads)
+            const bool hl = ray_box_all_axes(V3{(double)l_lo.x, (double)l_lo.y, (double)l_lo.z}, V3{(double)l_hi.x, (double)l_hi.y, (double)l_hi.z}, c.nee, c.inv_dir, 0.0);
+            const bool hr = ray_box_all_axes(V3{(double)r_lo.x, (double)r_lo.y, (double)r_lo.z}, V3{(double)r_hi.x, (double)r_hi.y, (double)r_hi.z}, c.nee, c.inv_dir, 0.0);
+            if (hl) {
+                if (el & kGatherLeafBit) { RDR_STACK_AT(lst, nl) = el; nl++; }
+                else if (sp < NS) { RDR_STACK_AT(stk, sp) = el; sp++; }
+            }
+            if (hr) {
+                if (er & kGatherLeafBit) { RDR_STACK_AT(lst, nl) = er; nl++; }
+                else if (sp < NS) { RDR_STACK_AT(stk, sp) = er; sp++; }
+            }
         }
-    } else {
-        const GatherQuad l_lo = quads[2 * e], l_hi = quads[2 * e + 1], r_lo = quads[2 * e + 2], r_hi = quads[2 * e + 3];
-        const int el = gather_entry(l_lo, l_hi), er = gather_entry(r_lo, r_hi);      // (before the tests: whole-record loads)
-        const bool hl = ray_box_all_axes(V3{(double)l_lo.x, (double)l_lo.y, (double)l_lo.z}, V3{(double)l_hi.x, (double)l_hi.y, (double)l_hi.z}, c.nee, c.inv_dir, 0.0);
-        const bool hr = ray_box_all_axes(V3{(double)r_lo.x, (double)r_lo.y, (double)r_lo.z}, V3{(double)r_hi.x, (double)r_hi.y, (double)r_hi.z}, c.nee, c.inv_dir, 0.0);
-        if (hl && sp < NS) { RDR_STACK_AT(stk, sp) = el; sp++; }
-        if (hr && sp < NS) { RDR_STACK_AT(stk, sp) = er; sp++; }
+        for (int j = 0; j < nl; ++j) {
+            const int e = RDR_STACK_AT(lst, j);
+            const int first = e & 0xffffff, count = (e >> 24) & 63;
+            ++pops;
+            for (int k = 0; k < count; ++k) {
+                const GatherLeaf gl = es.gleaf[first + k];
+                h_edges++;
+                // the edge's own leaf, tested like the reference tests it from its parent
+                bool ok = sphere_box_x(c.q_pos, gl.dx_lo, gl.dx_hi);
+                if (c.nee_valid) ok = ok && sphere_box_x(c.q_nee, gl.dx_lo, gl.dx_hi);
+                const V3 p0 = v3_of(gl.v0), p1 = v3_of(gl.v1);
+                const V3 blo = V3{dmin(p0.x, p1.x), dmin(p0.y, p1.y), dmin(p0.z, p1.z)}, bhi = V3{dmax(p0.x, p1.x), dmax(p0.y, p1.y), dmax(p0.z, p1.z)};
+                ok = ok && ray_box_all_axes(blo, bhi, c.nee, c.inv_dir, es.edge_bounds_expand);
+                if (!ok) continue;
+                h_edges += 1000000;          // (harness statistics: survivors of the cheap tests in the upper digits)
+                const double w = leaf_importance_gathered(gl, es.edge_bounds_expand, c.lc, c.nee, c.nee_valid);
+                if (w > 0) emit(GatherCand{gl.rank, gl.eid, w});
+            }
+        }
+        nl = 0;
+        if (pops >= budget) break;
     }
 }
 // Reservoir replay in the reference's leaf order (src/edge.cpp:1300-1316) over `n` candidates, then the pick's tail.
@@ -1064,12 +1084,15 @@ template <int NS> struct SecEdgeGatherN {
         GatherCand *mine = cands + (size_t)kGatherCands * i;
         int ncand = 0, heavy = -1;
         RDR_STACK_DECL(int, stk, NS);
-        int sp = 0;
+        RDR_STACK_DECL(int, lst, kGatherLeafBatch);
+        int sp = 0, nl = 0;
         if (es.gather.num_nodes > 0) {
             const GatherQuad *quads = reinterpret_cast<const GatherQuad *>(es.gather.nodes);
             const GatherQuad lo = quads[0], hi = quads[1];
             if (ray_box_all_axes(V3{(double)lo.x, (double)lo.y, (double)lo.z}, V3{(double)hi.x, (double)hi.y, (double)hi.z}, c.nee, c.inv_dir, 0.0)) {
-                RDR_STACK_AT(stk, sp) = gather_entry(lo, hi); sp++;
+                const int e = gather_entry(lo, hi);          // a one-leaf hierarchy: the root goes straight to the leaf list
+                if (e & kGatherLeafBit) { RDR_STACK_AT(lst, nl) = e; nl++; }
+                else { RDR_STACK_AT(stk, sp) = e; sp++; }
             }
         }
         auto promote = [&]() {              // this slot continues in the big lists
@@ -1083,7 +1106,7 @@ template <int NS> struct SecEdgeGatherN {
             gather_append_big(sh, heavy, cd);
         };
         long h_nodes = 0, h_edges = 0;
-        while (sp > 0 && h_nodes < budget) { h_nodes++; gather_pop<NS>(sc, es, c, stk, sp, emit, h_edges); }
+        gather_walk<NS>(sc, es, c, stk, sp, lst, nl, budget, emit, h_nodes, h_edges);
         if (sp > 0) {                        // budget spent: every entry left is a subtree for SecEdgeGatherSub
             if (heavy < 0) promote();
             bool lost = heavy >= sh.heavy_cap;
@@ -1112,11 +1135,12 @@ template <int NS> struct SecEdgeGatherSub {
         const int idx = slots[sh.heavy_slot[wk.heavy]];
         const GatherCtx c = gather_ctx(a, idx);
         RDR_STACK_DECL(int, stk, NS);
-        int sp = 0;
-        RDR_STACK_AT(stk, sp) = wk.entry; sp++;
+        RDR_STACK_DECL(int, lst, kGatherLeafBatch);
+        int sp = 0, nl = 0;
+        RDR_STACK_AT(stk, sp) = wk.entry; sp++;             // (only inner entries are ever left on a stack)
         auto emit = [&](const GatherCand &cd) { gather_append_big(sh, wk.heavy, cd); };
-        long h_edges = 0;
-        while (sp > 0) gather_pop<NS>(a.sc, a.es, c, stk, sp, emit, h_edges);
+        long pops = 0, h_edges = 0;
+        gather_walk<NS>(a.sc, a.es, c, stk, sp, lst, nl, (long)1 << 60, emit, pops, h_edges);
     }
 };
 struct SecEdgeGatherReplay {
