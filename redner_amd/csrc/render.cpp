@@ -522,7 +522,8 @@ struct Backward {
         const bool secondary_on = edges_on && scene.use_secondary_edges;
         SecEdgeArgs early_sa{};
         bool hoisted = false;
-        if (secondary_on && overlap && scene.diffuse_only && pcg_edge == nullptr && has_lights && B >= 2 && num_active[0].upper > 0) {
+        static const bool hoist_allowed = std::getenv("RDR_NO_HOIST") == nullptr;          // A/B
+        if (hoist_allowed && secondary_on && overlap && scene.diffuse_only && pcg_edge == nullptr && has_lights && B >= 2 && num_active[0].upper > 0) {
             int edim0 = 0;
             for (int d = B - 1; d >= 1; --d) if (num_active[d].upper > 0) edim0 += 4;
             early_sa = start_picks(0, edim0, true, true);

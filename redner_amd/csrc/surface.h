@@ -492,13 +492,26 @@ RDR_FN void scatter_trigrad(const ShapeD &sh, const GShape &gs, int tri, const T
     int vi[3] = {tv.i0, tv.i1, tv.i2};
     int ui[3] = {at.ui0, at.ui1, at.ui2};
     int ni[3] = {at.ni0, at.ni1, at.ni2};
+    // Lanes that share a triangle were summed by the caller (scatter_trigrad_wave) for the three biggest groups of the wave.
+    // On a finely tessellated shape what is left rarely shares an address: plain atomics.  On a low-poly shape (a wall: two
+    // triangles, four vertices) the left-over lanes still pile onto a handful of addresses, so they keep the per-address search
+    // of accum() (without it the bounce adjoint of the config-5 stand-in, six bounces among two-sided walls, is 25 % slower).
+    if (sh.num_triangles >= 512) {
 #pragma unroll
-    // (lanes that share a triangle were summed by the caller, scatter_trigrad_wave; what is left rarely shares an address)
-    for (int k = 0; k < 3; ++k) {       // must unroll: dynamic indexing would push the TriGrad into scratch
-        accum3_plain(gs.vertices + 3 * vi[k], g.p[k]);
-        if (!plain && sh.uvs && gs.uvs) { accum_plain(gs.uvs + 2 * ui[k], g.uv[k].x); accum_plain(gs.uvs + 2 * ui[k] + 1, g.uv[k].y); }
-        if (sh.normals && gs.normals) accum3_plain(gs.normals + 3 * ni[k], g.n[k]);
-        if (!plain && sh.colors && gs.colors) accum3_plain(gs.colors + 3 * vi[k], g.c[k]);
+        for (int k = 0; k < 3; ++k) {       // must unroll: dynamic indexing would push the TriGrad into scratch
+            accum3_plain(gs.vertices + 3 * vi[k], g.p[k]);
+            if (!plain && sh.uvs && gs.uvs) { accum_plain(gs.uvs + 2 * ui[k], g.uv[k].x); accum_plain(gs.uvs + 2 * ui[k] + 1, g.uv[k].y); }
+            if (sh.normals && gs.normals) accum3_plain(gs.normals + 3 * ni[k], g.n[k]);
+            if (!plain && sh.colors && gs.colors) accum3_plain(gs.colors + 3 * vi[k], g.c[k]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        accum3(gs.vertices + 3 * vi[k], g.p[k]);
+        if (!plain && sh.uvs && gs.uvs) { accum(gs.uvs + 2 * ui[k], g.uv[k].x); accum(gs.uvs + 2 * ui[k] + 1, g.uv[k].y); }
+        if (sh.normals && gs.normals) accum3(gs.normals + 3 * ni[k], g.n[k]);
+        if (!plain && sh.colors && gs.colors) accum3(gs.colors + 3 * vi[k], g.c[k]);
     }
 }
 
