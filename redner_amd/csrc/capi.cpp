@@ -96,6 +96,11 @@ int rdr_debug_dump_edges(const rdr_scene *scene, const char *path) {
     const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
     FILE *f = fopen(path, "w");
     if (!f) return 1;
+    {
+        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+        exec::select_device(1, s.gpu_index);
+        try { s.edge_data(); } catch (const std::exception &e) { set_error(e.what()); fclose(f); return 1; }
+    }
     if (!s.edges) { fprintf(f, "edges 0\n"); fclose(f); return 0; }
     const rdr::EdgeData &ed = *s.edges;
     fprintf(f, "edges %d\n", (int)ed.edges.size());

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 
 namespace rdr {
 
@@ -151,6 +152,7 @@ struct TreeBuilder {
     std::vector<int> ids;               // edge ids of this tree, Morton-sorted
     std::vector<uint64_t> codes;
     std::vector<EdgeNode> nodes;        // [internal | leaves]
+    std::vector<int> leaves_below;      // per node: leaves in its subtree (kept current by the treelet pass)
     int n = 0, n_internal = 0;
 
     TreeBuilder(bool is3d_, const ShapeD *shapes_, const std::vector<EdgeD> &edges_, const std::vector<Box6> &bounds_)
@@ -209,13 +211,33 @@ struct TreeBuilder {
         }
         });
         timer.lap("codes");
-        // stable sort of (code, id) by code
-        std::vector<int> order(n);
-        for (int i = 0; i < n; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return codes[a] < codes[b]; });
-        std::vector<int> sid(n); std::vector<uint64_t> scode(n);
-        for (int i = 0; i < n; ++i) { sid[i] = ids[order[i]]; scode[i] = codes[order[i]]; }
-        ids.swap(sid); codes.swap(scode);
+        // stable sort of (code, id) by code.  (code, position before the sort) is a unique key, so any comparison sort of
+        // those records gives the stable order: four runs sorted on pool threads, then merged
+        {
+            struct Rec { uint64_t code; int pos, id; };
+            std::vector<Rec> recs(n);
+            for (int i = 0; i < n; ++i) recs[i] = Rec{codes[i], i, ids[i]};
+            auto before = [](const Rec &a, const Rec &b) { return a.code != b.code ? a.code < b.code : a.pos < b.pos; };
+            if (n >= 8192) {
+                const int q1 = n / 4, q2 = n / 2, q3 = q2 + n / 4;
+                {
+                    auto j1 = hostpool::run([&] { std::sort(recs.begin(), recs.begin() + q1, before); });
+                    auto j2 = hostpool::run([&] { std::sort(recs.begin() + q1, recs.begin() + q2, before); });
+                    auto j3 = hostpool::run([&] { std::sort(recs.begin() + q2, recs.begin() + q3, before); });
+                    std::sort(recs.begin() + q3, recs.end(), before);
+                    j1.wait(); j2.wait(); j3.wait();
+                }
+                {
+                    auto j1 = hostpool::run([&] { std::inplace_merge(recs.begin(), recs.begin() + q1, recs.begin() + q2, before); });
+                    std::inplace_merge(recs.begin() + q2, recs.begin() + q3, recs.end(), before);
+                    j1.wait();
+                }
+                std::inplace_merge(recs.begin(), recs.begin() + q2, recs.end(), before);
+            } else {
+                std::sort(recs.begin(), recs.end(), before);
+            }
+            for (int i = 0; i < n; ++i) { ids[i] = recs[i].id; codes[i] = recs[i].code; }
+        }
 
         timer.lap("sort");
         n_internal = std::max(n - 1, 1);
@@ -261,7 +283,7 @@ struct TreeBuilder {
         timer.lap("radix tree");
         // leaves + bottom-up bounds / weighted length
         std::vector<int> counter(n_internal + n, 0);
-        std::vector<int> leaves_below(n_internal + n, 1);
+        leaves_below.assign(n_internal + n, 1);
         parallel_chunks(n, 2048, [&](int begin, int end) {
             for (int i = begin; i < end; ++i) {
                 EdgeNode &lf = nodes[leaf_ref(i)];
@@ -273,11 +295,13 @@ struct TreeBuilder {
                 lf.edge_id = ids[i];
             }
         });
-        for (int i = 0; i < n; ++i) {
+        // (arrival counters: whoever reaches a node second finds both children complete and carries on upwards)
+        parallel_chunks(n, 1024, [&](int begin, int end) {
+        for (int i = begin; i < end; ++i) {
             EdgeNode &lf = nodes[leaf_ref(i)];
             int cur = lf.parent;
             while (cur >= 0) {
-                if (++counter[cur] == 1) break;       // first arrival waits for the sibling
+                if (__atomic_fetch_add(&counter[cur], 1, __ATOMIC_ACQ_REL) == 0) break;       // first arrival waits for the sibling
                 EdgeNode &nd = nodes[cur];
                 merge_children(nd, nodes[nd.child0], nodes[nd.child1]);
                 nd.wlen = nodes[nd.child0].wlen + nodes[nd.child1].wlen;
@@ -285,6 +309,7 @@ struct TreeBuilder {
                 cur = nd.parent;
             }
         }
+        });
         if (n == 1) { nodes[0] = nodes[leaf_ref(0)]; }     // single primitive: the root is a copy of the leaf
 
         // treelet optimisation, bottom-up: a node is restructured once both child subtrees are done
@@ -293,16 +318,16 @@ struct TreeBuilder {
         // below the top levels are independent jobs.
         timer.lap("bounds");
         for (int i = 0; i < n; ++i) nodes[leaf_ref(i)].cost = area(nodes[leaf_ref(i)]);
-        if (n > 1) optimize_subtree(0, 0, leaves_below);
+        if (n > 1) optimize_subtree(0, 0);
         timer.lap("treelets");
     }
 
-    void optimize_subtree(int node, int depth, const std::vector<int> &leaves_below) {
+    void optimize_subtree(int node, int depth) {
         if (nodes[node].edge_id != -1) return;
         const int c0 = nodes[node].child0, c1 = nodes[node].child1;
-        if (depth < 6 && leaves_below[node] >= 2048) {
-            auto job = hostpool::run([&] { optimize_subtree(c0, depth + 1, leaves_below); });
-            optimize_subtree(c1, depth + 1, leaves_below);
+        if (depth < 24 && leaves_below[node] >= 512) {          // (a node's leaf set does not change when its subtree is restructured)
+            auto job = hostpool::run([&] { optimize_subtree(c0, depth + 1); });
+            optimize_subtree(c1, depth + 1);
             job.wait();
         } else {
             optimize_sequential(c0);
@@ -342,6 +367,7 @@ struct TreeBuilder {
         merge_children(nd, nodes[nd.child0], nodes[nd.child1]);
         nd.wlen = nodes[nd.child0].wlen + nodes[nd.child1].wlen;
         nd.cost = area(nd) + nodes[nd.child0].cost + nodes[nd.child1].cost;
+        leaves_below[node] = leaves_below[nd.child0] + leaves_below[nd.child1];
     }
 
     struct Treelet {
@@ -432,7 +458,11 @@ struct TreeBuilder {
 
 void delete_edge_data(EdgeData *e) { delete e; }
 
-EdgeData *build_edge_data(Scene &scene) {
+EdgeData *compute_edge_data(const Scene &scene) {
+    // one build at a time: the topology caches below are process-wide, and builds of different Scenes may be in flight
+    // together now that they run beside the caller (scene.cpp: create_scene)
+    static std::mutex build_lock;
+    std::lock_guard<std::mutex> build_guard(build_lock);
     PhaseTimer timer("edge build");
     std::unique_ptr<EdgeData> ed(new EdgeData());
     const int ns = (int)scene.shapes.size();
@@ -579,35 +609,38 @@ EdgeData *build_edge_data(Scene &scene) {
         }
         });
         for (int i = 0; i < ne; ++i) (is_sil[i] ? cs_ids : ncs_ids).push_back(i);
-        // mean absolute deviation of the endpoints -> billboard half-width
-        std::vector<int> all_ids(cs_ids);
-        all_ids.insert(all_ids.end(), ncs_ids.begin(), ncs_ids.end());
-        V3 mean = v3(0);
-        for (int id : all_ids) {
-            F3 a = edge_v0f(shapes, edges[id]), b = edge_v1f(shapes, edges[id]);
-            mean += to_v3(F3{a.x + b.x, a.y + b.y, a.z + b.z});
-        }
-        mean = mean / (2. * double(ne));
-        V3 mad = v3(0);
-        for (int id : all_ids) {
-            F3 a = edge_v0f(shapes, edges[id]), b = edge_v1f(shapes, edges[id]);
-            V3 aa = V3{fabs(a.x - mean.x), fabs(a.y - mean.y), fabs(a.z - mean.z)};
-            V3 bb = V3{fabs(b.x - mean.x), fabs(b.y - mean.y), fabs(b.z - mean.z)};
-            mad += aa + bb;
-        }
-        mad = mad / double(ne);
-        ed->edge_bounds_expand = 0.01f * len(mad);
-
         timer.lap("pmf, bounds, split");
         // The billboard hierarchy of the NEE-mode gather (stages_edge.h: SecEdgeGatherN) needs only the edge bounds and
-        // the billboard half-width: it is built on another thread while this one builds the two reference hierarchies.
+        // the billboard half-width (two running sums in the reference's order: sequential): both are computed on another
+        // thread while this one builds the two reference hierarchies.
         // Boxes: each edge's own spatial bounds grown by the half-width (rounded outwards; the builder pads on top).
         // (the billboard hierarchy only has to be conservative: with the edge list of the previous Scene its topology is kept
         //  and its boxes are refitted; rebuilt when the inner surface area has grown by more than 30 %)
         struct GatherCache { std::vector<EdgeD> edges; rt::BvhHost bvh; };
         static GatherCache *gather_cache = new GatherCache();            // guarded by the API lock (capi.cpp)
         rt::BvhHost gather_built;
-        auto gather_job = hostpool::run([&gather_built, &bounds, &edges, ne, e = ed->edge_bounds_expand] {
+        double &expand_out = ed->edge_bounds_expand;
+        auto gather_job = hostpool::run([&gather_built, &bounds, &edges, &cs_ids, &ncs_ids, shapes, ne, &expand_out] {
+            // mean absolute deviation of the endpoints -> billboard half-width
+            std::vector<int> all_ids(cs_ids);
+            all_ids.insert(all_ids.end(), ncs_ids.begin(), ncs_ids.end());
+            V3 mean = v3(0);
+            for (int id : all_ids) {
+                F3 a = edge_v0f(shapes, edges[id]), b = edge_v1f(shapes, edges[id]);
+                mean += to_v3(F3{a.x + b.x, a.y + b.y, a.z + b.z});
+            }
+            mean = mean / (2. * double(ne));
+            V3 mad = v3(0);
+            for (int id : all_ids) {
+                F3 a = edge_v0f(shapes, edges[id]), b = edge_v1f(shapes, edges[id]);
+                V3 aa = V3{fabs(a.x - mean.x), fabs(a.y - mean.y), fabs(a.z - mean.z)};
+                V3 bb = V3{fabs(b.x - mean.x), fabs(b.y - mean.y), fabs(b.z - mean.z)};
+                mad += aa + bb;
+            }
+            mad = mad / double(ne);
+            const double e = 0.01f * len(mad);
+            expand_out = e;
+
             std::vector<float> boxes((size_t)6 * ne);
             for (int i = 0; i < ne; ++i) {
                 const double lo[3] = {bounds[i].p_min.x - e, bounds[i].p_min.y - e, bounds[i].p_min.z - e};
@@ -642,30 +675,47 @@ EdgeData *build_edge_data(Scene &scene) {
         // its position in that order, which is all the order-free gather needs to replay the reservoir.
         std::vector<int> leaf_rank(ne, 0);
         std::vector<double> leaf_dx((size_t)2 * ne, 0.0);
-        auto walk_tree = [&](const std::vector<EdgeNode> &tree, bool hough, int first_rank) {
-            int max_depth = 0, rank = first_rank;
-            if (tree.empty()) return max_depth;
-            const double inf = std::numeric_limits<double>::infinity();
-            std::vector<std::pair<int, int>> todo;
-            todo.reserve(256);
-            todo.push_back({0, 1});
-            while (!todo.empty()) {
-                auto [node, depth] = todo.back();
-                todo.pop_back();
-                max_depth = std::max(max_depth, depth);
-                const EdgeNode &nd = tree[node];
-                if (nd.edge_id != -1) {
-                    leaf_rank[nd.edge_id] = rank++;
-                    leaf_dx[2 * (size_t)nd.edge_id] = hough ? nd.d_min.x : -inf;
-                    leaf_dx[2 * (size_t)nd.edge_id + 1] = hough ? nd.d_max.x : inf;
-                } else if (nd.child0 >= 0) { todo.push_back({nd.child0, depth + 1}); todo.push_back({nd.child1, depth + 1}); }
+        // (subtrees are independent once their first rank is known: child 1's leaves come first, then child 0's)
+        struct Walker {
+            const std::vector<EdgeNode> &tree; const std::vector<int> &below; bool hough;
+            std::vector<int> &leaf_rank; std::vector<double> &leaf_dx;
+            int serial(int top, int top_depth, int rank) const {
+                const double inf = std::numeric_limits<double>::infinity();
+                int max_depth = 0;
+                std::vector<std::pair<int, int>> todo;
+                todo.reserve(256);
+                todo.push_back({top, top_depth});
+                while (!todo.empty()) {
+                    auto [node, depth] = todo.back();
+                    todo.pop_back();
+                    max_depth = std::max(max_depth, depth);
+                    const EdgeNode &nd = tree[node];
+                    if (nd.edge_id != -1) {
+                        leaf_rank[nd.edge_id] = rank++;
+                        leaf_dx[2 * (size_t)nd.edge_id] = hough ? nd.d_min.x : -inf;
+                        leaf_dx[2 * (size_t)nd.edge_id + 1] = hough ? nd.d_max.x : inf;
+                    } else if (nd.child0 >= 0) { todo.push_back({nd.child0, depth + 1}); todo.push_back({nd.child1, depth + 1}); }
+                }
+                return max_depth;
             }
-            return max_depth;
+            int walk(int node, int depth, int rank) const {
+                const EdgeNode &nd = tree[node];
+                if (nd.edge_id != -1 || nd.child0 < 0 || below[node] < 1024 || depth > 24) return serial(node, depth, rank);
+                int d0 = 0;
+                auto job = hostpool::run([&] { d0 = walk(nd.child0, depth + 1, rank + below[nd.child1]); });
+                const int d1 = walk(nd.child1, depth + 1, rank);
+                job.wait();
+                return std::max(d0, d1);
+            }
+        };
+        auto walk_tree = [&](const std::vector<EdgeNode> &tree, const std::vector<int> &below, bool hough, int first_rank) {
+            if (tree.empty()) return 0;
+            return Walker{tree, below, hough, leaf_rank, leaf_dx}.walk(0, 1, first_rank);
         };
         // the 6-D tree is walked first, so the 3-D tree's ranks start after its leaves
         int cs_depth_value = 0;
-        auto cs_depth = hostpool::run([&] { cs_depth_value = walk_tree(ed->cs_nodes, false, ed->ncs_leaves); });
-        const int ncs_depth_value = walk_tree(ed->ncs_nodes, true, 0);
+        auto cs_depth = hostpool::run([&] { cs_depth_value = walk_tree(ed->cs_nodes, cs.leaves_below, false, ed->ncs_leaves); });
+        const int ncs_depth_value = walk_tree(ed->ncs_nodes, ncs.leaves_below, true, 0);
         cs_depth.wait();
         const int depths[2] = {ncs_depth_value, cs_depth_value};
         for (int max_depth : depths) {
@@ -702,42 +752,29 @@ EdgeData *build_edge_data(Scene &scene) {
         timer.lap("gather hierarchy");
     }
 
-    // ---- device view ----
-    auto up = [&](const void *src, size_t bytes) -> void * {
-        void *p = exec::pool_alloc(bytes);
-        scene.owned.push_back(p);
-        if (bytes) exec::upload_async(p, src, bytes);          // create_scene() flushes the batch
-        return p;
-    };
-    EdgeSceneD &d = ed->d;
-    d.num_edges = ne;
-    d.edges = (const EdgeD *)up(edges.data(), sizeof(EdgeD) * edges.size());
-    timer.lap("copy: edges");
+    // ---- what the device will hold, still on the host (publish_edge_data copies it over) ----
     {
         // per-edge geometry records, from the host copies of the shapes
-        std::vector<EdgeGeom> geom(edges.size());
-        std::vector<ShapeD> hs(scene.shapes.begin(), scene.shapes.end());
-        for (size_t i = 0; i < hs.size(); ++i) { hs[i].geom = nullptr; hs[i].vertices = scene.h_vertices[i].data(); hs[i].indices = scene.h_indices[i].data(); }
+        std::vector<EdgeGeom> &geom = ed->geom;
+        geom.resize(edges.size());
         parallel_chunks((int)edges.size(), 4096, [&](int begin, int end) {
         for (int i = begin; i < end; ++i) {
             const EdgeD &e = edges[i];
             EdgeGeom &g = geom[i];
-            F3 a = edge_v0f(hs.data(), e), b = edge_v1f(hs.data(), e);
-            F3 o0 = e.f0 != -1 ? edge_opp0f(hs.data(), e) : a, o1 = e.f1 != -1 ? edge_opp1f(hs.data(), e) : b;
+            F3 a = edge_v0f(shapes, e), b = edge_v1f(shapes, e);
+            F3 o0 = e.f0 != -1 ? edge_opp0f(shapes, e) : a, o1 = e.f1 != -1 ? edge_opp1f(shapes, e) : b;
             g.v0[0] = a.x; g.v0[1] = a.y; g.v0[2] = a.z; g.v1[0] = b.x; g.v1[1] = b.y; g.v1[2] = b.z;
             g.o0[0] = o0.x; g.o0[1] = o0.y; g.o0[2] = o0.z; g.o1[0] = o1.x; g.o1[1] = o1.y; g.o1[2] = o1.z;
             g.f0 = e.f0; g.f1 = e.f1; g.has_normals = scene.shapes[e.shape_id].normals != nullptr; g.pad = 0;
         }
         });
-        d.geom = (const EdgeGeom *)up(geom.data(), sizeof(EdgeGeom) * geom.size());
     }
-    timer.lap("copy: edge geometry");
-    d.primary_pmf = ed->primary_pmf.empty() ? nullptr : (const double *)up(ed->primary_pmf.data(), sizeof(double) * ne);
-    d.primary_cdf = ed->primary_cdf.empty() ? nullptr : (const double *)up(ed->primary_cdf.data(), sizeof(double) * ne);
+    timer.lap("edge geometry");
     // [internal | leaves]: n - 1 interior nodes first, then the n leaves (see TreeBuilder)
-    auto fatten = [&](const std::vector<EdgeNode> &nodes, int num_leaves, int tree_bit, int &root) -> const EdgeNodeP * {
+    auto fatten = [&](const std::vector<EdgeNode> &nodes, int num_leaves, int tree_bit, int &root, std::vector<EdgeNodeP> &out) {
         root = kNoEdgeTree;
-        if (nodes.empty()) return nullptr;
+        out.clear();
+        if (nodes.empty()) return;
         const int num_inner = (int)nodes.size() - num_leaves;
         auto to_f32 = [](double x) {
             float f = (float)x;
@@ -746,8 +783,8 @@ EdgeData *build_edge_data(Scene &scene) {
         };
         auto ref_of = [&](int idx) { return idx >= num_inner ? ~nodes[idx].edge_id : idx; };
         root = nodes[0].edge_id != -1 ? ~nodes[0].edge_id : (0 | tree_bit);
-        if (num_inner <= 0) return nullptr;               // a single edge: the root reference is the leaf
-        std::vector<EdgeNodeP> out(num_inner);
+        if (num_inner <= 0) return;               // a single edge: the root reference is the leaf
+        out.resize(num_inner);
         parallel_chunks(num_inner, 4096, [&](int begin, int end) {
         for (int i = begin; i < end; ++i) {
             const EdgeNode &n = nodes[i];
@@ -764,28 +801,45 @@ EdgeData *build_edge_data(Scene &scene) {
             }
         }
         });
-        return (const EdgeNodeP *)up(out.data(), sizeof(EdgeNodeP) * out.size());
     };
-    timer.lap("copy: pmf, cdf");
-    d.cs_nodes = fatten(ed->cs_nodes, ed->cs_leaves, 0, d.cs_root);
-    timer.lap("copy: 3-D nodes");
-    d.ncs_nodes = fatten(ed->ncs_nodes, ed->ncs_leaves, kEdgeTreeBit, d.ncs_root);
-    timer.lap("device copies");
+    fatten(ed->cs_nodes, ed->cs_leaves, 0, ed->d.cs_root, ed->cs_fat);
+    fatten(ed->ncs_nodes, ed->ncs_leaves, kEdgeTreeBit, ed->d.ncs_root, ed->ncs_fat);
+    timer.lap("sampler records");
+    ed->d.num_edges = ne;
+    ed->d.edge_bounds_expand = ed->edge_bounds_expand;
+    ed->d.max_stack = ed->max_stack;
+    ed->d.cam_org = cam_org;
+    ed->d.ltc = scene.ltc_table;
+    return ed.release();
+}
+
+// Device copies of what compute_edge_data prepared (queued on the calling thread's stream; the caller flushes).
+void publish_edge_data(Scene &scene, EdgeData &ed) {
+    PhaseTimer timer("edge publish");
+    auto up = [&](const void *src, size_t bytes) -> void * {
+        void *p = exec::pool_alloc(bytes);
+        scene.owned.push_back(p);
+        if (bytes) exec::upload_async(p, src, bytes);
+        return p;
+    };
+    EdgeSceneD &d = ed.d;
+    const size_t ne = ed.edges.size();
+    d.edges = (const EdgeD *)up(ed.edges.data(), sizeof(EdgeD) * ne);
+    d.geom = (const EdgeGeom *)up(ed.geom.data(), sizeof(EdgeGeom) * ed.geom.size());
+    d.primary_pmf = ed.primary_pmf.empty() ? nullptr : (const double *)up(ed.primary_pmf.data(), sizeof(double) * ne);
+    d.primary_cdf = ed.primary_cdf.empty() ? nullptr : (const double *)up(ed.primary_cdf.data(), sizeof(double) * ne);
+    d.cs_nodes = ed.cs_fat.empty() ? nullptr : (const EdgeNodeP *)up(ed.cs_fat.data(), sizeof(EdgeNodeP) * ed.cs_fat.size());
+    d.ncs_nodes = ed.ncs_fat.empty() ? nullptr : (const EdgeNodeP *)up(ed.ncs_fat.data(), sizeof(EdgeNodeP) * ed.ncs_fat.size());
     d.gather = rt::BvhD{nullptr, nullptr, nullptr, 0, 0, 2};
     d.gleaf = nullptr;
-    if (!ed->gather.nodes.empty()) {
-        d.gather.nodes = (const rt::Node *)up(ed->gather.nodes.data(), sizeof(rt::Node) * ed->gather.nodes.size());
-        d.gather.num_nodes = (int)ed->gather.nodes.size();
-        d.gather.num_tris = (int)ed->gleaf.size();
-        d.gather.stack_need = ed->gather.depth + 2;
-        d.gleaf = (const GatherLeaf *)up(ed->gleaf.data(), sizeof(GatherLeaf) * ed->gleaf.size());
+    if (!ed.gather.nodes.empty()) {
+        d.gather.nodes = (const rt::Node *)up(ed.gather.nodes.data(), sizeof(rt::Node) * ed.gather.nodes.size());
+        d.gather.num_nodes = (int)ed.gather.nodes.size();
+        d.gather.num_tris = (int)ed.gleaf.size();
+        d.gather.stack_need = ed.gather.depth + 2;
+        d.gleaf = (const GatherLeaf *)up(ed.gleaf.data(), sizeof(GatherLeaf) * ed.gleaf.size());
     }
-    timer.lap("copy: gather");
-    d.edge_bounds_expand = ed->edge_bounds_expand;
-    d.max_stack = ed->max_stack;
-    d.cam_org = cam_org;
-    d.ltc = scene.ltc_table;
-    return ed.release();
+    timer.lap("device copies");
 }
 
 } // namespace rdr

@@ -219,9 +219,14 @@ struct EdgeData {
     double edge_bounds_expand = 0;
     rt::BvhHost gather;            // see EdgeSceneD::gather
     std::vector<GatherLeaf> gleaf;
-    EdgeSceneD d;            // device view
+    std::vector<EdgeGeom> geom;                  // per edge, what EdgeSceneD::geom will hold
+    std::vector<EdgeNodeP> cs_fat, ncs_fat;      // the samplers' interior-node records (EdgeSceneD::cs_nodes / ncs_nodes)
+    EdgeSceneD d;            // device view (pointers valid after publish_edge_data)
 };
-EdgeData *build_edge_data(Scene &scene);
+// The build in two steps so that the first can run beside the caller (scene.cpp): everything computed on the host, reading
+// only the Scene's host mirrors; then the device copies, queued on the calling thread's stream.
+EdgeData *compute_edge_data(const Scene &scene);
+void publish_edge_data(Scene &scene, EdgeData &ed);
 void delete_edge_data(EdgeData *e);
 
 } // namespace rdr

@@ -15,6 +15,10 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <algorithm>
+#include <cstdlib>
+#include <pthread.h>
+#include <sched.h>
 
 namespace hostpool {
 
@@ -51,8 +55,9 @@ public:
         {
             std::lock_guard<std::mutex> lk(m_);
             q_.push_back(s);
+            queued_.fetch_add(1, std::memory_order_release);
         }
-        cv_.notify_one();
+        if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_one();
         return Job(this, std::move(s));
     }
     int threads() const { return (int)workers_.size(); }
@@ -62,7 +67,22 @@ private:
         unsigned hw = std::thread::hardware_concurrency();
         int n = (int)(hw ? hw : 8) - 1;
         n = n < 1 ? 1 : (n > 31 ? 31 : n);
-        for (int i = 0; i < n; ++i) workers_.emplace_back([this] { loop(); }), workers_.back().detach();
+        if (const char *e = std::getenv("RDR_POOL_THREADS")) n = std::max(1, std::min(63, std::atoi(e)));
+        // RDR_POOL_PIN=k: workers restricted to the k-aligned block of k CPUs the creating thread runs on (phases hand their
+        // data from thread to thread: cores that share a last-level cache pass it on without leaving the cache)
+        int pin = 0;
+        if (const char *e = std::getenv("RDR_POOL_PIN")) pin = std::atoi(e);
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (pin > 0) {
+            const int here = sched_getcpu();
+            if (here >= 0) { const int base = here - here % pin; for (int c = base; c < base + pin; ++c) CPU_SET(c, &set); } else pin = 0;
+        }
+        for (int i = 0; i < n; ++i) {
+            workers_.emplace_back([this] { loop(); });
+            if (pin > 0) (void)pthread_setaffinity_np(workers_.back().native_handle(), sizeof(set), &set);
+            workers_.back().detach();
+        }
     }
     static void execute(State &s) {
         try { s.fn(); } catch (...) { s.error = std::current_exception(); }
@@ -76,43 +96,58 @@ private:
             if (q_.empty()) return false;
             s = std::move(q_.back());          // newest first: the job a waiter needs was queued last
             q_.pop_back();
+            queued_.fetch_sub(1, std::memory_order_release);
         }
         execute(*s);
-        done_cv_.notify_all();
         return true;
     }
     void help_until(State &want) {
+        // the jobs of a build last tens of microseconds: a waiter polls (and helps) instead of sleeping
+        int idle = 0;
         while (!want.done.load(std::memory_order_acquire)) {
-            if (try_one()) continue;
-            std::unique_lock<std::mutex> lk(m_);
-            done_cv_.wait_for(lk, std::chrono::microseconds(50), [&] { return want.done.load(std::memory_order_acquire) || !q_.empty(); });
+            if (queued_.load(std::memory_order_acquire) > 0 && try_one()) { idle = 0; continue; }
+            if (++idle < 20000) { relax(); continue; }
+            std::this_thread::yield();
         }
     }
     void loop() {
         for (;;) {
             std::shared_ptr<State> s;
+            // A build is a burst of short jobs a few microseconds apart: after a job a worker polls for the next one for a
+            // while (~100 us) before it goes to sleep on the condition variable -- waking a sleeper costs more than most jobs.
+            for (int spin = 0; spin < 4000 && queued_.load(std::memory_order_acquire) == 0; ++spin) relax();
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return !q_.empty(); });
+                if (q_.empty()) {
+                    sleepers_.fetch_add(1, std::memory_order_acq_rel);
+                    cv_.wait(lk, [&] { return !q_.empty(); });
+                    sleepers_.fetch_sub(1, std::memory_order_acq_rel);
+                }
                 s = std::move(q_.front());
                 q_.pop_front();
+                queued_.fetch_sub(1, std::memory_order_release);
             }
             execute(*s);
-            done_cv_.notify_all();
         }
     }
+    static void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
     std::mutex m_;
-    std::condition_variable cv_, done_cv_;
+    std::atomic<int> queued_{0}, sleepers_{0};
+    std::condition_variable cv_;
     std::deque<std::shared_ptr<State>> q_;
     std::vector<std::thread> workers_;
 };
 
 template <class F> inline Pool::Job run(F f) { return Pool::get().run(std::move(f)); }
 
-// f(begin, end) over [0, n) in up to 16 chunks of at least `grain` items; the caller takes the first chunk.
+// f(begin, end) over [0, n) in up to 32 chunks of at least `grain` items; the caller takes the first chunk.
 template <class F> inline void parallel_chunks(int n, int grain, F f) {
     int chunks = (n + grain - 1) / grain;
-    if (chunks > 16) chunks = 16;
+    if (chunks > 32) chunks = 32;
     if (chunks <= 1) { if (n > 0) f(0, n); return; }
     std::vector<Pool::Job> jobs;
     jobs.reserve((size_t)chunks - 1);

@@ -628,6 +628,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     if (opt.sampler_type != RDR_SAMPLER_SOBOL && opt.sampler_type != RDR_SAMPLER_INDEPENDENT)
         throw std::runtime_error("render: unknown sampler type");
     if (d_image && !d_scene) throw std::runtime_error("render: d_rendered_image given without d_scene");
+    if (d_image) scene.edge_data();          // joins the edge build create_scene() started (scene.h); a forward render never waits for it
     const CameraD &cam = scene.d.cam;
     const int P = (cam.vp_x1 - cam.vp_x0) * (cam.vp_y1 - cam.vp_y0);
     if (P <= 0) return;

@@ -48,7 +48,18 @@ M3 m3_from(const float *p) { M3 m; for (int i = 0; i < 3; ++i) for (int j = 0; j
 
 } // namespace
 
+const EdgeData *Scene::edge_data() const {
+    if (edge_build.valid()) {
+        EdgeData *built = edge_build.get();             // rethrows what the build threw
+        Scene &self = const_cast<Scene &>(*this);       // the device copies belong to this Scene's allocations
+        try { publish_edge_data(self, *built); exec::upload_flush(); } catch (...) { delete_edge_data(built); throw; }
+        edges = built;
+    }
+    return edges;
+}
+
 Scene::~Scene() {
+    if (edge_build.valid()) { try { edges = edge_build.get(); } catch (...) {} }
     delete_edge_data(edges);
     for (void *p : owned) exec::pool_free(p);
 }
@@ -359,7 +370,12 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
 
     timer.lap("device copies");
     // ---- edge sampling structures ----
-    if (s.use_primary_edges || s.use_secondary_edges) s.edges = build_edge_data(s);
+    if (s.use_primary_edges || s.use_secondary_edges) {
+        static const bool sync_edges = std::getenv("RDR_SYNC_EDGES") != nullptr;
+        const Scene *sc = &s;
+        s.edge_build = std::async(std::launch::async, [sc] { return compute_edge_data(*sc); });
+        if (sync_edges || timer.on) s.edge_data();
+    }
     timer.lap("edge structures");
     {
         bvh_job.wait();
