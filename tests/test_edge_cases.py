@@ -144,3 +144,51 @@ np.savez(sys.argv[1], image=img, grad=grad)
     a, b = outs['refit']['grad'].astype(np.float64), outs['fresh']['grad'].astype(np.float64)
     assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b)
     assert np.abs(b).sum() > 0
+
+
+def test_edge_build_beside_the_caller_equals_build_in_place(hostsim_backend, tmp_path):
+    """create_scene() starts the edge structures' build on its own thread and the first gradient render joins it (scene.h).
+    Covered here: Scenes created back to back (their builds queue up on the build lock), gradient renders in the other order,
+    a Scene dropped without ever being rendered backward (the destructor joins), and equality -- bit for bit on the images,
+    fp32-atomics noise on the gradients -- with a process that builds inside create_scene() (RDR_SYNC_EDGES=1)."""
+    import subprocess
+    import sys
+    from conftest import HOSTSIM_LIB, ROOT
+    code = r'''
+import gc, os, sys
+sys.path[:0] = [%r, %r + '/tests']
+import numpy as np, torch
+from redner_amd import _capi
+_capi.load(%r)
+from redner_amd import redner
+from redner_amd.render_pytorch import RenderFunction
+import scenes
+dev = torch.device('cpu')
+def make(res, shift):
+    sc = scenes.bunny_box(dev, (res, res))
+    v = (sc.shapes[6].vertices.detach() + shift).requires_grad_(True)
+    sc.shapes[6].vertices = v
+    args = RenderFunction.serialize_scene(sc, 2, 2, sampler_type=redner.SamplerType.sobol, device=dev, backend=redner)
+    return v, args
+va, a = make(24, 0.0)
+vb, b = make(32, 0.05)
+vc, c = make(16, 0.1)
+img_a = RenderFunction.apply(1, *a)          # three Scenes alive, three builds in flight or queued
+img_b = RenderFunction.apply(2, *b)
+img_c = RenderFunction.apply(3, *c)
+del img_c, c; gc.collect()                   # never rendered backward: dropped with its build possibly still running
+img_b.sum().backward()
+img_a.sum().backward()
+np.savez(sys.argv[1], img_a=img_a.detach().numpy(), img_b=img_b.detach().numpy(), ga=va.grad.numpy(), gb=vb.grad.numpy())
+''' % (ROOT, ROOT, HOSTSIM_LIB)
+    outs = {}
+    for tag, env in (('beside', {}), ('in_place', {'RDR_SYNC_EDGES': '1'})):
+        out = str(tmp_path / (tag + '.npz'))
+        subprocess.check_call([sys.executable, '-c', code, out], env=dict(os.environ, **env), timeout=900)
+        outs[tag] = np.load(out)
+    for k in ('img_a', 'img_b'):
+        assert np.array_equal(outs['beside'][k], outs['in_place'][k])
+    for k in ('ga', 'gb'):
+        x, y = outs['beside'][k].astype(np.float64), outs['in_place'][k].astype(np.float64)
+        assert np.abs(y).sum() > 0
+        assert np.linalg.norm(x - y) <= 1e-6 * np.linalg.norm(y)
