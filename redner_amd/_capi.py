@@ -122,7 +122,8 @@ _lib_path = None
 def load(path=None):
     """Load the C-ABI library (default: the HIP build).  Raises RuntimeError when it is missing."""
     global _lib, _lib_path
-    path = path or DEFAULT_LIBRARY
+    # REDNER_AMD_LIB: another build of the same library (A/B of two builds inside one GPU session, tools/gpu_ab_builds.sh)
+    path = path or os.environ.get('REDNER_AMD_LIB') or DEFAULT_LIBRARY
     if not os.path.exists(path):
         raise RuntimeError(
             "redner_amd: native library %s not found. Build it with "

@@ -55,6 +55,31 @@ static __device__ unsigned long long g_replica_stride = 0;   // doubles between 
 static __device__ unsigned g_replica_mask = 0;               // replicas - 1 (power of two)
 constexpr int kAccumRounds = 3;                              // distinct addresses summed across the wave per call
 
+// Sum of x over the 64 lanes of a wave, returned in every lane; ALL lanes must be active.  Four data-parallel-primitive
+// steps inside each row of 16 lanes (swap neighbours, swap pairs, mirror the half row, mirror the row: after each the lane
+// holds the sum of a group twice as large) -- two v_mov_b32_dpp and one v_add_f64 per step, no LDS traffic, no address
+// arithmetic -- then the four row totals are read into scalar registers.  (__shfl_xor on a double is two ds_bpermute_b32
+// through the LDS crossbar per step, six steps.)
+__device__ inline double wave_sum(double x) {
+#define RDR_DPP_ADD(ctrl)                                                                                  \
+    {                                                                                                      \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xf, 0xf, true);         \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xf, 0xf, true);         \
+        x += __hiloint2double(hi_, lo_);                                                                   \
+    }
+    RDR_DPP_ADD(0xB1)        // quad_perm:[1,0,3,2]
+    RDR_DPP_ADD(0x4E)        // quad_perm:[2,3,0,1]
+    RDR_DPP_ADD(0x141)       // row_half_mirror
+    RDR_DPP_ADD(0x140)       // row_mirror
+#undef RDR_DPP_ADD
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 __device__ inline void accum(double *p, double v) {
     p += (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & g_replica_mask) * g_replica_stride;
     const unsigned long long act = __ballot(1);
@@ -73,8 +98,7 @@ __device__ inline void accum(double *p, double v) {
         if (__popcll(m) < 2) continue;        // a lone lane adds for itself below
         double s;
         if (act == ~0ull) {
-            s = same ? v : 0.0;
-            for (int x = 32; x >= 1; x >>= 1) s += __shfl_xor(s, x, 64);
+            s = wave_sum(same ? v : 0.0);
         } else {
             s = 0;
             unsigned long long mm = m;

@@ -518,7 +518,7 @@ RDR_FN void scatter_trigrad(const ShapeD &sh, const GShape &gs, int tri, const T
 // Wave-cooperative version for the adjoint kernels, called by EVERY lane of the stage at a convergent point
 // (shape < 0: nothing to add).  Lanes of a wave often hit the same triangle -- neighbouring pixels, the two triangles
 // of a wall -- and then add to the same 9..18 addresses; the three biggest same-triangle groups (>= 4 lanes) are
-// summed across the wave first (xor butterfly) and only their first lane issues the atomics.  Measured on the
+// summed across the wave first (exec.h: wave_sum) and only their first lane issues the atomics.  Measured on the
 // benchmark: AdjPrimary 0.90 -> 0.43 ms, AdjBounceScatter 0.94 -> 0.73 ms per launch.
 RDR_FN void scatter_trigrad_wave(const ShapeD *shapes, const GShape *gshapes, int shape, int tri, const TriGrad &g, bool plain) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -553,7 +553,7 @@ RDR_FN void scatter_trigrad_wave(const ShapeD *shapes, const GShape *gshapes, in
             }
             const bool any_n = __ballot(has_n) != 0, any_uv = __ballot(has_uv) != 0, any_c = __ballot(has_c) != 0;
             const int vi[3] = {tv.i0, tv.i1, tv.i2}, ui[3] = {at.ui0, at.ui1, at.ui2}, ni[3] = {at.ni0, at.ni1, at.ni2};
-#define RDR_WSUM(x) { double s_ = in ? (x) : 0.0; for (int sh_ = 32; sh_ >= 1; sh_ >>= 1) s_ += __shfl_xor(s_, sh_, 64); (x) = s_; }
+#define RDR_WSUM(x) { (x) = wave_sum(in ? (x) : 0.0); }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 V3 p = g.p[k];
@@ -611,9 +611,7 @@ RDR_FN void scatter_positions_wave(const ShapeD *shapes, const GShape *gshapes, 
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 V3 p = in ? pb[k] : V3{0.0, 0.0, 0.0};
-                for (int sh_ = 32; sh_ >= 1; sh_ >>= 1) {
-                    p.x += __shfl_xor(p.x, sh_, 64); p.y += __shfl_xor(p.y, sh_, 64); p.z += __shfl_xor(p.z, sh_, 64);
-                }
+                p.x = wave_sum(p.x); p.y = wave_sum(p.y); p.z = wave_sum(p.z);
                 if (lead) accum3(gv + 3 * vi[k], p);
             }
         }
