@@ -72,6 +72,7 @@ struct AdjBounceArgs {
 
 struct AdjBounceScatter {
     AdjBounceArgs a;
+    static constexpr int kMidBlocksPerCU = 2;          // 320 -> 256 registers (256 B of scratch), two waves per SIMD
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; a.adj.plain = 1; }
     RDR_FN void make_mid() { mid_scene(a.sc); a.nd = 3; a.radiance_dim = 0; }
     RDR_FN void operator()(int idx) const {
@@ -87,6 +88,14 @@ struct AdjBounceScatter {
         int bshape = vn.shape[p];
         TriGrad tg = trigrad_zero();          // gradient of the triangle hit by the continuation, scattered at the end
         int tg_shape = -1, tg_tri = -1;
+        // Order of the two halves (register pressure: the Surf adjoints are 35 doubles each): first everything that needs this
+        // vertex's surface point and accumulates into its adjoint sp_bar (the BSDF's adjoint); then sp_bar goes to the adjoint
+        // record -- all but its position, which the second half still changes -- and only then is the successor's adjoint point
+        // loaded (same record: read before it is overwritten) and pushed through the hit triangle's surface adjoint.
+        V3 dir_bar = v3(0);
+        bool through_hit = false;
+        double d2 = 0;
+        V3 wo = v3(0);
         if (bshape >= 0) {
             const ShapeD &bsh = sc.shapes[bshape];
             int btri = vn.tri[p];
@@ -95,10 +104,9 @@ struct AdjBounceScatter {
             Surf bp = surf_at(bsh, btri, load_ray(vn, p), wo_rd, tmp, !sc.no_diffs);
             V3 next_thr_bar = ld3(adj.thr, adj.n, p, 0);
             V3 next_dir_bar = ld3(adj.ray_dir, adj.n, p, 0);
-            Surf next_pt_bar = load_adj_point(adj, p);
             V3 dir = bp.position - pos;
-            double d2 = len_sq(dir);
-            V3 wo = dir / sqrt(d2);
+            d2 = len_sq(dir);
+            wo = dir / sqrt(d2);
             double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough);
             if (pdf_b > 0) {
                 V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
@@ -124,32 +132,22 @@ struct AdjBounceScatter {
                 V3 wi_bar = v3(0);
                 V3 wo_bar = next_dir_bar;
                 adj_bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough, f_bar, gm, sp_bar, wi_bar, wo_bar);
-                V3 dir_bar = wo_bar / sqrt(d2);
+                dir_bar = wo_bar / sqrt(d2);
                 double sd_bar = -sum(wo_bar * dir) / d2;
                 double d2_bar = 0.5f * sd_bar / sqrt(d2);
                 dir_bar += adj_len_sq(dir, d2_bar);
-                Surf bp_bar = next_pt_bar;
-                bp_bar.position += dir_bar;
-                DRay r_bar = dray_zero();
-                RayDiff rd_bar = raydiff_zero();
-                Ray br = make_ray(pos, wo);
-                adj_surf_at(bsh, btri, br, wo_rd, bp_bar, raydiff_zero(), r_bar, rd_bar, tg, !sc.no_diffs, sc.plain_materials != 0);
-                tg_shape = bshape; tg_tri = btri;
-                if (c.mrough > 0.01f) {
-                    sp_bar.position -= dir_bar;
-                    sp_bar.position += r_bar.org;
-                }
                 in_dir_bar -= wi_bar;
+                through_hit = true;
             }
         } else if (sc.envmap != nullptr) {
             // the BSDF ray reached the environment light (src/path_contribution.cpp:520-600); MIS weight and
             // pdf are treated as constants, nothing flows into the sampling procedure
-            V3 wo = load_ray(vn, p).dir;
-            double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo, c.mrough);
-            if (len_sq(wo) > 0 && pdf_b > 0) {
-                V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough);
-                V3 Le = envmap_eval(*sc.envmap, wo, raydiff_zero());
-                double pdf_nee = envmap_pdf(*sc.envmap, wo) * sc.light_pmf[sc.num_lights - 1];
+            V3 wo_e = load_ray(vn, p).dir;
+            double pdf_b = bsdf_pdf(*c.mat, c.sp, c.wi, wo_e, c.mrough);
+            if (len_sq(wo_e) > 0 && pdf_b > 0) {
+                V3 f = bsdf_eval(*c.mat, c.sp, c.wi, wo_e, c.mrough);
+                V3 Le = envmap_eval(*sc.envmap, wo_e, raydiff_zero());
+                double pdf_nee = envmap_pdf(*sc.envmap, wo_e) * sc.light_pmf[sc.num_lights - 1];
                 double mis = 1 / (1 + sq(pdf_nee / pdf_b));
                 V3 sc_contrib = (mis / pdf_b) * f * Le;
                 V3 scb = pc_bar * thr;
@@ -158,14 +156,33 @@ struct AdjBounceScatter {
                 V3 f_bar = w * scb * Le, Le_bar = w * scb * f;
                 V3 wo_bar = v3(0), wi_bar = v3(0);
                 RayDiff rd_bar = raydiff_zero();
-                adj_envmap_eval(*sc.envmap, wo, raydiff_zero(), Le_bar, g.envmap, wo_bar, rd_bar);
-                adj_bsdf_eval(*c.mat, c.sp, c.wi, wo, c.mrough, f_bar, gm, sp_bar, wi_bar, wo_bar);
+                adj_envmap_eval(*sc.envmap, wo_e, raydiff_zero(), Le_bar, g.envmap, wo_bar, rd_bar);
+                adj_bsdf_eval(*c.mat, c.sp, c.wi, wo_e, c.mrough, f_bar, gm, sp_bar, wi_bar, wo_bar);
                 in_dir_bar -= wi_bar;
             }
         }
         st3(adj.thr, adj.n, p, 0, thr_bar);
         st3(adj.ray_dir, adj.n, p, 0, in_dir_bar);
-        store_adj_point(adj, p, sp_bar);
+        V3 pos_bar = sp_bar.position;
+        Surf next_pt_bar = surf_zero();
+        if (through_hit) next_pt_bar = load_adj_point(adj, p);
+        store_adj_point(adj, p, sp_bar);                 // the position is stored again below
+        if (through_hit) {
+            const ShapeD &bsh = sc.shapes[bshape];
+            const int btri = vn.tri[p];
+            Surf bp_bar = next_pt_bar;
+            bp_bar.position += dir_bar;
+            DRay r_bar = dray_zero();
+            RayDiff rd_bar = raydiff_zero();
+            Ray br = make_ray(pos, wo);
+            adj_surf_at(bsh, btri, br, load_rdiff(vn, p), bp_bar, raydiff_zero(), r_bar, rd_bar, tg, !sc.no_diffs, sc.plain_materials != 0);
+            tg_shape = bshape; tg_tri = btri;
+            if (c.mrough > 0.01f) {
+                pos_bar -= dir_bar;
+                pos_bar += r_bar.org;
+                st3(adj.point, adj.n, p, 0, pos_bar);
+            }
+        }
         scatter_trigrad_wave(sc.shapes, g.shapes, tg_shape, tg_tri, tg, sc.plain_materials != 0);   // every lane gets here
     }
 };
