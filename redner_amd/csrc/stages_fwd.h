@@ -109,7 +109,10 @@ RDR_FN void lean_slice(VSlice &v) { v.rdiff = nullptr; v.erd = nullptr; }
 // estimators and the G-buffer code and need every register plus AGPR spills for it.
 RDR_FN void mid_scene(SceneD &sc) { sc.envmap = nullptr; sc.cam.kind = kCamPerspective; sc.cam.distortion.defined = 0; }
 RDR_FN void lean_channels(ChannelsD &ch) { ch.n = 1; ch.radiance_only = 1; ch.radiance_dim = 0; ch.radiance_off = 0; ch.nd = 3; }
+template <class Stage, class = void> struct LeanBlocks { static constexpr int value = 1; };
+template <class Stage> struct LeanBlocks<Stage, decltype((void)Stage::kLeanBlocksPerCU)> { static constexpr int value = Stage::kLeanBlocksPerCU; };
 template <class Stage> struct LeanStage {
+    static constexpr int kMinBlocksPerCU = LeanBlocks<Stage>::value;
     Stage f;
     RDR_FN void operator()(int i) const { Stage g = f; g.make_lean(); RDR_INLINE_CALL g(i); }
 };
