@@ -283,12 +283,19 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda:%d' % local_rank)
+    # RDR_BENCH_SHARE_GPU=1 (rehearsal of the multi-rank path on a box with fewer GPUs than ranks: gloo, ranks share devices;
+    # the number it prints is not a measurement)
+    share = os.environ.get('RDR_BENCH_SHARE_GPU') == '1'
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda:%d' % dev_index)
     under_launcher = 'RANK' in os.environ and 'MASTER_PORT' in os.environ      # torch.distributed.run, also with one rank
     if world > 1 or under_launcher:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
         assert dist.get_world_size() == world
     assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE is %d)' % (a.gpus, world)
     assert a.spp % world == 0, '--spp must be divisible by the number of GPUs'

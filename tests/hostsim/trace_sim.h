@@ -61,7 +61,7 @@ inline Path record(const rt::BvhD &bvh, const float o[3], const float d[3], floa
 
 constexpr double Ci = 110, Ct = 190, Cr = 150;
 
-struct Tot { double vote[4] = {0, 0, 0, 0}, vote_sorted[4] = {0, 0, 0, 0}; double useful = 0, ifif = 0, whilewhile = 0, ww_sorted = 0, refill8 = 0, refill24 = 0, refill_sorted = 0; long rays = 0, live = 0; };
+struct Tot { double multi_s[3] = {0, 0, 0}, multi_d[3] = {0, 0, 0}; double vote[4] = {0, 0, 0, 0}, vote_sorted[4] = {0, 0, 0, 0}; double useful = 0, ifif = 0, whilewhile = 0, ww_sorted = 0, refill8 = 0, refill24 = 0, refill_sorted = 0; long rays = 0, live = 0; };
 inline Tot &tot(bool any) { static Tot t[2]; return t[any ? 1 : 0]; }
 
 inline double useful_of(const Path &p) { double c = 0; for (const Seg &s : p) c += Ci * s.inner + Ct * s.tris; return c; }
@@ -102,6 +102,46 @@ inline double sim_ww(const Path *const *lanes, int n) {
     }
     return cost;
 }
+// "if-if" flat loop with several rays per lane: a wave owns 64 * k consecutive rays; static: lane l takes rays l, l + 64, ...
+// of them in turn; dynamic: a lane that finishes takes the next unclaimed ray of the wave's block.  A lane that starts a ray
+// pays the set-up as one more kind of step of the iteration.
+inline double sim_multi(const Path *const *rays, int n, int k, bool dynamic) {
+    const int lanes = 64;
+    std::vector<int> cur(lanes, -1), nextj(lanes, 0);
+    std::vector<size_t> seg(lanes, 0); std::vector<int> done_inner(lanes, 0);
+    int pool = 0;                                   // dynamic: next unclaimed ray
+    double cost = 0;
+    auto take = [&](int l) -> bool {
+        for (;;) {
+            int r;
+            if (dynamic) { if (pool >= n) return false; r = pool++; }
+            else { r = l + lanes * nextj[l]; if (nextj[l] >= k || r >= n) return false; ++nextj[l]; }
+            cur[l] = r; seg[l] = 0; done_inner[l] = 0;
+            return true;
+        }
+    };
+    std::vector<char> finished(lanes, 0);
+    for (;;) {
+        bool any_setup = false, any_i = false, alive = false; int max_t = 0;
+        for (int l = 0; l < lanes; ++l) {
+            if (finished[l]) continue;
+            if (cur[l] < 0 || seg[l] >= rays[cur[l]]->size()) {
+                if (!take(l)) { finished[l] = 1; continue; }
+                any_setup = true; alive = true;
+                continue;                           // the set-up is this lane's step of the iteration
+            }
+            alive = true;
+            const Path &p = *rays[cur[l]];
+            const Seg &sg = p[seg[l]];
+            if (done_inner[l] < sg.inner) { any_i = true; ++done_inner[l]; if (done_inner[l] == sg.inner && sg.tris == 0) { ++seg[l]; done_inner[l] = 0; } }
+            else { max_t = std::max(max_t, sg.tris); ++seg[l]; done_inner[l] = 0; }
+        }
+        if (!alive) break;
+        cost += (any_setup ? Cr : 0) + (any_i ? Ci : 0) + Ct * max_t;
+    }
+    return cost;
+}
+
 // persistent wave over a whole queue, while-while, lanes refilled when >= `idle_min` of them are idle
 inline double sim_refill(const std::vector<const Path *> &q, int idle_min) {
     size_t next = 0;
@@ -194,7 +234,9 @@ inline void report() {
         if (!t.rays) continue;
         std::fprintf(stderr, "[trace_sim] %s: %ld rays (%ld live), useful %.0f/ray; wave cost per ray and lane efficiency:\n", a ? "any-hit" : "closest", t.rays, t.live, t.useful / t.rays);
         auto line = [&](const char *name, double c) { std::fprintf(stderr, "[trace_sim]   %-28s %8.0f  eff %.2f\n", name, c * 64 / t.rays, t.useful / (c * 64)); };
-        line("if-if", t.ifif); line("while-while", t.whilewhile); line("while-while, sorted rays", t.ww_sorted);
+        line("if-if", t.ifif);
+        { const int ks[3] = {2, 4, 8}; for (int i = 0; i < 3; ++i) { char nm[64]; std::snprintf(nm, sizeof nm, "if-if, %d rays/lane static", ks[i]); line(nm, t.multi_s[i]); std::snprintf(nm, sizeof nm, "if-if, %d rays/lane dynamic", ks[i]); line(nm, t.multi_d[i]); } }
+        line("while-while", t.whilewhile); line("while-while, sorted rays", t.ww_sorted);
         const int parks[4] = {8, 16, 32, 48};
         for (int i = 0; i < 4; ++i) { char nm[64]; std::snprintf(nm, sizeof nm, "vote park>=%d", parks[i]); line(nm, t.vote[i]); }
         for (int i = 0; i < 4; ++i) { char nm[64]; std::snprintf(nm, sizeof nm, "vote park>=%d, sorted", parks[i]); line(nm, t.vote_sorted[i]); }
@@ -219,6 +261,8 @@ inline void launch(const rt::BvhD &bvh, const rt::RayRec *rays, int n, bool any)
     std::vector<const Path *> q(n);
     for (int i = 0; i < n; ++i) q[i] = &paths[i];
     for (int w = 0; w < n; w += 64) { int m = std::min(64, n - w); t.ifif += sim_ifif(q.data() + w, m); t.whilewhile += sim_ww(q.data() + w, m); }
+    { const int ks[3] = {2, 4, 8};
+      for (int i = 0; i < 3; ++i) for (int w = 0; w < n; w += 64 * ks[i]) { int m = std::min(64 * ks[i], n - w); t.multi_s[i] += sim_multi(q.data() + w, m, ks[i], false); t.multi_d[i] += sim_multi(q.data() + w, m, ks[i], true); } }
     t.refill8 += sim_refill(q, 8); t.refill24 += sim_refill(q, 24);
     { const int parks[4] = {8, 16, 32, 48}; for (int i = 0; i < 4; ++i) t.vote[i] += sim_vote(q, 8, parks[i]); }
     std::vector<int> order(n);
