@@ -106,6 +106,8 @@ def build_scene(a, device, res):
     import scenes
     if a.workload == 'living_room_standin':
         return scenes.living_room_standin(device, resolution=(res, res))
+    if a.workload == 'living_room_standin_envmap':      # + environment map, specular / roughness textures: the GENERAL kernels
+        return scenes.living_room_standin_envmap(device, resolution=(res, res))
     return scenes.bunny_box(device, resolution=(res, res))
 
 
@@ -268,14 +270,14 @@ def main():
     ap.add_argument('--spp', type=int, default=256, help='samples per pixel of the whole job (sharded over the GPUs)')
     ap.add_argument('--res', type=int, default=1024)
     ap.add_argument('--max-bounces', type=int, default=None)
-    ap.add_argument('--workload', default='bunny_box', choices=['bunny_box', 'living_room_standin'])
+    ap.add_argument('--workload', default='bunny_box', choices=['bunny_box', 'living_room_standin', 'living_room_standin_envmap'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alone-leg', action='store_true', help='skip the extra single-stream step behind roofline.alone')
     ap.add_argument('--no-profile', action='store_true', help='skip the rocprofv3 counter passes behind roofline.kernels')
     ap.add_argument('--inner', action='store_true', help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.max_bounces is None:
-        a.max_bounces = 6 if a.workload == 'living_room_standin' else 4
+        a.max_bounces = 6 if a.workload.startswith('living_room_standin') else 4
     if a.inner:
         return inner_run(a)
 
@@ -384,7 +386,7 @@ def main():
             'config': {'workload': '%s %dx%d, max_bounces %d, Sobol, %d spp fwd+bwd per step (%s gradients, primary+secondary '
                                    'edge sampling), sharded by sample index over %d GPU(s): %d spp per GPU'
                                    % (a.workload, a.res, a.res, a.max_bounces, a.spp,
-                                      'camera-pose' if a.workload == 'living_room_standin' else 'vertex', world, spp_rank),
+                                      'camera-pose' if a.workload.startswith('living_room_standin') else 'vertex', world, spp_rank),
                        'resolution': [a.res, a.res], 'spp': a.spp, 'spp_per_gpu': spp_rank, 'max_bounces': a.max_bounces,
                        'parallelism': 'sample-sharded x%d' % world, 'world_size': world},
             'scene_build_ms': prep.scene_build_s * 1e3,

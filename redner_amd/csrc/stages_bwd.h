@@ -73,6 +73,7 @@ struct AdjBounceArgs {
 struct AdjBounceScatter {
     AdjBounceArgs a;
     static constexpr int kMidBlocksPerCU = 2;          // 320 -> 256 registers (256 B of scratch), two waves per SIMD
+    static constexpr int kMinBlocksPerCU = 2;          // general form
     static constexpr int kLeanBlocksPerCU = 3;         // 190 -> 168 registers (100 B of scratch), three waves per SIMD: +2 % on the benchmark
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; a.adj.plain = 1; }
     RDR_FN void make_mid() { mid_scene(a.sc); a.nd = 3; a.radiance_dim = 0; }
@@ -203,6 +204,7 @@ RDR_FN void adj_record_add(const AdjState &adj, int p, V3 thr_bar, V3 in_dir_bar
 struct AdjBounceNee {
     // mid specialisation at two waves per SIMD: 256 VGPR + 240 B of spills instead of 256 + 66 AGPR at one wave (0.89 -> 0.71 ms per
     // launch on the config-5 stand-in); the same cap costs AdjBounceScatter 650 B of spills and 1.8 -> 3.0 ms, so it keeps one wave
+    static constexpr int kMinBlocksPerCU = 2;
     static constexpr int kMidBlocksPerCU = 2;
     AdjBounceArgs a;
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; a.adj.plain = 1; }
@@ -358,6 +360,7 @@ RDR_FN void adj_first_hit_channels(const SceneD &sc, const GScene &g, const Chan
 }
 
 struct AdjPrimary {
+    static constexpr int kMinBlocksPerCU = 2;
     static constexpr int kMidBlocksPerCU = 2;
     SceneD sc; GScene g; SamplerD rng; int sample_center;
     VSlice v0; const float *d_image; int nd, radiance_dim; double weight;

@@ -315,6 +315,7 @@ RDR_FN VertexCtx load_vertex(const SceneD &sc, const VSlice &v, int p) {
 // ---- stage: draw the NEE point and the BSDF direction, emit both rays ---------------------------
 struct BounceSample {
     static constexpr int kMidBlocksPerCU = 3;
+    static constexpr int kMinBlocksPerCU = 3;          // general form
     SceneD sc; SamplerD rng; int dim, rng_shift;
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); lean_slice(vn); }
     RDR_FN void make_mid() { mid_scene(sc); }
@@ -457,6 +458,7 @@ RDR_FN BounceEval eval_bounce(const SceneD &sc, const VertexCtx &c, V3 thr,
 // ---- stage: gather both query results, accumulate the bounce, advance the throughput ------------
 struct BounceContrib {
     static constexpr int kMidBlocksPerCU = 3;
+    static constexpr int kMinBlocksPerCU = 3;          // general form
     SceneD sc; SamplerD rng; int dim, rng_shift;
     const int *active; VSlice v, vn;
     const rt::HitRec *h_nee, *h_bsdf;
