@@ -160,16 +160,8 @@ struct TreeBuilder {
 
     int leaf_ref(int i) const { return n_internal + i; }
 
-    double area(const EdgeNode &nd) const {
-        V3 dp = nd.p_max - nd.p_min;
-        if (is3d) return 2 * (dp.x * dp.y + dp.x * dp.z + dp.y * dp.z);
-        V3 dd = nd.d_max - nd.d_min;
-        return 2 * ((dp.x * dp.y + dp.x * dp.z + dp.y * dp.z) + (dd.x * dd.y + dd.x * dd.z + dd.y * dd.z));
-    }
-    void merge_children(EdgeNode &dst, const EdgeNode &a, const EdgeNode &b) const {
-        dst.p_min = vmin(a.p_min, b.p_min); dst.p_max = vmax(a.p_max, b.p_max);
-        if (!is3d) { dst.d_min = vmin(a.d_min, b.d_min); dst.d_max = vmax(a.d_max, b.d_max); }
-    }
+    double area(const EdgeNode &nd) const { return edge_node_area(nd, is3d); }
+    void merge_children(EdgeNode &dst, const EdgeNode &a, const EdgeNode &b) const { edge_node_merge(dst, a, b, is3d); }
 
     int lcp(int i, int j) const {
         if (i < 0 || i >= n || j < 0 || j >= n) return -1;
@@ -456,7 +448,11 @@ struct TreeBuilder {
 
 } // namespace
 
-void delete_edge_data(EdgeData *e) { delete e; }
+void delete_edge_data(EdgeData *e) {
+    if (!e) return;
+    for (void *p : e->owned) exec::pool_free(p);
+    delete e;
+}
 
 EdgeData *compute_edge_data(const Scene &scene) {
     // one build at a time: the topology caches below are process-wide, and builds of different Scenes may be in flight
@@ -660,6 +656,30 @@ EdgeData *compute_edge_data(const Scene &scene) {
             gather_cache->edges = edges;
             gather_cache->bvh = gather_built;
         });
+#ifdef RDR_HOSTSIM
+        ed->device_trees = false;                 // the CPU debugging harness has no kernels: host builder below
+#else
+        static const bool host_trees = std::getenv("RDR_EDGE_HOST_BUILD") != nullptr;      // A/B, and the check of one against the other
+        ed->device_trees = !host_trees;
+#endif
+        if (ed->device_trees) {
+            // The two reference hierarchies are built by kernels on the stream of the first gradient render (edges_gpu.cpp);
+            // the host contributes what must carry the host libm's last bit: length x exterior dihedral angle (acos) per edge
+            ed->wlen.resize(ne);
+            parallel_chunks(ne, 2048, [&](int begin, int end) {
+                for (int i = begin; i < end; ++i) {
+                    const EdgeD &e = edges[i];
+                    ed->wlen[i] = f3_distance(edge_v0f(shapes, e), edge_v1f(shapes, e)) * edge_exterior_dihedral(shapes, e);
+                }
+            });
+            timer.lap("edge weights");
+            gather_job.wait();
+            ed->cs_ids = cs_ids; ed->ncs_ids = ncs_ids;
+            ed->gather = std::move(gather_built);
+            if (ed->gather.depth + 2 > 64) throw std::runtime_error("edge gather hierarchy deeper than the traversal stack (64)");
+            if (ed->gather.ids.size() / 2 >= ((size_t)1 << 24) || ed->gather.nodes.size() >= ((size_t)1 << 30))
+                throw std::runtime_error("edge gather hierarchy: more than 2^24 edges are not supported");
+        } else {
         TreeBuilder cs(true, shapes, edges, bounds), ncs(false, shapes, edges, bounds);
         {   // the two hierarchies are independent
             auto cs_job = hostpool::run([&] { cs.build(cs_ids); });
@@ -749,6 +769,7 @@ EdgeData *compute_edge_data(const Scene &scene) {
             }
             });
         }
+        }
         timer.lap("gather hierarchy");
     }
 
@@ -802,8 +823,12 @@ EdgeData *compute_edge_data(const Scene &scene) {
         }
         });
     };
-    fatten(ed->cs_nodes, ed->cs_leaves, 0, ed->d.cs_root, ed->cs_fat);
-    fatten(ed->ncs_nodes, ed->ncs_leaves, kEdgeTreeBit, ed->d.ncs_root, ed->ncs_fat);
+    ed->d.cs_nodes = ed->d.ncs_nodes = nullptr;
+    ed->d.cs_root = ed->d.ncs_root = kNoEdgeTree;
+    if (!ed->device_trees) {
+        fatten(ed->cs_nodes, ed->cs_leaves, 0, ed->d.cs_root, ed->cs_fat);
+        fatten(ed->ncs_nodes, ed->ncs_leaves, kEdgeTreeBit, ed->d.ncs_root, ed->ncs_fat);
+    }
     timer.lap("sampler records");
     ed->d.num_edges = ne;
     ed->d.edge_bounds_expand = ed->edge_bounds_expand;
@@ -813,12 +838,13 @@ EdgeData *compute_edge_data(const Scene &scene) {
     return ed.release();
 }
 
-// Device copies of what compute_edge_data prepared (queued on the calling thread's stream; the caller flushes).
-void publish_edge_data(Scene &scene, EdgeData &ed) {
+// Device copies of what compute_edge_data prepared and, in the gfx950 build, the hierarchy kernels (on the calling thread's
+// stream; the caller flushes).
+void publish_edge_data(EdgeData &ed) {
     PhaseTimer timer("edge publish");
     auto up = [&](const void *src, size_t bytes) -> void * {
         void *p = exec::pool_alloc(bytes);
-        scene.owned.push_back(p);
+        ed.owned.push_back(p);
         if (bytes) exec::upload_async(p, src, bytes);
         return p;
     };
@@ -828,17 +854,26 @@ void publish_edge_data(Scene &scene, EdgeData &ed) {
     d.geom = (const EdgeGeom *)up(ed.geom.data(), sizeof(EdgeGeom) * ed.geom.size());
     d.primary_pmf = ed.primary_pmf.empty() ? nullptr : (const double *)up(ed.primary_pmf.data(), sizeof(double) * ne);
     d.primary_cdf = ed.primary_cdf.empty() ? nullptr : (const double *)up(ed.primary_cdf.data(), sizeof(double) * ne);
-    d.cs_nodes = ed.cs_fat.empty() ? nullptr : (const EdgeNodeP *)up(ed.cs_fat.data(), sizeof(EdgeNodeP) * ed.cs_fat.size());
-    d.ncs_nodes = ed.ncs_fat.empty() ? nullptr : (const EdgeNodeP *)up(ed.ncs_fat.data(), sizeof(EdgeNodeP) * ed.ncs_fat.size());
     d.gather = rt::BvhD{nullptr, nullptr, nullptr, 0, 0, 2};
     d.gleaf = nullptr;
     if (!ed.gather.nodes.empty()) {
         d.gather.nodes = (const rt::Node *)up(ed.gather.nodes.data(), sizeof(rt::Node) * ed.gather.nodes.size());
         d.gather.num_nodes = (int)ed.gather.nodes.size();
-        d.gather.num_tris = (int)ed.gleaf.size();
+        d.gather.num_tris = (int)(ed.gather.ids.size() / 2);
         d.gather.stack_need = ed.gather.depth + 2;
-        d.gleaf = (const GatherLeaf *)up(ed.gleaf.data(), sizeof(GatherLeaf) * ed.gleaf.size());
     }
+#ifndef RDR_HOSTSIM
+    if (ed.device_trees) {
+        if (d.gather.num_tris > 0) d.gather.ids = (const int *)up(ed.gather.ids.data(), sizeof(int) * ed.gather.ids.size());
+        timer.lap("device copies");
+        if (!ed.cs_ids.empty() || !ed.ncs_ids.empty()) build_edge_trees_device(ed);
+        timer.lap("hierarchies (device)");
+        return;
+    }
+#endif
+    d.cs_nodes = ed.cs_fat.empty() ? nullptr : (const EdgeNodeP *)up(ed.cs_fat.data(), sizeof(EdgeNodeP) * ed.cs_fat.size());
+    d.ncs_nodes = ed.ncs_fat.empty() ? nullptr : (const EdgeNodeP *)up(ed.ncs_fat.data(), sizeof(EdgeNodeP) * ed.ncs_fat.size());
+    if (!ed.gather.nodes.empty()) d.gleaf = (const GatherLeaf *)up(ed.gleaf.data(), sizeof(GatherLeaf) * ed.gleaf.size());
     timer.lap("device copies");
 }
 

@@ -29,6 +29,30 @@ struct EdgeNode {
     int parent, child0, child1, edge_id;   // edge_id >= 0 marks a leaf
 };
 
+// The arithmetic of the hierarchy build that decides its topology, shared by the host builder (edges.cpp) and the gfx950
+// kernels (edges_gpu.cpp) so that both round alike: minima / maxima with std::min / std::max's operand order, the surface
+// area the treelet pass prices boxes with (src/edge_tree.cpp:14-23, src/aabb.h).
+RDR_FN double dmin_std(double a, double b) { return (b < a) ? b : a; }
+RDR_FN double dmax_std(double a, double b) { return (a < b) ? b : a; }
+RDR_FN float fminf_std(float a, float b) { return (b < a) ? b : a; }
+RDR_FN float fmaxf_std(float a, float b) { return (a < b) ? b : a; }
+RDR_FN double edge_node_area(const EdgeNode &nd, bool is3d) {
+    V3 dp = nd.p_max - nd.p_min;
+    if (is3d) return 2 * (dp.x * dp.y + dp.x * dp.z + dp.y * dp.z);
+    V3 dd = nd.d_max - nd.d_min;
+    return 2 * ((dp.x * dp.y + dp.x * dp.z + dp.y * dp.z) + (dd.x * dd.y + dd.x * dd.z + dd.y * dd.z));
+}
+RDR_FN void edge_node_merge(EdgeNode &dst, const EdgeNode &a, const EdgeNode &b, bool is3d) {
+    const V3 pl = V3{dmin_std(a.p_min.x, b.p_min.x), dmin_std(a.p_min.y, b.p_min.y), dmin_std(a.p_min.z, b.p_min.z)};
+    const V3 ph = V3{dmax_std(a.p_max.x, b.p_max.x), dmax_std(a.p_max.y, b.p_max.y), dmax_std(a.p_max.z, b.p_max.z)};
+    dst.p_min = pl; dst.p_max = ph;
+    if (!is3d) {
+        const V3 dl = V3{dmin_std(a.d_min.x, b.d_min.x), dmin_std(a.d_min.y, b.d_min.y), dmin_std(a.d_min.z, b.d_min.z)};
+        const V3 dh = V3{dmax_std(a.d_max.x, b.d_max.x), dmax_std(a.d_max.y, b.d_max.y), dmax_std(a.d_max.z, b.d_max.z)};
+        dst.d_min = dl; dst.d_max = dh;
+    }
+}
+
 // What the samplers read: one 128-byte line per INTERIOR node holding everything a traversal step needs about
 // both children -- their spatial bounds, Hough x-interval, weight and reference -- plus the node's own bounds
 // (for the "shading point inside this node" test).  Leaves are not nodes here: a leaf child is a negative
@@ -221,12 +245,24 @@ struct EdgeData {
     std::vector<GatherLeaf> gleaf;
     std::vector<EdgeGeom> geom;                  // per edge, what EdgeSceneD::geom will hold
     std::vector<EdgeNodeP> cs_fat, ncs_fat;      // the samplers' interior-node records (EdgeSceneD::cs_nodes / ncs_nodes)
+    // GPU build of the two hierarchies (edges_gpu.cpp): the host prepares the edge ids of each tree (ascending) and the
+    // per-edge weight; the kernels leave the node arrays on the device (dev_nodes, [interior | leaves] like cs_nodes)
+    bool device_trees = false;
+    std::vector<int> cs_ids, ncs_ids;
+    std::vector<double> wlen;
+    EdgeNode *dev_nodes[2] = {nullptr, nullptr};
+    int dev_n[2] = {0, 0};
+    std::vector<void *> owned;                   // device allocations (pool blocks), released by delete_edge_data
     EdgeSceneD d;            // device view (pointers valid after publish_edge_data)
 };
-// The build in two steps so that the first can run beside the caller (scene.cpp): everything computed on the host, reading
-// only the Scene's host mirrors; then the device copies, queued on the calling thread's stream.
+// The build in two steps, both run by the edge-builder thread beside the caller (scene.cpp): everything computed on the
+// host, reading only the Scene's host mirrors; then the device copies and the hierarchy kernels on that thread's stream.
 EdgeData *compute_edge_data(const Scene &scene);
-void publish_edge_data(Scene &scene, EdgeData &ed);
+void publish_edge_data(EdgeData &ed);
+// edges_gpu.cpp (not part of the CPU debugging harness): both hierarchies, leaf order, sampler and gather records on the
+// calling thread's stream; and the node arrays back on the host for rdr_debug_dump_edges.
+void build_edge_trees_device(EdgeData &ed);
+void download_edge_trees(EdgeData &ed);
 void delete_edge_data(EdgeData *e);
 
 } // namespace rdr

@@ -5,6 +5,11 @@
 #include "sobol.h"
 #include <memory>
 #include "edges.h"
+#include <thread>
+#include <mutex>
+#include <functional>
+#include <deque>
+#include <condition_variable>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -48,13 +53,45 @@ M3 m3_from(const float *p) { M3 m; for (int i = 0; i < 3; ++i) for (int j = 0; j
 
 } // namespace
 
-const EdgeData *Scene::edge_data() const {
-    if (edge_build.valid()) {
-        EdgeData *built = edge_build.get();             // rethrows what the build threw
-        Scene &self = const_cast<Scene &>(*this);       // the device copies belong to this Scene's allocations
-        try { publish_edge_data(self, *built); exec::upload_flush(); } catch (...) { delete_edge_data(built); throw; }
-        edges = built;
+namespace {
+// One long-lived thread builds the edge structures of every Scene, one after the other (the topology caches of edges.cpp are
+// process-wide): the host part on the pool, then the device copies and the hierarchy kernels on a stream of its own.  It keeps
+// its pinned staging buffer and its stream from Scene to Scene (a thread per Scene would allocate them each time).
+class EdgeBuilder {
+public:
+    static EdgeBuilder &get() { static EdgeBuilder *b = new EdgeBuilder(); return *b; }      // never destroyed
+    std::future<EdgeData *> submit(std::function<EdgeData *()> fn) {
+        std::packaged_task<EdgeData *()> task(std::move(fn));
+        std::future<EdgeData *> fut = task.get_future();
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            q_.push_back(std::move(task));
+        }
+        cv_.notify_one();
+        return fut;
     }
+private:
+    EdgeBuilder() { std::thread([this] { loop(); }).detach(); }
+    void loop() {
+        for (;;) {
+            std::packaged_task<EdgeData *()> task;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return !q_.empty(); });
+                task = std::move(q_.front());
+                q_.pop_front();
+            }
+            task();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::packaged_task<EdgeData *()>> q_;
+};
+}
+
+const EdgeData *Scene::edge_data() const {
+    if (edge_build.valid()) edges = edge_build.get();             // rethrows what the build threw
     return edges;
 }
 
@@ -373,7 +410,16 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     if (s.use_primary_edges || s.use_secondary_edges) {
         static const bool sync_edges = std::getenv("RDR_SYNC_EDGES") != nullptr;
         const Scene *sc = &s;
-        s.edge_build = std::async(std::launch::async, [sc] { return compute_edge_data(*sc); });
+        s.edge_build = EdgeBuilder::get().submit([sc]() -> EdgeData * {
+            EdgeData *ed = compute_edge_data(*sc);
+            try {
+                exec::select_device(1, sc->gpu_index);
+                exec::StreamScope on(exec::side_stream(0));             // this thread's own stream
+                publish_edge_data(*ed);
+                exec::upload_flush();
+            } catch (...) { delete_edge_data(ed); throw; }
+            return ed;
+        });
         if (sync_edges || timer.on) s.edge_data();
     }
     timer.lap("edge structures");

@@ -63,11 +63,13 @@ struct Scene {
     rt::BvhD bvh;
     const uint64_t *sobol_table = nullptr;   // 1024 x 52 u64
     const float *ltc_table = nullptr;        // 128 x 128 x 9 f32
-    // Edge-sampling structures.  Only a gradient render reads them, so create_scene() starts their (host-side) build on a
-    // thread of its own and returns; the forward render and whatever the caller does before its backward call run beside
-    // it.  edge_data() joins that build, queues the device copies on the calling thread's stream and flushes them; the
-    // destructor joins too.  (The reference builds them inside the Scene constructor, src/scene.cpp:63-307, i.e. in front of
-    // every forward render, pyredner/render_pytorch.py:609.)  RDR_SYNC_EDGES=1 / RDR_DEBUG_DUMP: built inside create_scene().
+    // Edge-sampling structures.  Only a gradient render reads them, so create_scene() hands their build to the edge-builder
+    // thread (scene.cpp) and returns: the host part (edge list, PMF, billboard hierarchy refit, per-edge records) on the
+    // pool, then the device copies and the kernels that build the two order-exact hierarchies (edges_gpu.cpp) on that
+    // thread's own stream.  The forward render and whatever the caller does before its backward call run beside all of it;
+    // edge_data() joins (the first gradient render calls it), and so does the destructor.  (The reference builds them inside
+    // the Scene constructor, src/scene.cpp:63-307, i.e. in front of every forward render, pyredner/render_pytorch.py:609.)
+    // RDR_SYNC_EDGES=1 / RDR_DEBUG_DUMP: joined inside create_scene().  RDR_EDGE_HOST_BUILD=1: hierarchies by the host builder.
     const EdgeData *edge_data() const;
     mutable EdgeData *edges = nullptr;            // valid after edge_data()
     mutable std::future<EdgeData *> edge_build;   // pending build, if any

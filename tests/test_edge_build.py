@@ -12,9 +12,9 @@ import scenes
 from redner_amd.render_pytorch import RenderFunction
 
 
-def _dump(backend, builder, path, is_oracle):
-    sc = getattr(scenes, builder)(torch.device('cpu'), resolution=(32, 32))
-    args = RenderFunction.serialize_scene(sc, 1, 2, sampler_type=backend.SamplerType.sobol, device=torch.device('cpu'),
+def _dump(backend, builder, path, is_oracle, device=torch.device('cpu')):
+    sc = getattr(scenes, builder)(device, resolution=(32, 32))
+    args = RenderFunction.serialize_scene(sc, 1, 2, sampler_type=backend.SamplerType.sobol, device=device,
                                           backend=backend)
     u = RenderFunction.unpack_args((1, 2), args[0], args[1:])
     if is_oracle:
@@ -31,13 +31,11 @@ def _dump(backend, builder, path, is_oracle):
         assert lib.rdr_debug_dump_edges(u.scene._handle, path.encode()) == 0
 
 
-@pytest.mark.skipif(not oracle_util.oracle_available(), reason='oracle/_ref not built')
-@pytest.mark.parametrize('builder', ['two_triangles', 'bunny_box'])
-def test_edge_structures_match_reference(hostsim_backend, tmp_path, builder):
+def _compare(backend, builder, tmp_path, device):
     ref = oracle_util.load_oracle()
     sys.modules.setdefault('redner', ref)        # pybind type registry for the dump helper
     a, b = str(tmp_path / 'mine.txt'), str(tmp_path / 'ref.txt')
-    _dump(hostsim_backend, builder, a, False)
+    _dump(backend, builder, a, False, device)
     _dump(ref, builder, b, True)
     la, lb = open(a).read().split('\n'), open(b).read().split('\n')
     assert len(la) == len(lb)
@@ -50,3 +48,21 @@ def test_edge_structures_match_reference(hostsim_backend, tmp_path, builder):
                 assert float(p) == float(q), (x, y)
         else:
             assert xs == ys, (x, y)
+
+
+@pytest.mark.skipif(not oracle_util.oracle_available(), reason='oracle/_ref not built')
+@pytest.mark.parametrize('builder', ['two_triangles', 'bunny_box'])
+def test_edge_structures_match_reference(hostsim_backend, tmp_path, builder):
+    """The host builder (edges.cpp: TreeBuilder), through the CPU harness."""
+    _compare(hostsim_backend, builder, tmp_path, torch.device('cpu'))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not oracle_util.oracle_available(), reason='oracle/_ref not built')
+@pytest.mark.parametrize('builder', ['two_triangles', 'bunny_box', 'living_room_standin', 'single_triangle'])
+def test_edge_structures_built_on_the_gpu_match_reference(gpu_backend, tmp_path, builder):
+    """The kernels of edges_gpu.cpp (codes, sort, radix tree, bounds, treelets): the node arrays are read back from the
+    device and must equal the reference's link for link, their weights, costs and bounds bit for bit."""
+    if not hasattr(scenes, builder):
+        pytest.skip('no such scene builder')
+    _compare(gpu_backend, builder, tmp_path, torch.device('cuda:0'))
