@@ -583,6 +583,13 @@ EdgeData *compute_edge_data(const Scene &scene) {
 
     // ---- secondary edges: the two hierarchies (src/edge_tree.cpp:724-882) ----
     if (scene.use_secondary_edges && ne > 0) {
+#ifdef RDR_HOSTSIM
+        ed->device_trees = false;                 // the CPU debugging harness has no kernels: host builder below
+#else
+        static const bool host_trees = std::getenv("RDR_EDGE_HOST_BUILD") != nullptr;      // A/B, and the check of one against the other
+        ed->device_trees = !host_trees;
+#endif
+        const bool spatial_only = ed->device_trees;      // the kernels compute the Hough-space bounds themselves (edges_gpu.cpp)
         std::vector<int> cs_ids, ncs_ids;
         std::vector<unsigned char> is_sil(ne, 0);
         std::vector<Box6> bounds(ne);
@@ -594,6 +601,7 @@ EdgeData *compute_edge_data(const Scene &scene) {
             Box6 bx;
             bx.p_min = V3{(double)std::min(a.x, b.x), (double)std::min(a.y, b.y), (double)std::min(a.z, b.z)};
             bx.p_max = V3{(double)std::max(a.x, b.x), (double)std::max(a.y, b.y), (double)std::max(a.z, b.z)};
+            if (spatial_only) { bx.d_min = bx.d_max = v3(0); bounds[i] = bx; continue; }
             V3 n0 = edge_n0(shapes, e);
             V3 n1 = (e.f1 == -1) ? -n0 : edge_n1(shapes, e);
             F3 mid = F3{0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
@@ -656,12 +664,6 @@ EdgeData *compute_edge_data(const Scene &scene) {
             gather_cache->edges = edges;
             gather_cache->bvh = gather_built;
         });
-#ifdef RDR_HOSTSIM
-        ed->device_trees = false;                 // the CPU debugging harness has no kernels: host builder below
-#else
-        static const bool host_trees = std::getenv("RDR_EDGE_HOST_BUILD") != nullptr;      // A/B, and the check of one against the other
-        ed->device_trees = !host_trees;
-#endif
         if (ed->device_trees) {
             // The two reference hierarchies are built by kernels on the stream of the first gradient render (edges_gpu.cpp);
             // the host contributes what must carry the host libm's last bit: length x exterior dihedral angle (acos) per edge

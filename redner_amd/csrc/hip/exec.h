@@ -511,12 +511,14 @@ TraceStats &trace_stats();
 void trace_stats_collect();     // folds pending hipEvent pairs / device counters into trace_stats()
 void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count n, bool any);
 // Host threads render() may drive samples from (RDR_WORKERS=1 turns the second one off).
-inline int sample_workers(int lanes) {
+inline int sample_workers(int lanes, int samples) {
     static const int forced = [] { const char *e = std::getenv("RDR_WORKERS"); return e ? std::min(1 + kMaxHelpers, std::max(1, std::atoi(e))) : 0; }();
     if (forced) return forced;
-    // measured (bunny_box backward): 256x256x16 spp 123 -> 87 ms, 512x512x8 spp 92 -> 83 ms with a second worker, four are
-    // slower than two; at 1024x1024 the second worker adds 2 % and stretches every kernel it shares the GPU with
-    return lanes >= (1 << 19) ? 1 : 2;
+    // measured (bunny_box backward, round 2): 256x256x4 spp 13.8 / 14.6 / 15.2 ms with 2 / 3 / 4 workers, 256x256x16 spp
+    // 52.1 / 47.9 / 46.7 / 48.7 ms with 3 / 4 / 6 / 8; 512x512x8 spp 92 -> 83 ms with a second worker; at 1024x1024 the second
+    // worker adds 2-4 % and stretches every kernel it shares the GPU with
+    if (lanes >= (1 << 19)) return 1;
+    return (lanes <= (1 << 17) && samples >= 8) ? std::min(4, 1 + kMaxHelpers) : 2;
 }
 void select_device(int use_gpu, int gpu_index);
 

@@ -725,7 +725,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     // (the camera-vertex adjoint adds to the screen-gradient image with plain read-modify-writes: one worker then)
     if (d_image != nullptr && image == nullptr && screen_gradient_image == nullptr && lean == kLean &&
         opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on)
-        workers = std::max(1, std::min(exec::sample_workers(P), opt.num_samples));
+        workers = std::max(1, std::min(exec::sample_workers(P, opt.num_samples), opt.num_samples));
     Worker w0;
     make_worker(w0);
     if (timer.on) exec::sync();

@@ -54,7 +54,7 @@ inline Context &ctx() { static Context c; return c; }
 inline hipStream_t side_stream(int) { return nullptr; }
 struct StreamScope { explicit StreamScope(hipStream_t) {} ~StreamScope() {} };
 struct Fence { void after(hipStream_t) {} void gate(hipStream_t) {} };
-inline int sample_workers(int) { return 1; }
+inline int sample_workers(int, int) { return 1; }
 struct SecondThread {          // never used: sample_workers() == 1
     static SecondThread &get(int = 0) { static SecondThread t; return t; }
     template <class F> void start(F) {}

@@ -7,6 +7,9 @@ timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/pytest.log
 unset RDR_PARITY_REPORT
 timeout 900 python bench.py 2> $OUT/bench_default.err | tail -1 > $OUT/bench_default.json
 timeout 600 python bench.py --workload living_room_standin --spp 32 --steps 2 --no-cpu-baseline 2> $OUT/bench_living.err | tail -1 > $OUT/bench_living_room_standin.json
+timeout 600 python bench.py --workload living_room_standin_envmap --spp 32 --steps 2 --no-cpu-baseline 2> $OUT/bench_living_envmap.err | tail -1 > $OUT/bench_living_room_standin_envmap.json
+timeout 900 python bench.py --workload living_room_standin --spp 512 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-alone-leg 2> /dev/null | tail -1 > $OUT/bench_living_512spp.json
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 python tools/small_loop_timing.py 256 4 > $OUT/small_loop.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 P="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --spp 8 --no-cpu-baseline --no-alone-leg --no-profile"
