@@ -47,6 +47,42 @@ def two_triangles(device, resolution=(256, 256)):
     return Scene(cam, [t0, t1, light], mats, [AreaLight(2, _t([20.0, 20.0, 20.0], 'cpu'))])
 
 
+def triangle_soup(device, resolution=(32, 32)):
+    """Stress input for the edge-structure build (tests/test_edge_build.py): 1 500 seeded triangles in four shapes -- a cloud of
+    free triangles, a coarse-grid cloud (vertex coordinates snapped to 1/8: many edges share their Morton code, so the order of
+    equal codes and the id tie-break of the radix tree decide the topology), a strip mesh with shared vertices, and a stack of
+    exact duplicates (identical bounds, identical codes).  Not a BASELINE configuration."""
+    g = torch.Generator().manual_seed(4711)
+    cam = Camera(position=_t([0.0, 0.0, -6.0], 'cpu'), look_at=_t([0.0, 0.0, 0.0], 'cpu'),
+                 up=_t([0.0, 1.0, 0.0], 'cpu'), fov=_t([45.0], 'cpu'), clip_near=1e-2, resolution=resolution)
+    mats = [Material(diffuse_reflectance=_t([0.5, 0.5, 0.5], device)), Material(diffuse_reflectance=_t([0.0, 0.0, 0.0], device))]
+
+    def free(n, snap):
+        c = (torch.rand(n, 1, 3, generator=g) - 0.5) * torch.tensor([4.0, 4.0, 2.0])
+        v = c + (torch.rand(n, 3, 3, generator=g) - 0.5) * 0.6
+        if snap:
+            v = torch.round(v * 8.0) / 8.0
+            v = v + torch.tensor([[[0.0, 0.0, 0.0], [0.125, 0.0, 0.0], [0.0, 0.125, 0.0]]]) * (torch.rand(n, 1, 1, generator=g) < 0.3)   # some flat ones
+        return v.reshape(-1, 3).contiguous(), torch.arange(3 * n, dtype=torch.int32).reshape(n, 3)
+
+    v0, i0 = free(600, False)
+    v1, i1 = free(500, True)
+    # strip: 2 x 101 vertices, 200 triangles
+    xs = torch.linspace(-2.0, 2.0, 101)
+    top = torch.stack([xs, 0.3 + 0.2 * torch.sin(3 * xs), 1.5 + 0.1 * torch.cos(5 * xs)], 1)
+    bot = torch.stack([xs, -0.3 + 0.1 * torch.cos(2 * xs), 1.5 + 0.1 * torch.sin(4 * xs)], 1)
+    v2 = torch.cat([top, bot], 0).contiguous()
+    i2 = torch.tensor([[k, k + 1, 101 + k] for k in range(100)] + [[k + 1, 102 + k, 101 + k] for k in range(100)], dtype=torch.int32)
+    # duplicates: the same triangle 200 times (separate vertices)
+    t = torch.tensor([[-0.5, -0.5, -1.0], [0.5, -0.4, -1.1], [0.1, 0.6, -0.9]])
+    v3 = t.repeat(200, 1).contiguous()
+    i3 = torch.arange(600, dtype=torch.int32).reshape(200, 3)
+    shapes = [Shape(v.to(device).requires_grad_(True), i.to(device), 0) for v, i in ((v0, i0), (v1, i1), (v2, i2), (v3, i3))]
+    light = Shape(_t([[-1.0, -1.0, -7.0], [1.0, -1.0, -7.0], [-1.0, 1.0, -7.0], [1.0, 1.0, -7.0]], device),
+                  _t([[0, 1, 2], [1, 3, 2]], device, torch.int32), 1)
+    return Scene(cam, shapes + [light], mats, [AreaLight(4, _t([20.0, 20.0, 20.0], 'cpu'))])
+
+
 def bunny_box(device, resolution=(512, 512), vertex_grad=True):
     """tests/scenes/bunny_box.xml as loaded by pyredner.load_mitsuba (tests/test_bunny_box.py):
     Stanford bunny in a Cornell box, 7 shapes / 14 416 triangles, one area light.  The mesh
