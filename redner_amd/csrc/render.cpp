@@ -123,6 +123,9 @@ template <class F> void launch_v(int kind, exec::Count n, const F &f) {
     else exec::launch(n, f);
 }
 
+// Side streams of a large frame run at low priority (exec::side_stream: 2, 3), those of a small one at the default (0, 1).
+inline int side_index(int k, int lanes) { return lanes >= (1 << 19) ? k + 2 : k; }
+
 // One NEE + BSDF bounce over the live lanes of `v`; fills `vn` and the next live-lane list.  The lane count stays on the
 // device (exec::Count); `dyn` / `dyn_inc`: the dimension counter that advances if this bounce had lanes to run.
 exec::Count run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng_shift,
@@ -141,7 +144,7 @@ exec::Count run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng
         hipStream_t main_stream = exec::ctx().stream;
         queued->after(main_stream);
         {
-            exec::StreamScope on(exec::side_stream(1));
+            exec::StreamScope on(exec::side_stream(side_index(1, num_active.upper)));
             queued->gate(exec::ctx().stream);
             exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true);
             shadow_done->after(exec::ctx().stream);
@@ -483,7 +486,7 @@ struct Backward {
             if (early) {
                 picks_begin.after(main_stream);
                 {
-                    exec::StreamScope on(exec::side_stream(1));
+                    exec::StreamScope on(exec::side_stream(side_index(1, P)));
                     picks_begin.gate(exec::ctx().stream);
                     lists();
                     setup_done.after(exec::ctx().stream);
@@ -491,7 +494,7 @@ struct Backward {
                     walk_done.after(exec::ctx().stream);
                 }
                 {
-                    exec::StreamScope on(exec::side_stream(0));
+                    exec::StreamScope on(exec::side_stream(side_index(0, P)));
                     setup_done.gate(exec::ctx().stream);
                     hierarchical();
                     pickh_done.after(exec::ctx().stream);
@@ -500,7 +503,7 @@ struct Backward {
                 lists();
                 {
                     if (side) setup_done.after(main_stream);
-                    exec::StreamScope on(side ? exec::side_stream(1) : main_stream);
+                    exec::StreamScope on(side ? exec::side_stream(side_index(1, P)) : main_stream);
                     if (side) setup_done.gate(exec::ctx().stream);
                     gather();
                     if (side) walk_done.after(exec::ctx().stream);
@@ -551,7 +554,7 @@ struct Backward {
             const bool side = overlap && with_edges && !early_here;
             if (side) {
                 depth_begin.after(main_stream);
-                exec::StreamScope on(exec::side_stream(0));
+                exec::StreamScope on(exec::side_stream(side_index(0, P)));
                 depth_begin.gate(exec::ctx().stream);
                 launch_v(lean, nA, AdjBounceScatter{ba});
                 launch_v(lean, nA, AdjBounceNee{ba});
@@ -590,7 +593,7 @@ struct Backward {
         if (adj_primary_aside) {
             hipStream_t main_stream = exec::ctx().stream;
             depth_begin.after(main_stream);
-            exec::StreamScope on(exec::side_stream(0));
+            exec::StreamScope on(exec::side_stream(side_index(0, P)));
             depth_begin.gate(exec::ctx().stream);
             launch_v(lean, P, AdjPrimary{scene.d, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
                                        adj, screen_grad, ch});
