@@ -217,7 +217,13 @@ private:
             try {
                 check(hipSetDevice(dev), "hipSetDevice");
                 hipStream_t &s = streams[dev & 15];
-                if (!s) check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+                if (!s) {
+                    static const bool low = std::getenv("RDR_HELPER_LOW") != nullptr;        // experiment: helpers at the lowest priority
+                    int least = 0, greatest = 0;
+                    if (low && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+                        check(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least), "hipStreamCreateWithPriority");
+                    else check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+                }
                 ctx().stream = s;
                 job();
                 check(hipStreamSynchronize(s), "second stream sync");

@@ -9,6 +9,7 @@ timeout 900 python bench.py 2> $OUT/bench_default.err | tail -1 > $OUT/bench_def
 timeout 600 python bench.py --workload living_room_standin --spp 32 --steps 2 --no-cpu-baseline 2> $OUT/bench_living.err | tail -1 > $OUT/bench_living_room_standin.json
 timeout 600 python bench.py --workload living_room_standin_envmap --spp 32 --steps 2 --no-cpu-baseline 2> $OUT/bench_living_envmap.err | tail -1 > $OUT/bench_living_room_standin_envmap.json
 timeout 900 python bench.py --workload living_room_standin --spp 512 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-alone-leg 2> /dev/null | tail -1 > $OUT/bench_living_512spp.json
+RDR_WORKERS=2 RDR_HELPER_LOW=1 timeout 600 python bench.py --no-cpu-baseline --no-profile 2> /dev/null | tail -1 > $OUT/bench_two_workers.json
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 python tools/small_loop_timing.py 256 4 > $OUT/small_loop.log 2>&1
 cd /tmp && export TMPDIR=/tmp
