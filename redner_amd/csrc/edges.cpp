@@ -477,7 +477,7 @@ EdgeData *compute_edge_data(const Scene &scene) {
     // buffer only; a shape whose index buffer equals the one seen last at its position reuses it (an optimisation loop moves
     // vertices, not connectivity).  Everything after it depends on positions and is redone.
     struct MergedCache { std::vector<std::vector<int>> indices; std::vector<std::vector<EdgeD>> merged; };
-    static MergedCache *merged_cache = new MergedCache();            // guarded by the API lock (capi.cpp)
+    static MergedCache *merged_cache = new MergedCache();            // one build at a time (build_lock above; scene.cpp: EdgeBuilder)
     static const bool cache_allowed = std::getenv("RDR_NO_REFIT") == nullptr;
     if ((int)merged_cache->indices.size() != ns) { merged_cache->indices.assign(ns, {}); merged_cache->merged.assign(ns, {}); }
     std::vector<EdgeD> &edges = ed->edges;
@@ -621,7 +621,7 @@ EdgeData *compute_edge_data(const Scene &scene) {
         // (the billboard hierarchy only has to be conservative: with the edge list of the previous Scene its topology is kept
         //  and its boxes are refitted; rebuilt when the inner surface area has grown by more than 30 %)
         struct GatherCache { std::vector<EdgeD> edges; rt::BvhHost bvh; };
-        static GatherCache *gather_cache = new GatherCache();            // guarded by the API lock (capi.cpp)
+        static GatherCache *gather_cache = new GatherCache();            // one build at a time (build_lock above; scene.cpp: EdgeBuilder)
         rt::BvhHost gather_built;
         double &expand_out = ed->edge_bounds_expand;
         auto gather_job = hostpool::run([&gather_built, &bounds, &edges, &cs_ids, &ncs_ids, shapes, ne, &expand_out] {

@@ -67,11 +67,21 @@ public:
             std::lock_guard<std::mutex> lk(m_);
             q_.push_back(std::move(task));
         }
-        cv_.notify_one();
+        cv_.notify_all();
         return fut;
     }
+    // Process exit: a build that is still running (a Scene that was never destroyed) must not be inside the HIP runtime
+    // when the runtime's own exit handlers tear it down.  Registered after the runtime's (the first Scene initialised it),
+    // so it runs before them.
+    void drain() {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return q_.empty() && !running_; });
+    }
 private:
-    EdgeBuilder() { std::thread([this] { loop(); }).detach(); }
+    EdgeBuilder() {
+        std::thread([this] { loop(); }).detach();
+        std::atexit([] { EdgeBuilder::get().drain(); });
+    }
     void loop() {
         for (;;) {
             std::packaged_task<EdgeData *()> task;
@@ -80,13 +90,20 @@ private:
                 cv_.wait(lk, [&] { return !q_.empty(); });
                 task = std::move(q_.front());
                 q_.pop_front();
+                running_ = true;
             }
             task();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                running_ = false;
+            }
+            cv_.notify_all();
         }
     }
     std::mutex m_;
     std::condition_variable cv_;
     std::deque<std::packaged_task<EdgeData *()>> q_;
+    bool running_ = false;
 };
 }
 
