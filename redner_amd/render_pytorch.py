@@ -156,11 +156,16 @@ class RenderFunction(torch.autograd.Function):
             scene.shapes[light.shape_id].light_id = light_id
 
         tensors = []
+        finite_flags = []       # device tensors are checked together at the end: one synchronisation instead of one per tensor
 
         def put(t, dev):
             if t is None:
                 return -1
-            assert torch.isfinite(t).all() if t.is_floating_point() else True
+            if t.is_floating_point():
+                if t.device.type == 'cpu':
+                    assert torch.isfinite(t).all()
+                else:
+                    finite_flags.append(torch.isfinite(t).all())
             tensors.append(t.to(dev).contiguous())
             return len(tensors) - 1
 
@@ -217,6 +222,8 @@ class RenderFunction(torch.autograd.Function):
                               'pdf_norm': em.pdf_norm, 'directly_visible': em.directly_visible}
         meta['use_primary_edge_sampling'] = bool(use_primary_edge_sampling and needs_visibility)
         meta['use_secondary_edge_sampling'] = bool(use_secondary_edge_sampling and needs_visibility)
+        if finite_flags:
+            assert bool(torch.stack(finite_flags).all()), 'serialize_scene: a scene tensor holds non-finite values'
         return [meta] + tensors
 
     @staticmethod
