@@ -208,6 +208,15 @@ def _read_durations(out_dir):
     return {k: (n[k], tot[k] / n[k]) for k in n}
 
 
+def under_profiler():
+    """True when this process already runs under rocprofv3 / rocprof (its tool library is preloaded or configured): the
+    in-run counter passes would nest a profiler inside a profiler, so they are skipped and `roofline.kernels` stays null."""
+    env = os.environ
+    if 'rocprof' in env.get('LD_PRELOAD', '').lower():
+        return True
+    return any(k.startswith(('ROCPROF', 'ROCP_TOOL', 'ROCPROFILER_')) for k in env)
+
+
 def profile_kernels(a):
     """Four rocprofv3 passes on a 2-spp forward+backward of the same workload: kernel durations (stages overlapped as in
     the benchmark, and each kernel on its own with RDR_NO_OVERLAP=1), SQ counters, FETCH_SIZE, WRITE_SIZE (separate passes,
@@ -374,7 +383,7 @@ def main():
         achieved = alg_bytes_launch / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
         rays_per_launch = rays / max(cnt.closest_launches, 1)
         prof = None
-        if world == 1 and not a.no_profile:
+        if world == 1 and not a.no_profile and not under_profiler():
             try:
                 prof = profile_kernels(a)
             except Exception as e:      # the counters must never take the throughput number down with them
