@@ -271,6 +271,8 @@ struct TreeletShared {
     int leaf_parent[7];
     double leaf_area[7];           // of the interior ones among the leaves (the growth opens the largest)
     struct Frame { unsigned char part; signed char side; unsigned char stage; signed char parent_slot, slot, c0, c1; } frames[16];
+    unsigned char list[64];        // the subsets of one size (dynamic programme)
+    int list_n;
     int nl, ni, open;
 };
 constexpr int kRootSlot = 5;
@@ -398,21 +400,64 @@ __device__ inline void treelet_optimize_wave(const TreeD &t, TreeletShared &sh, 
     }
     if (lane < nl) sh.best[1 << lane] = sh.leaf[lane].cost;
     __syncthreads();
-    // cheapest split of every subset with >= 2 leaves, by subset size; ties go to the first split in the order p = (p - d) & s
+    // Cheapest split of every subset with >= 2 leaves, by subset size; ties go to the first split in the reference's order
+    // p = (p - d) & s with d = s without its lowest leaf, i.e. the j-th split puts the bits of j into the positions of d's set
+    // bits (j = 1, 2, ...).  Sizes 2 and 3: a lane per subset.  From size 4 on a subset's 2^(size-1) - 1 splits are evaluated
+    // by a group of 8 / 16 / 32 / 64 lanes at once and reduced to their minimum; among equal minima the lowest j wins, which
+    // is the first in that order -- the same choice as the sequential scan with a strict comparison.
     for (int k = 2; k <= nl; ++k) {
-        for (int s = lane + 1; s <= full; s += 64) {
-            if (__popc((unsigned)s) != k) continue;
-            double cheapest = INFINITY;
-            unsigned arg = 0;
-            const unsigned d = ((unsigned)s - 1u) & (unsigned)s;
-            unsigned p = (0u - d) & (unsigned)s;
-            do {
-                const double c = sh.best[p] + sh.best[(unsigned)s ^ p];
-                if (c < cheapest) { cheapest = c; arg = p; }
-                p = (p - d) & (unsigned)s;
-            } while (p != 0);
-            sh.best[s] = sh.sa[s] + cheapest;
-            sh.best_left[s] = (unsigned char)arg;
+        if (k < 4) {
+            for (int s = lane + 1; s <= full; s += 64) {
+                if (__popc((unsigned)s) != k) continue;
+                double cheapest = INFINITY;
+                unsigned arg = 0;
+                const unsigned d = ((unsigned)s - 1u) & (unsigned)s;
+                unsigned p = (0u - d) & (unsigned)s;
+                do {
+                    const double c = sh.best[p] + sh.best[(unsigned)s ^ p];
+                    if (c < cheapest) { cheapest = c; arg = p; }
+                    p = (p - d) & (unsigned)s;
+                } while (p != 0);
+                sh.best[s] = sh.sa[s] + cheapest;
+                sh.best_left[s] = (unsigned char)arg;
+            }
+            __syncthreads();
+            continue;
+        }
+        // the subsets of this size, in increasing order
+        {
+            const int s0 = lane + 1, s1 = lane + 65;
+            const bool f0 = s0 <= full && __popc((unsigned)s0) == k, f1 = s1 <= full && __popc((unsigned)s1) == k;
+            const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (f0) sh.list[__popcll(b0 & below)] = (unsigned char)s0;
+            if (f1) sh.list[__popcll(b0) + __popcll(b1 & below)] = (unsigned char)s1;
+            if (lane == 0) sh.list_n = __popcll(b0) + __popcll(b1);
+        }
+        __syncthreads();
+        const int count = sh.list_n;
+        const int group = 1 << (k - 1);              // lanes per subset: 8, 16, 32, 64
+        const int per_pass = 64 / group;
+        const int g = lane / group, j = lane % group;            // this lane evaluates split j + 1 of its group's subset
+        for (int first = 0; first < count; first += per_pass) {
+            const bool has = first + g < count;
+            const unsigned s = has ? sh.list[first + g] : 0u;
+            const unsigned d = (s - 1u) & s;
+            unsigned p = 0;
+            { unsigned m = d, x = (unsigned)j + 1u; while (m) { const unsigned low = m & (0u - m); if (x & 1u) p |= low; x >>= 1; m &= m - 1u; } }
+            const bool valid = has && j < group - 1;
+            const double c = valid ? sh.best[p] + sh.best[s ^ p] : INFINITY;
+            double m = c;
+            for (int step = 1; step < group; step <<= 1) { const double o = __shfl_xor(m, step, 64); m = o < m ? o : m; }
+            const unsigned long long hit = __ballot(valid && c == m && c < INFINITY);
+            const unsigned long long mine = group == 64 ? hit : (hit >> (g * group)) & ((1ull << group) - 1ull);
+            if (valid && mine != 0ull && j == __builtin_ctzll(mine)) {
+                sh.best[s] = sh.sa[s] + m;
+                sh.best_left[s] = (unsigned char)p;
+            } else if (has && mine == 0ull && j == 0) {          // no finite split (the sequential scan keeps its initial values)
+                sh.best[s] = sh.sa[s] + INFINITY;
+                sh.best_left[s] = 0;
+            }
         }
         __syncthreads();
     }
