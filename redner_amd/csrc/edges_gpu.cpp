@@ -25,6 +25,7 @@
 #include "scene.h"
 
 #ifndef RDR_HOSTSIM
+#include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <limits>
@@ -62,13 +63,14 @@ __global__ void __launch_bounds__(256) edge_bounds_kernel(const EdgeGeom *geom, 
     bounds[i] = bx;
 }
 
-// ---- bounds of one tree's edges: one workgroup, exact min / max ----
+// ---- bounds of one tree's edges: exact min / max, partial results per workgroup, then one workgroup over the partials ----
+// (ids == nullptr: `bounds` holds the partials themselves)
 __global__ void __launch_bounds__(256) scene_bounds_kernel(const Box6D *bounds, const int *ids, int n, Box6D *out) {
     __shared__ double lo[6][256], hi[6][256];
     const double inf = INFINITY;
     double l[6] = {inf, inf, inf, inf, inf, inf}, h[6] = {-inf, -inf, -inf, -inf, -inf, -inf};
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const Box6D b = bounds[ids[i]];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const Box6D b = bounds[ids ? ids[i] : i];
         const double bl[6] = {b.p_min.x, b.p_min.y, b.p_min.z, b.d_min.x, b.d_min.y, b.d_min.z};
         const double bh[6] = {b.p_max.x, b.p_max.y, b.p_max.z, b.d_max.x, b.d_max.y, b.d_max.z};
 #pragma unroll
@@ -91,7 +93,7 @@ __global__ void __launch_bounds__(256) scene_bounds_kernel(const Box6D *bounds, 
         Box6D o;
         o.p_min = V3{lo[0][0], lo[1][0], lo[2][0]}; o.d_min = V3{lo[3][0], lo[4][0], lo[5][0]};
         o.p_max = V3{hi[0][0], hi[1][0], hi[2][0]}; o.d_max = V3{hi[3][0], hi[4][0], hi[5][0]};
-        *out = o;
+        out[blockIdx.x] = o;
     }
 }
 
@@ -598,10 +600,13 @@ void build_edge_trees_device(EdgeData &ed) {
         if (n == 0) continue;
         const int total = t.n_internal + n;
         const int *ids_in = (const int *)up(ids_h.data(), sizeof(int) * (size_t)n);
+        const int sb_blocks = std::max(1, std::min(128, n / 2048));
+        Box6D *sb_part = (Box6D *)alloc(sizeof(Box6D) * (size_t)sb_blocks);
         Box6D *sb = (Box6D *)alloc(sizeof(Box6D));
         uint64_t *codes_in = (uint64_t *)alloc(sizeof(uint64_t) * (size_t)n), *codes = (uint64_t *)alloc(sizeof(uint64_t) * (size_t)n);
         int *ids = (int *)alloc(sizeof(int) * (size_t)n);
-        hipLaunchKernelGGL(scene_bounds_kernel, dim3(1), dim3(256), 0, s, bounds, ids_in, n, sb);
+        hipLaunchKernelGGL(scene_bounds_kernel, dim3((unsigned)sb_blocks), dim3(256), 0, s, bounds, ids_in, n, sb_part);
+        hipLaunchKernelGGL(scene_bounds_kernel, dim3(1), dim3(256), 0, s, (const Box6D *)sb_part, (const int *)nullptr, sb_blocks, sb);
         hipLaunchKernelGGL(codes_kernel, grid_of(n), dim3(256), 0, s, bounds, ids_in, n, sb, t.is3d, codes_in);
         {
             size_t temp_bytes = 0;
