@@ -47,7 +47,12 @@ def two_triangles(device, resolution=(256, 256)):
     return Scene(cam, [t0, t1, light], mats, [AreaLight(2, _t([20.0, 20.0, 20.0], 'cpu'))])
 
 
-def triangle_soup(device, resolution=(32, 32)):
+def triangle_soup_large(device, resolution=(32, 32)):
+    """The same at 40x the size (60 k triangles, 180 k edges): the edge-structure kernels beyond one workgroup's worth of anything."""
+    return triangle_soup(device, resolution, scale=40)
+
+
+def triangle_soup(device, resolution=(32, 32), scale=1):
     """Stress input for the edge-structure build (tests/test_edge_build.py): 1 500 seeded triangles in four shapes -- a cloud of
     free triangles, a coarse-grid cloud (vertex coordinates snapped to 1/8: many edges share their Morton code, so the order of
     equal codes and the id tie-break of the radix tree decide the topology), a strip mesh with shared vertices, and a stack of
@@ -65,8 +70,8 @@ def triangle_soup(device, resolution=(32, 32)):
             v = v + torch.tensor([[[0.0, 0.0, 0.0], [0.125, 0.0, 0.0], [0.0, 0.125, 0.0]]]) * (torch.rand(n, 1, 1, generator=g) < 0.3)   # some flat ones
         return v.reshape(-1, 3).contiguous(), torch.arange(3 * n, dtype=torch.int32).reshape(n, 3)
 
-    v0, i0 = free(600, False)
-    v1, i1 = free(500, True)
+    v0, i0 = free(600 * scale, False)
+    v1, i1 = free(500 * scale, True)
     # strip: 2 x 101 vertices, 200 triangles
     xs = torch.linspace(-2.0, 2.0, 101)
     top = torch.stack([xs, 0.3 + 0.2 * torch.sin(3 * xs), 1.5 + 0.1 * torch.cos(5 * xs)], 1)
@@ -75,7 +80,7 @@ def triangle_soup(device, resolution=(32, 32)):
     i2 = torch.tensor([[k, k + 1, 101 + k] for k in range(100)] + [[k + 1, 102 + k, 101 + k] for k in range(100)], dtype=torch.int32)
     # duplicates: the same triangle 200 times (separate vertices)
     t = torch.tensor([[-0.5, -0.5, -1.0], [0.5, -0.4, -1.1], [0.1, 0.6, -0.9]])
-    v3 = t.repeat(200, 1).contiguous()
+    v3 = t.repeat(200, 1).contiguous()            # (not scaled: thousands of identical codes make the radix tree deeper than the 64-entry traversal stacks)
     i3 = torch.arange(600, dtype=torch.int32).reshape(200, 3)
     shapes = [Shape(v.to(device).requires_grad_(True), i.to(device), 0) for v, i in ((v0, i0), (v1, i1), (v2, i2), (v3, i3))]
     light = Shape(_t([[-1.0, -1.0, -7.0], [1.0, -1.0, -7.0], [-1.0, 1.0, -7.0], [1.0, 1.0, -7.0]], device),

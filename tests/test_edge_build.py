@@ -51,7 +51,7 @@ def _compare(backend, builder, tmp_path, device):
 
 
 @pytest.mark.skipif(not oracle_util.oracle_available(), reason='oracle/_ref not built')
-@pytest.mark.parametrize('builder', ['two_triangles', 'bunny_box', 'triangle_soup'])
+@pytest.mark.parametrize('builder', ['two_triangles', 'bunny_box', 'triangle_soup', 'triangle_soup_large'])
 def test_edge_structures_match_reference(hostsim_backend, tmp_path, builder):
     """The host builder (edges.cpp: TreeBuilder), through the CPU harness."""
     _compare(hostsim_backend, builder, tmp_path, torch.device('cpu'))
@@ -59,7 +59,7 @@ def test_edge_structures_match_reference(hostsim_backend, tmp_path, builder):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not oracle_util.oracle_available(), reason='oracle/_ref not built')
-@pytest.mark.parametrize('builder', ['two_triangles', 'bunny_box', 'living_room_standin', 'single_triangle', 'triangle_soup'])
+@pytest.mark.parametrize('builder', ['two_triangles', 'bunny_box', 'living_room_standin', 'single_triangle', 'triangle_soup', 'triangle_soup_large'])
 def test_edge_structures_built_on_the_gpu_match_reference(gpu_backend, tmp_path, builder):
     """The kernels of edges_gpu.cpp (codes, sort, radix tree, bounds, treelets): the node arrays are read back from the
     device and must equal the reference's link for link, their weights, costs and bounds bit for bit."""
