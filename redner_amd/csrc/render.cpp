@@ -304,6 +304,7 @@ struct Backward {
     int lean = kGeneral;               // which stage specialisation the scene qualifies for (kLean / kMid / kGeneral)
     uint64_t *pcg_edge = nullptr;      // PCG edge sampler: one state per slot (src/pathtracer.cpp:221-222)
     int *edge_dyn = nullptr;           // device-side part of the edge sampler's dimension counter (see run_sample)
+    int *hoist_dyn = nullptr;          // the same counter as the hoisted first-vertex picks will find it (they run beside the sweep)
     double *multipliers = nullptr;     // [2P x nd], primary-edge channel weights (non-radiance channels only)
 
     Backward(const Scene &scene_, const rdr_render_options &opt_, GradStore &grads_, int P_, int B_,
@@ -319,6 +320,7 @@ struct Backward {
                               (scene.use_primary_edges || scene.use_secondary_edges);
         if (edges_on) {
             edge_dyn = arena.get<int>(1);
+            hoist_dyn = arena.get<int>(1);
             const int L = 2 * P;                      // edge lanes: two rays per sample slot
             ea = make_slice(arena, L, false);
             eb = make_slice(arena, L, false);
@@ -383,7 +385,14 @@ struct Backward {
     }
     void edge_rng_consumed_n(exec::Count n, int count) { edge_rng_consumed(n, count, nullptr); }
     // The edge sampler at dimension `edim` + what the device-side counter holds (see SamplerD::dyn)
-    SamplerD edge_rng_at(const SamplerD &rng_edge, int edim) const { SamplerD r = rng_edge; r.pcg_base = edim; r.dyn = edge_dyn; return r; }
+    SamplerD edge_rng_at(const SamplerD &rng_edge, int edim, const int *dyn = nullptr) const {
+        SamplerD r = rng_edge; r.pcg_base = edim; r.dyn = dyn ? dyn : edge_dyn; return r;
+    }
+    // A secondary-edge pass at a depth that had lanes has drawn its four numbers per slot (`n`: that depth's live-lane count)
+    void secondary_pass_consumed(exec::Count n) {
+        exec::launch(1, BumpDyn{edge_dyn, n.dev, 4});
+        edge_rng_consumed_n(n, 4);
+    }
 
     template <int LEAN> void launch_pick_n(int need, exec::Count nN, const SecEdgeArgs &sa) {
         // order-free gather over the billboard hierarchy (SecEdgeGatherN), then the reference-order walk for the slots it
@@ -443,8 +452,10 @@ struct Backward {
         const bool edges_on = prim_recs != nullptr;
         Sink esink{nullptr, edge_contrib, nd, radiance_dim, weight, ch, nullptr};
         Sink psink{nullptr, edge_contrib, nd, radiance_dim, weight, ch, multipliers};
-        // Edge-sampler dimension = edim (what the host can count: 4 per secondary pass, 2 for the primary pass) + *edge_dyn
-        // (7 per bounce of an edge sub-path that had lanes to run -- a device-side count, see trace_edge_paths)
+        // Edge-sampler dimension = edim (what the host can count: 2 for the primary pass) + *edge_dyn (what depends on live-lane
+        // counts, which stay on the device: 4 per secondary pass of a depth THAT HAD LANES -- the reference skips a dead depth
+        // before its sampler draws, src/pathtracer.cpp:432-436 -- and 7 per bounce of an edge sub-path that had lanes to run,
+        // see trace_edge_paths)
         int edim = 0;
         if (edge_dyn) exec::zero(edge_dyn, sizeof(int));
         exec::zero(adj.thr, sizeof(double) * 3 * P);
@@ -459,11 +470,11 @@ struct Backward {
         // run on the calling stream and the gather beside them.  Joined by join_picks().
         struct PickPhase { bool running = false, early = false, side = false; };
         PickPhase picks_phase;
-        auto start_picks = [&](int d, int edim_d, bool early, bool side) -> SecEdgeArgs {
+        auto start_picks = [&](int d, int edim_d, const int *dyn, bool early, bool side) -> SecEdgeArgs {
             const exec::Count nA = num_active[d];
             const int *act = active + (size_t)d * P;
             const EdgeSceneD &es = scene.edges->d;
-            SecEdgeArgs sa{scene.d, es, rng, dim0 + 7 * d, edge_rng_at(rng_edge, edim_d), edim_d, act, vs[d]};
+            SecEdgeArgs sa{scene.d, es, rng, dim0 + 7 * d, edge_rng_at(rng_edge, edim_d, dyn), edim_d, act, vs[d]};
             hipStream_t main_stream = exec::ctx().stream;
             const int need = es.max_stack;
             exec::Count nH(0), nN(0);
@@ -527,9 +538,24 @@ struct Backward {
         bool hoisted = false;
         static const bool hoist_allowed = std::getenv("RDR_NO_HOIST") == nullptr;          // A/B
         if (hoist_allowed && secondary_on && overlap && scene.diffuse_only && pcg_edge == nullptr && has_lights && B >= 2 && num_active[0].upper > 0) {
-            int edim0 = 0;
-            for (int d = B - 1; d >= 1; --d) if (num_active[d].upper > 0) edim0 += 4;
-            early_sa = start_picks(0, edim0, true, true);
+            // the dimension the sweep will have reached at the first vertex: 4 per deeper depth that has lanes (device counts)
+            int host_part = 0, k = 0;
+            bool first = true;
+            CountLiveDepths cl{hoist_dyn, {}, 0, 4, 0};
+            auto flush_gates = [&] {
+                cl.n = k; cl.add = first ? 0 : 1;
+                exec::launch(1, cl);
+                first = false; k = 0;
+            };
+            for (int d = B - 1; d >= 1; --d) {
+                if (num_active[d].upper <= 0) continue;
+                if (!num_active[d].dev) { host_part += 4; continue; }
+                cl.gate[k++] = num_active[d].dev;
+                if (k == kDepthGates) flush_gates();
+            }
+            if (k > 0 || first) flush_gates();
+            if (host_part) exec::launch(1, BumpDyn{hoist_dyn, nullptr, host_part});
+            early_sa = start_picks(0, 0, hoist_dyn, true, true);
             hoisted = true;
         }
         for (int d = B - 1; d >= 0 && has_lights; --d) {
@@ -543,8 +569,7 @@ struct Backward {
                 // and the sampler returns at once for every slot (src/edge.cpp:1396-1401).  Nothing of the pass remains but its
                 // sampler bookkeeping: four numbers drawn per slot.
                 with_edges = false;
-                edim += 4;
-                edge_rng_consumed_n(nA, 4);
+                secondary_pass_consumed(nA);
             }
             // The bounce adjoint of this depth, the hierarchical edge pick and the NEE-mode gather do not depend on each other
             // (the edge pass touches the adjoint records only in SecondaryEdgeDerivatives); each of them keeps a fraction of
@@ -566,14 +591,13 @@ struct Backward {
             if (with_edges) {
                 // ---- secondary (shadow / inter-reflection) edges at this vertex, :500-706 ----
                 const exec::Count lanes = exec::scaled_count(nA, 2);
-                const SecEdgeArgs sa = early_here ? early_sa : start_picks(d, edim, false, side);
+                const SecEdgeArgs sa = early_here ? early_sa : start_picks(d, edim, nullptr, false, side);
                 join_picks();
                 debug_dump("sec_mode", sample_id, d, sec_mode, (size_t)nA.upper);
                 debug_dump("sec_picks", sample_id, d, sec_picks, sizeof(SecPick) * (size_t)nA.upper);
                 launch_v(lean, nA, SecEdgeFinish{sa, sec_mode, sec_picks, d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});
                 debug_dump("sec_recs", sample_id, d, sec_recs, sizeof(SecondaryEdgeRec) * (size_t)nA.upper);
-                edim += 4;
-                edge_rng_consumed_n(nA, 4);
+                secondary_pass_consumed(nA);
                 const exec::Count n0 = exec::compact_dev((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
                 exec::launch(n0, QueueRays{elist[0], ea, edge_tmin, q.bsdf});
                 exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);

@@ -102,4 +102,21 @@ struct PcgAdvance {
     }
 };
 
+// Sobol' dimension bookkeeping that depends on live-lane counts the host never sees (`gate`: a device-side count).
+// The reference's backward sweep skips a path depth without live lanes BEFORE its edge sampler draws anything
+// (src/pathtracer.cpp:432-436), so the 4 numbers of a secondary-edge pass are consumed only by depths that have lanes.
+struct BumpDyn {                    // *dyn += inc if the depth had lanes (gate null: it had)
+    int *dyn; const int *gate; int inc;
+    RDR_FN void operator()(int) const { if (!gate || *gate > 0) *dyn += inc; }
+};
+constexpr int kDepthGates = 16;
+struct CountLiveDepths {            // *out (+)= inc x #{gates whose count is positive}
+    int *out; const int *gate[kDepthGates]; int n, inc, add;
+    RDR_FN void operator()(int) const {
+        int c = add ? *out : 0;
+        for (int i = 0; i < kDepthGates; ++i) if (i < n && *gate[i] > 0) c += inc;
+        *out = c;
+    }
+};
+
 } // namespace rdr

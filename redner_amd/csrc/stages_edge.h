@@ -190,11 +190,16 @@ struct SamplePrimaryEdges {
         int vw = sc.cam.vp_x1 - sc.cam.vp_x0, vh = sc.cam.vp_y1 - sc.cam.vp_y0;
         int xi = iclamp(int(pt.x * sc.cam.width - sc.cam.vp_x0), 0, vw);
         int yi = iclamp(int(pt.y * sc.cam.height - sc.cam.vp_y0), 0, vh);
-        V3 dc = radiance_dim >= 0 ? image_grad(d_image, nd, radiance_dim, yi * vw + xi) : v3(0);
+        // [quirk] the reference clamps to [0, vw] x [0, vh] INCLUSIVE (src/edge.cpp:447-450, 541-544): a point on the right
+        // border reads the first pixel of the next row (reproduced: same linear index); one on the bottom border, or in the
+        // bottom-right corner, reads past the image there -- here it reads the last pixel of its row / column instead
+        int pix = yi * vw + xi;
+        if (pix >= vw * vh) pix = (yi < vh ? yi : vh - 1) * vw + (xi < vw ? xi : vw - 1);
+        V3 dc = radiance_dim >= 0 ? image_grad(d_image, nd, radiance_dim, pix) : v3(0);
         double pmf = es.primary_pmf[eid];
         if (multipliers) {
             for (int d = 0; d < nd; ++d) {
-                double dch = d_image[(size_t)nd * (yi * vw + xi) + d];
+                double dch = d_image[(size_t)nd * pix + d];
                 multipliers[(size_t)nd * l0 + d] = linear ? dch / pmf : dch * jacobian / pmf;
                 multipliers[(size_t)nd * l1 + d] = linear ? -dch / pmf : -dch * jacobian / pmf;
             }

@@ -105,6 +105,9 @@ CASES = {
     'bunny_box_panorama_nosec_32x32x4': ('bunny_box_panorama', 32, 4, 2, None, {'use_secondary_edge_sampling': False}),
     # environment light only: NEE / BSDF-miss lookups, envmap adjoint, edge rays that reach the environment
     'envmap_sphere_48x48x4': ('envmap_sphere', 48, 4, 2),
+    # a convex object under the environment: path depths 1 and 2 have no live lanes (Sobol' dimension bookkeeping of the edge
+    # sampler across dead depths)
+    'envmap_convex_48x48x4': ('envmap_convex', 48, 4, 3),
     # separate uv / normal index buffers, two lights (two-sided; not directly visible), non-square image, viewport,
     # samples at pixel centres
     'misc_features_40x56x4': ('misc_features', (40, 56), 4, 2),
@@ -302,6 +305,43 @@ def oracle_self_inconsistency(ref, case, K=4):
 
 SELFDIFF_CASES = set(CONFIG_CASES) | {'bunny_box_96x96x8'}
 
+# ---- ref64: the oracle's estimator with the fp32 accumulation error taken out ------------------------------------------------
+# Few-element gradient tensors (light intensity, constant reflectances, camera, the 3 + 4 vertices of two_triangles) collect
+# millions of fp32 atomic adds per element in ONE backward pass of the reference (src/atomic.h:43-141), and the value it returns
+# moves by 1e-4 ... 1e-2 with the order of those adds (selfdiff above).  The backward pass is linear in the upstream gradient and
+# draws the same samples whatever it is, so the SAME estimator on the SAME samples is also the sum of K passes that each see the
+# upstream gradient on every K-th pixel only; each pass's fp32 accumulators then take K times fewer non-zero adds (adding an
+# exact 0 is exact) and the K results are summed in fp64.  ref64_<tensor> = that sum for K = 64, ref64conv_<tensor> = rel-L2
+# between the K = 16 and the K = 64 sums (what is left of the accumulation error: it shrinks with K).  The parity tests hold
+# every tensor that has a ref64_ entry to 1e-4 against it (tests/parity_util.py) -- no widened bar.
+REF64_K = (16, 64)
+REF64_MAX_ELEMS = 4096        # larger tensors (per-vertex / per-texel data) take few adds per element and meet 1e-4 as they are
+
+
+def oracle_striped_sum(ref, case, K):
+    acc = None
+    for k in range(K):
+        part = render_case(ref, *case, stripe=(k, K))
+        part = {n: v.astype(np.float64) for n, v in part.items() if n != 'image' and v.size <= REF64_MAX_ELEMS}
+        acc = part if acc is None else {n: acc[n] + part[n] for n in acc}
+    return acc
+
+
+def add_ref64(ref, name, case):
+    """Adds ref64_* / ref64conv_* to an existing fixture (its single-pass tensors stay as they are)."""
+    path = os.path.join(HERE, name + '.npz')
+    z = np.load(path)
+    out = {k: z[k] for k in z.files if not k.startswith('ref64')}
+    lo, hi = (oracle_striped_sum(ref, case, K) for K in REF64_K)
+    for n, v in hi.items():
+        nv = np.linalg.norm(v)
+        out['ref64_' + n] = v
+        out['ref64conv_' + n] = np.float64(np.linalg.norm(lo[n] - v) / nv if nv > 0 else 0.0)
+        one = out[n].astype(np.float64)
+        print('  %-28s single pass vs ref64 %.2e   K=%d vs K=%d %.2e' % (n, np.linalg.norm(one - v) / nv if nv > 0 else 0.0,
+                                                                         REF64_K[0], REF64_K[1], float(out['ref64conv_' + n])), flush=True)
+    np.savez_compressed(path, **out)
+
 
 def main():
     # The reference's primary-edge pass reads ray differentials from a scratch buffer at indices it never
@@ -315,6 +355,13 @@ def main():
         export_bunny_box()
     ref = oracle_util.load_oracle()
     only = [a for a in sys.argv[1:] if not a.startswith('--')]
+    if '--ref64' in sys.argv:                          # python make_golden.py --ref64 [case ...]: tens of minutes per config case
+        for name in sorted(SELFDIFF_CASES):
+            if only and name not in only:
+                continue
+            print(name, flush=True)
+            add_ref64(ref, name, (CASES.get(name) or CONFIG_CASES[name]))
+        return
     for name, case in list(CASES.items()) + list(CONFIG_CASES.items()):
         if (only and name not in only) or (not only and name in CONFIG_CASES and os.path.exists(os.path.join(HERE, name + '.npz'))):
             continue                                   # the config-size fixtures take minutes: made once, or on request

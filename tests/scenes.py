@@ -261,6 +261,15 @@ def envmap_sphere(device, resolution=(48, 48)):
     return Scene(base.camera, [sphere, ground], mats, [], envmap=env)
 
 
+def envmap_convex(device, resolution=(48, 48)):
+    """The glossy sphere of envmap_sphere ALONE under the environment map: a convex object, so every path leaves the scene
+    at its first bounce and the deeper path depths have no live lanes.  The reference's backward sweep skips such a depth
+    before its edge sampler draws (src/pathtracer.cpp:432-436): the Sobol' dimensions of the shallower edge passes must not
+    move (rendered with max_bounces 3)."""
+    full = envmap_sphere(device, resolution)
+    return Scene(full.camera, [full.shapes[0]], [full.materials[0]], [], envmap=full.envmap)
+
+
 def misc_features(device, resolution=(40, 56), viewport=None):
     """Odds and ends of the interface in one scene: separate uv / normal index buffers, a two-sided light, a light
     that is not directly visible, two area lights (light CDF), a non-square image and an optional viewport
