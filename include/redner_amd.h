@@ -199,6 +199,12 @@ void rdr_trace_stats_get(rdr_trace_stats *out);
  * traversal parity tests and micro-benchmarks. */
 int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, int num_rays, int any_hit);
 
+/* Per-call device buffers (the reference's PathBuffer, src/pathtracer.cpp:36-152, allocated and freed by every render())
+ * come from a caching allocator: blocks are parked for the next call of the same shape (bounded by RDR_POOL_CAP_MB per device,
+ * default 16384).  rdr_trim_cache() returns every parked block to the driver -- for processes that share the device with
+ * another allocator (torch) and change resolution.  Returns the number of bytes released. */
+uint64_t rdr_trim_cache(void);
+
 /* Test hook: how often the library has gone to the runtime for device memory (hipMalloc calls made by its caching allocator)
  * and how often the host has read a live-lane count back from the device, since the library was loaded.  A steady-state
  * rdr_render() adds nothing to either (the reference allocates its PathBuffer per call, src/pathtracer.cpp:36-152, and

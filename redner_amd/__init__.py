@@ -13,3 +13,9 @@ def install():
     from . import redner as _redner
     sys.modules['redner'] = _redner
     return _redner
+
+
+def trim_cache():
+    """Release the per-call device buffers the library keeps parked between render() calls (bytes released)."""
+    from . import redner as _redner
+    return _redner.trim_cache()

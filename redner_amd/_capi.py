@@ -113,7 +113,7 @@ class DebugCounters(C.Structure):
 EXPORTS = ('rdr_scene_create', 'rdr_scene_destroy', 'rdr_scene_max_generic_texture_dimension',
            'rdr_render', 'rdr_compute_num_channels', 'rdr_last_error',
            'rdr_trace_stats_enable', 'rdr_trace_stats_reset', 'rdr_trace_stats_get', 'rdr_scene_trace',
-           'rdr_debug_counters_get')
+           'rdr_debug_counters_get', 'rdr_trim_cache')
 
 _lib = None
 _lib_path = None
@@ -153,6 +153,8 @@ def load(path=None):
     lib.rdr_trace_stats_reset.restype = None
     lib.rdr_debug_counters_get.restype = None
     lib.rdr_debug_counters_get.argtypes = [C.POINTER(DebugCounters)]
+    lib.rdr_trim_cache.restype = C.c_uint64
+    lib.rdr_trim_cache.argtypes = []
     lib.rdr_trace_stats_get.restype = None
     lib.rdr_trace_stats_get.argtypes = [C.POINTER(TraceStats)]
     lib.rdr_scene_trace.restype = C.c_int

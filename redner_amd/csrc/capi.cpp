@@ -87,6 +87,13 @@ void rdr_trace_stats_get(rdr_trace_stats *out) {
     out->any_nodes = s.nodes[1]; out->any_tris = s.tris[1];
 }
 
+uint64_t rdr_trim_cache(void) {
+    std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+    const uint64_t bytes = exec::pool_cached_bytes();
+    exec::pool_trim();
+    return bytes;
+}
+
 void rdr_debug_counters_get(rdr_debug_counters *out) {
     out->device_mallocs = exec::pool_device_mallocs();
     out->host_count_reads = exec::host_count_reads();

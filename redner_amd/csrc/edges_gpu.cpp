@@ -566,22 +566,29 @@ inline dim3 grid_of(int n) { return dim3((unsigned)((n + 255) / 256)); }
 }  // namespace
 
 // Builds both hierarchies and everything derived from them on the calling thread's stream.  Inputs already on the device:
-// d.geom (per-edge geometry), d.gather (the billboard hierarchy with its slot -> edge table).  ed.owned receives every
-// allocation (released with the Scene).  Returns after the one read-back the host needs: the depth of the deeper tree.
+// d.geom (per-edge geometry), d.gather (the billboard hierarchy with its slot -> edge table).  ed.owned receives what the
+// samplers (and the debug dump) read -- node arrays, the samplers' records, the gather's leaf records -- released with the Scene.  Returns after the one read-back the host needs: the depth of the deeper tree.
 void build_edge_trees_device(EdgeData &ed) {
     hipStream_t s = exec::ctx().stream;
     auto alloc = [&](size_t bytes) -> void * { void *p = exec::pool_alloc(bytes ? bytes : 16); ed.owned.push_back(p); return p; };
-    auto up = [&](const void *src, size_t bytes) -> void * { void *p = alloc(bytes); if (bytes) exec::upload_async(p, src, bytes); return p; };
+    // what only the build reads (bounds, codes, sort scratch, counters, heights, level lists) goes back to the pool when the
+    // build ends -- after the stream has drained, also when it ends by an exception
+    struct Temporaries {
+        hipStream_t s; std::vector<void *> blocks;
+        ~Temporaries() { (void)hipStreamSynchronize(s); for (void *p : blocks) exec::pool_free(p); }
+    } temporaries{s, {}};
+    auto talloc = [&](size_t bytes) -> void * { void *p = exec::pool_alloc(bytes ? bytes : 16); temporaries.blocks.push_back(p); return p; };
+    auto up = [&](const void *src, size_t bytes) -> void * { void *p = talloc(bytes); if (bytes) exec::upload_async(p, src, bytes); return p; };
     EdgeSceneD &d = ed.d;
     const int ne = (int)ed.edges.size();
-    Box6D *bounds = (Box6D *)alloc(sizeof(Box6D) * (size_t)ne);
+    Box6D *bounds = (Box6D *)talloc(sizeof(Box6D) * (size_t)ne);
     const double *wlen = (const double *)up(ed.wlen.data(), sizeof(double) * (size_t)ne);
-    int *leaf_rank = (int *)alloc(sizeof(int) * (size_t)ne);
-    double *leaf_dx = (double *)alloc(sizeof(double) * 2 * (size_t)ne);
+    int *leaf_rank = (int *)talloc(sizeof(int) * (size_t)ne);
+    double *leaf_dx = (double *)talloc(sizeof(double) * 2 * (size_t)ne);
     // small integers the host reads back: per tree kMaxLevels + 1 level counts; then [0] depth of the 3-D tree, [1] of the
     // 6-D tree, [2] bounds not fp32
     constexpr int kLevelInts = kMaxLevels + 1;
-    int *ints = (int *)alloc(sizeof(int) * (size_t)(4 * kLevelInts + 4));
+    int *ints = (int *)talloc(sizeof(int) * (size_t)(4 * kLevelInts + 4));
     exec::zero(ints, sizeof(int) * (size_t)(4 * kLevelInts + 4));
     int *level_count[2] = {ints, ints + kLevelInts}, *cursor[2] = {ints + 2 * kLevelInts, ints + 3 * kLevelInts};
     int *flags = ints + 4 * kLevelInts;
@@ -601,25 +608,25 @@ void build_edge_trees_device(EdgeData &ed) {
         const int total = t.n_internal + n;
         const int *ids_in = (const int *)up(ids_h.data(), sizeof(int) * (size_t)n);
         const int sb_blocks = std::max(1, std::min(128, n / 2048));
-        Box6D *sb_part = (Box6D *)alloc(sizeof(Box6D) * (size_t)sb_blocks);
-        Box6D *sb = (Box6D *)alloc(sizeof(Box6D));
-        uint64_t *codes_in = (uint64_t *)alloc(sizeof(uint64_t) * (size_t)n), *codes = (uint64_t *)alloc(sizeof(uint64_t) * (size_t)n);
-        int *ids = (int *)alloc(sizeof(int) * (size_t)n);
+        Box6D *sb_part = (Box6D *)talloc(sizeof(Box6D) * (size_t)sb_blocks);
+        Box6D *sb = (Box6D *)talloc(sizeof(Box6D));
+        uint64_t *codes_in = (uint64_t *)talloc(sizeof(uint64_t) * (size_t)n), *codes = (uint64_t *)talloc(sizeof(uint64_t) * (size_t)n);
+        int *ids = (int *)talloc(sizeof(int) * (size_t)n);
         hipLaunchKernelGGL(scene_bounds_kernel, dim3((unsigned)sb_blocks), dim3(256), 0, s, bounds, ids_in, n, sb_part);
         hipLaunchKernelGGL(scene_bounds_kernel, dim3(1), dim3(256), 0, s, (const Box6D *)sb_part, (const int *)nullptr, sb_blocks, sb);
         hipLaunchKernelGGL(codes_kernel, grid_of(n), dim3(256), 0, s, bounds, ids_in, n, sb, t.is3d, codes_in);
         {
             size_t temp_bytes = 0;
             exec::check(rocprim::radix_sort_pairs(nullptr, temp_bytes, codes_in, codes, ids_in, ids, (size_t)n, 0, 64, s), "radix_sort_pairs (size)");
-            void *temp = alloc(temp_bytes);
+            void *temp = talloc(temp_bytes);
             exec::check(rocprim::radix_sort_pairs(temp, temp_bytes, codes_in, codes, ids_in, ids, (size_t)n, 0, 64, s), "radix_sort_pairs");
         }
         t.nodes = (EdgeNode *)alloc(sizeof(EdgeNode) * (size_t)total);
-        t.below = (int *)alloc(sizeof(int) * (size_t)total);
-        t.counter = (int *)alloc(sizeof(int) * (size_t)total);
-        t.height = (int *)alloc(sizeof(int) * (size_t)total);
+        t.below = (int *)talloc(sizeof(int) * (size_t)total);
+        t.counter = (int *)talloc(sizeof(int) * (size_t)total);
+        t.height = (int *)talloc(sizeof(int) * (size_t)total);
         t.level_count = level_count[tree];
-        t.level_list = (int *)alloc(sizeof(int) * (size_t)t.n_internal);
+        t.level_list = (int *)talloc(sizeof(int) * (size_t)t.n_internal);
         t.codes = codes; t.ids = ids;
         ed.dev_nodes[tree] = t.nodes;
         hipLaunchKernelGGL(init_nodes_kernel, grid_of(total), dim3(256), 0, s, t, bounds, wlen);

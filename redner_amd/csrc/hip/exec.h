@@ -148,7 +148,8 @@ inline void dfree(void *p) { if (p) (void)hipFree(p); }
 // arrays of a 1024 x 1024 render cost milliseconds and hipFree synchronises the device).  pool_trim() releases the cache.
 void *pool_alloc(size_t bytes);
 void pool_free(void *p);
-void pool_trim();
+void pool_trim();                     // hipFree of every parked block (synchronises the device first)
+size_t pool_cached_bytes();           // bytes parked in the free lists right now
 size_t pool_device_mallocs();          // number of hipMalloc calls made by the pool so far (tests: steady state adds none)
 inline std::atomic<size_t> &host_count_reads_ref() { static std::atomic<size_t> n{0}; return n; }
 inline size_t host_count_reads() { return host_count_reads_ref().load(); }     // live-lane counts read back by the host so far
@@ -162,6 +163,7 @@ inline void download(void *dst, const void *src, size_t bytes) {
     check(hipStreamSynchronize(ctx().stream), "download sync");
 }
 inline void sync() { check(hipStreamSynchronize(ctx().stream), "sync"); }
+inline void device_sync() { (void)hipDeviceSynchronize(); }        // every stream of the device (error paths; never throws)
 // Batched transfers for the Scene build (trace.hip): every array goes through one pinned staging buffer, the copies are
 // queued on the stream and ONE synchronisation ends the batch -- a pageable hipMemcpy + sync per array cost 30-200 us each,
 // ~50 of them per Scene.

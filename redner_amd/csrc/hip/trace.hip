@@ -75,17 +75,38 @@ void pool_free(void *p) {
     std::lock_guard<std::mutex> lk(pl.lock);
     auto it = pl.live.find(p);
     if (it == pl.live.end()) { (void)hipFree(p); return; }
-    pl.free_blocks[it->second.second & 15].emplace(it->second.first, p);
+    // The cache is bounded (RDR_POOL_CAP_MB, default 16 GiB per device of the 288 GB): a torch process shares the device with
+    // torch's own allocator, which cannot reclaim what is parked here; rdr_trim_cache() releases everything.
+    static const size_t cap = [] { const char *e = std::getenv("RDR_POOL_CAP_MB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 16384) << 20; }();
+    auto &fl = pl.free_blocks[it->second.second & 15];
+    size_t parked = it->second.first;
+    for (auto &kv : fl) parked += kv.first;
+    if (parked > cap) { (void)hipFree(p); pl.live.erase(it); return; }       // hipFree waits for the device: safe whatever is in flight
+    fl.emplace(it->second.first, p);
     pl.live.erase(it);
 }
 
 void pool_trim() {
     Pool &pl = pool();
     std::lock_guard<std::mutex> lk(pl.lock);
-    for (auto &fl : pl.free_blocks) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (int d = 0; d < 16; ++d) {
+        auto &fl = pl.free_blocks[d];
+        if (fl.empty()) continue;
+        (void)hipSetDevice(d);
         for (auto &kv : fl) (void)hipFree(kv.second);
         fl.clear();
     }
+    (void)hipSetDevice(dev);
+}
+
+size_t pool_cached_bytes() {
+    Pool &pl = pool();
+    std::lock_guard<std::mutex> lk(pl.lock);
+    size_t total = 0;
+    for (auto &fl : pl.free_blocks) for (auto &kv : fl) total += kv.first;
+    return total;
 }
 
 size_t pool_device_mallocs() { Pool &pl = pool(); std::lock_guard<std::mutex> lk(pl.lock); return pl.device_mallocs; }

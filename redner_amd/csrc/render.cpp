@@ -37,7 +37,12 @@ struct Arena {
         blocks.push_back(p);
         return p;
     }
-    ~Arena() { for (void *p : blocks) exec::pool_free(p); }
+    // Blocks go back to the pool for ANY stream to reuse: on the normal path render() has drained its streams by then; when the
+    // call ends by an exception, kernels may still be running on them
+    ~Arena() {
+        if (std::uncaught_exceptions() > 0) exec::device_sync();
+        for (void *p : blocks) exec::pool_free(p);
+    }
 };
 
 VSlice make_slice(Arena &a, int n, bool with_occl) {

@@ -434,7 +434,11 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
                 exec::StreamScope on(exec::side_stream(0));             // this thread's own stream
                 publish_edge_data(*ed);
                 exec::upload_flush();
-            } catch (...) { delete_edge_data(ed); throw; }
+            } catch (...) {
+                exec::device_sync();          // the builder's kernels may still be running: no block returns to the pool before
+                delete_edge_data(ed);
+                throw;
+            }
             return ed;
         });
         if (sync_edges || timer.on) s.edge_data();

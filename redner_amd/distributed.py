@@ -42,13 +42,17 @@ def _all_gather_sum_many(tensors, group):
     world = dist.get_world_size(group)
     if world == 1 or not tensors:
         return list(tensors)
-    flat = torch.cat([t.reshape(-1) for t in tensors])
-    red = _all_gather_sum(flat, group)
-    out, at = [], 0
-    for t in tensors:
-        n = t.numel()
-        out.append(red[at:at + n].reshape(t.shape))
-        at += n
+    out = [None] * len(tensors)
+    by_dtype = {}
+    for i, t in enumerate(tensors):                 # one bucket per dtype: torch.cat would promote a mixed list
+        by_dtype.setdefault(t.dtype, []).append(i)
+    for dtype, idx in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):       # the same order on every rank
+        red = _all_gather_sum(torch.cat([tensors[i].reshape(-1) for i in idx]), group)
+        at = 0
+        for i in idx:
+            n = tensors[i].numel()
+            out[i] = red[at:at + n].reshape(tensors[i].shape)
+            at += n
     return out
 
 

@@ -404,6 +404,12 @@ def render(scene, options, rendered_image, d_rendered_image, d_scene, screen_gra
         raise RuntimeError('redner.render: ' + _capi.last_error())
 
 
+def trim_cache():
+    """Not in the reference: return the device buffers parked by the caching allocator to the driver (rdr_trim_cache) --
+    for processes that share the GPU with torch's allocator and change resolution.  Returns the bytes released."""
+    return int(_capi.lib().rdr_trim_cache())
+
+
 # ---- Mitsuba .serialized meshes (src/redner.cpp:232-238, src/load_serialized.cpp:124-288) -----------------------------
 class MitsubaTriMesh:
     """vertices [V,3] f32, indices [T,3] i32, uvs [V,2] f32 or [0], normals [V,3] f32 or [0] (numpy)."""

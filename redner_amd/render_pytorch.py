@@ -413,8 +413,10 @@ class RenderFunction(torch.autograd.Function):
         screen_gradient_image = torch.zeros(h, w, 2, device=meta['device'])
         if grad_img is None:
             grad_img = torch.ones(h, w, nc, device=meta['device'])
-        grad_img = grad_img.contiguous()
+        grad_img = grad_img.to(meta['device'], torch.float32).contiguous()      # what the native side reads: fp32 on that device
         assert grad_img.shape == (h, w, nc)
+        if not torch.isfinite(grad_img).all():
+            raise ValueError('visualize_screen_gradient: grad_img is not finite')
         rd.render(u.scene, u.options, rd.float_ptr(0), rd.float_ptr(grad_img.data_ptr()), d_scene,
                   rd.float_ptr(screen_gradient_image.data_ptr()), rd.float_ptr(0))
         return screen_gradient_image

@@ -149,10 +149,12 @@ CONFIG_CASES = {
 SAMPLE_EXACT_ON_CPU_ONLY = {'bunny_box_fisheye_32x32x4', 'bunny_box_panorama_32x32x4'}
 
 
-def render_case(backend, builder, res, spp, mb, channels=None, opts=None, device=torch.device('cpu'), stripe=None):
+def render_case(backend, builder, res, spp, mb, channels=None, opts=None, device=torch.device('cpu'), stripe=None, blocks=None,
+                seed=1):
     """Forward + backward of one case; returns {'image': ..., 'grad_<i>_<name>': ...}.
     stripe = (k, K): the upstream gradient is zeroed except on pixels k, k + K, ... (row-major) -- see
-    oracle_self_inconsistency."""
+    oracle_self_inconsistency.  blocks = R: the samples are rendered as R contiguous blocks (sample_offset = b * spp / R)
+    and summed in block order -- the single-device counterpart of an R-rank run (redner_amd/distributed.py)."""
     import scenes
     from redner_amd.render_pytorch import RenderFunction
     sc = getattr(scenes, builder)(device, resolution=res if isinstance(res, tuple) else (res, res))
@@ -170,7 +172,11 @@ def render_case(backend, builder, res, spp, mb, channels=None, opts=None, device
     sampler = getattr(backend.SamplerType, opts.pop('sampler', 'sobol'))
     args = RenderFunction.serialize_scene(sc, spp, mb, channels=ch, sampler_type=sampler,
                                           device=device, backend=backend, **opts)
-    img = RenderFunction.apply(1, *args)
+    if blocks:
+        from redner_amd.distributed import render_blocked
+        img = render_blocked(seed, args, blocks)
+    else:
+        img = RenderFunction.apply(seed, *args)
     out = {'image': img.detach().cpu().numpy()}
     # upstream gradient: a fixed smooth pattern so every pixel/channel has a distinct weight
     h, w, c = img.shape

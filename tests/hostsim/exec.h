@@ -40,6 +40,8 @@ inline void zero(void *p, size_t bytes) { memset(p, 0, bytes); }
 inline void upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void download(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void sync() {}
+inline void device_sync() {}
+inline size_t pool_cached_bytes() { return 0; }
 inline int current_device() { return 0; }
 inline void upload_async(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void upload_flush() {}
