@@ -50,7 +50,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9     # CUs x SIMDs x lanes/clk x clock = 39.3 T lane-operations/s (79 TFLOP/s fp64 FMA)
-RAY_BYTES, HIT_BYTES, NODE_BYTES, TRI_BYTES = 32, 8, 32, 36
+RAY_BYTES, HIT_BYTES, NODE_BYTES, WIDE_NODE_BYTES, TRI_BYTES = 32, 8, 32, 128, 36
 
 
 class Prepared:
@@ -377,7 +377,7 @@ def main():
     out = None
     if rank == 0:
         rays = cnt.closest_rays
-        alg_bytes = rays * (RAY_BYTES + HIT_BYTES) + cnt.closest_nodes * NODE_BYTES + cnt.closest_tris * TRI_BYTES
+        alg_bytes = rays * (RAY_BYTES + HIT_BYTES) + cnt.closest_nodes * NODE_BYTES + cnt.closest_wide_nodes * WIDE_NODE_BYTES + cnt.closest_tris * TRI_BYTES
         alg_bytes_launch = alg_bytes / max(cnt.closest_launches, 1)
         mean_launch_ms = st.closest_ms / max(st.closest_launches, 1)
         achieved = alg_bytes_launch / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
@@ -408,7 +408,7 @@ def main():
                          'mean_launch_ms': mean_launch_ms, 'launches_per_step': st.closest_launches / max(a.steps, 1),
                          'rays_per_launch': rays_per_launch,
                          'rays_per_s': rays_per_launch / (mean_launch_ms * 1e-3) if mean_launch_ms > 0 else None,
-                         'nodes_per_ray': cnt.closest_nodes / max(rays, 1), 'tris_per_ray': cnt.closest_tris / max(rays, 1),
+                         'nodes_per_ray': cnt.closest_nodes / max(rays, 1), 'wide_nodes_per_ray': cnt.closest_wide_nodes / max(rays, 1), 'tris_per_ray': cnt.closest_tris / max(rays, 1),
                          'algorithmic_bytes_per_launch': alg_bytes_launch,
                          'hbm_frac_measured': tc['hbm_frac_of_peak'] if tc else None,
                          'valu_lane_util': tc['valu_lane_util'] if tc else None,

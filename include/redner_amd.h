@@ -188,6 +188,8 @@ typedef struct rdr_trace_stats {
     /* 32-byte node records loaded / 36-byte triangle records tested, per query kind; only
      * counted when counting is enabled (instrumented kernel variant) */
     uint64_t closest_nodes, closest_tris, any_nodes, any_tris;
+    /* 128-byte records of the 4-wide form of the hierarchy loaded (the kernels walk one form or the other per launch) */
+    uint64_t closest_wide_nodes, any_wide_nodes;
 } rdr_trace_stats;
 void rdr_trace_stats_enable(int timing, int counting);
 void rdr_trace_stats_reset(void);

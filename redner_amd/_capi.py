@@ -103,7 +103,8 @@ class TraceStats(C.Structure):
                 ('closest_launches', C.c_uint64), ('any_launches', C.c_uint64),
                 ('closest_rays', C.c_uint64), ('any_rays', C.c_uint64),
                 ('closest_nodes', C.c_uint64), ('closest_tris', C.c_uint64),
-                ('any_nodes', C.c_uint64), ('any_tris', C.c_uint64)]
+                ('any_nodes', C.c_uint64), ('any_tris', C.c_uint64),
+                ('closest_wide_nodes', C.c_uint64), ('any_wide_nodes', C.c_uint64)]
 
 
 class DebugCounters(C.Structure):

@@ -32,7 +32,8 @@ struct Box {
 struct Builder {
     Prim *prims = nullptr;
     BvhHost out;
-    static constexpr int kMaxBins = 64, kLeafMax = 4;
+    static constexpr int kMaxBins = 64;
+    int kLeafMax = 4;          // triangles per leaf (RDR_BVH_LEAF, 1..4)
     int kBins = 64;            // tuning knobs (RDR_BVH_BINS / RDR_BVH_TCOST); defaults from a sweep on bunny_box (profiles/r1_notes.md)
     float kTravCost = 0.3f;
 
@@ -130,7 +131,7 @@ struct Builder {
         set_bounds(0, b);
         if (!inner) { make_leaf(0, first, count); return; }
         Builder L, R;
-        L.prims = R.prims = prims; L.kBins = R.kBins = kBins; L.kTravCost = R.kTravCost = kTravCost;
+        L.prims = R.prims = prims; L.kBins = R.kBins = kBins; L.kTravCost = R.kTravCost = kTravCost; L.kLeafMax = R.kLeafMax = kLeafMax;
         auto left_job = hostpool::run([&] { L.build_top(first, mid - first, depth + 1); });
         R.build_top(mid, first + count - mid, depth + 1);
         left_job.wait();
@@ -234,7 +235,13 @@ template <class LeafBox> double refit_sweep(BvhHost &h, LeafBox leaf_box) {
 }
 }
 
+static double refit_bvh_binary(BvhHost &h, const std::vector<MeshView> &meshes);
 double refit_bvh(BvhHost &h, const std::vector<MeshView> &meshes) {
+    const double r = refit_bvh_binary(h, meshes);
+    collapse_wide(h);
+    return r;
+}
+static double refit_bvh_binary(BvhHost &h, const std::vector<MeshView> &meshes) {
     const size_t slots = h.ids.size() / 2;
     for (size_t sl = 0; sl < slots; ++sl) {
         const MeshView &m = meshes[(size_t)h.ids[2 * sl]];
@@ -260,11 +267,62 @@ double refit_box_bvh(BvhHost &h, const float *boxes) {
     });
 }
 
+void collapse_wide(BvhHost &h) {
+    h.wide.clear();
+    h.wide_stack_need = 0;
+    if (h.nodes.empty()) return;
+    auto area = [&](int i) {
+        const Node &n = h.nodes[i];
+        const float dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Item { int binary; int wide; int pending; };      // binary interior record -> its wide record; pending: stack entries above it
+    std::vector<Item> queue;                                // breadth first: the first records are the top of the hierarchy
+    h.wide.push_back(Node4{});
+    queue.push_back(Item{0, 0, 0});
+    for (size_t q = 0; q < queue.size(); ++q) {
+        const Item it = queue[q];
+        int kids[4], nk = 0;
+        if (h.nodes[it.binary].b > 0) kids[nk++] = it.binary;                 // a hierarchy that is one leaf
+        else { kids[nk++] = h.nodes[it.binary].a; kids[nk++] = h.nodes[it.binary].a + 1; }
+        while (nk < 4) {
+            int pick = -1; float best = -1.f;
+            for (int k = 0; k < nk; ++k) if (h.nodes[kids[k]].b == 0 && area(kids[k]) > best) { best = area(kids[k]); pick = k; }
+            if (pick < 0) break;
+            const int a = h.nodes[kids[pick]].a;
+            kids[pick] = a; kids[nk++] = a + 1;
+        }
+        Node4 w;
+        for (int k = 0; k < 4; ++k) {
+            w.lox[k] = w.loy[k] = w.loz[k] = std::numeric_limits<float>::infinity();
+            w.hix[k] = w.hiy[k] = w.hiz[k] = -std::numeric_limits<float>::infinity();
+            w.link[k] = kEmptyLink; w.aux[k] = 0;
+        }
+        w.aux[0] = nk;
+        // a walk that enters this record pushes at most nk - 1 entries and descends into one child
+        const int below = it.pending + nk - 1;
+        h.wide_stack_need = std::max(h.wide_stack_need, below + 1);
+        for (int k = 0; k < nk; ++k) {
+            const Node &c = h.nodes[kids[k]];
+            w.lox[k] = c.lo[0]; w.loy[k] = c.lo[1]; w.loz[k] = c.lo[2];
+            w.hix[k] = c.hi[0]; w.hiy[k] = c.hi[1]; w.hiz[k] = c.hi[2];
+            if (c.b > 0) w.link[k] = leaf_link(c.a, c.b);
+            else {
+                w.link[k] = (int)h.wide.size();
+                h.wide.push_back(Node4{});
+                queue.push_back(Item{kids[k], w.link[k], below});
+            }
+        }
+        h.wide[it.wide] = w;
+    }
+}
+
 BvhHost build_bvh(const std::vector<MeshView> &meshes) {
     Builder bd;
     std::vector<Prim> prims;
     if (const char *e = std::getenv("RDR_BVH_BINS")) bd.kBins = std::min(64, std::max(2, std::atoi(e)));
     if (const char *e = std::getenv("RDR_BVH_TCOST")) bd.kTravCost = (float)std::atof(e);
+    if (const char *e = std::getenv("RDR_BVH_LEAF")) bd.kLeafMax = std::min(4, std::max(1, std::atoi(e)));
     for (size_t s = 0; s < meshes.size(); ++s) {
         const MeshView &m = meshes[s];
         for (int t = 0; t < m.num_triangles; ++t) {
@@ -287,6 +345,7 @@ BvhHost build_bvh(const std::vector<MeshView> &meshes) {
     if (bd.out.depth + 2 > kTraverseStack) throw std::runtime_error("triangle hierarchy deeper than the traversal stack");
     reorder_breadth_first(bd.out);
     bd.out.inner_area = inner_half_area(bd.out);
+    collapse_wide(bd.out);
     return bd.out;
 }
 

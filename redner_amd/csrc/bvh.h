@@ -22,12 +22,32 @@ struct Node {
 };
 static_assert(sizeof(Node) == 32, "node must be 32 bytes");
 
+// The 4-wide form of the same hierarchy (bvh.cpp: collapse_wide), what the gfx950 ray kernels walk: one 128-byte record
+// = one cache line per interior node, holding the boxes of up to four children (one axis of the four per 16-byte load) and a
+// link per child.  A ray then takes half as many dependent steps as on the binary records -- one fetch per step instead of
+// the node's link words + its two children -- and a step tests four boxes with all of a step's loads in flight together.
+//   link >= 0          : index of the child's own record
+//   link <  0          : a leaf: first triangle slot (link & 0x7fffffff) >> 2, triangle count (link & 3) + 1
+//   link == kEmptyLink : no child in this place (the places are filled from 0 up)
+// Boxes are the padded boxes of the binary records, so the walk is conservative with respect to raytri.h all the same.
+struct alignas(16) Node4 {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    int link[4];
+    int aux[4];            // aux[0]: number of children; the rest unused (pads the record to a cache line)
+};
+static_assert(sizeof(Node4) == 128, "wide node must be one 128-byte line");
+constexpr int kEmptyLink = 0x7fffffff;
+RT_HD inline int leaf_link(int slot, int count) { return (int)(0x80000000u | ((unsigned)slot << 2) | (unsigned)(count - 1)); }
+
 struct BvhD {              // device/host view
     const Node *nodes;
     const float *tris;     // 9 floats per slot
     const int *ids;        // 2 ints per slot
     int num_nodes, num_tris;
     int stack_need;        // entries a traversal can need (hierarchy depth + 2); picks the kernel's LDS stack size
+    const Node4 *wide = nullptr;   // 4-wide records (null: only the binary form exists, e.g. the edge gather's hierarchy)
+    int num_wide = 0;
+    int wide_stack_need = 0;       // entries a walk of the wide records can need
 };
 
 struct Counters { unsigned long long nodes, tris; };
@@ -111,6 +131,85 @@ RT_HD inline Hit traverse(const BvhD &bvh, const float o[3], const float d[3], f
     return traverse_with<ANY, IDX>(bvh, o, d, tnear, tfar, stack, stride, cnt, FetchGlobal{bvh.nodes});
 }
 
+// ---- the walk over the 4-wide records (Node4) ----------------------------------------------------------------------------
+// One ray per lane; a step fetches ONE 128-byte record (one dependent round trip), tests its four child boxes, orders the
+// children that are hit by entry distance (a five-exchange network), pushes the farther ones and descends into the nearest;
+// a leaf child carries its triangle range in the link, so its triangles are tested without another fetch.  Stack entries
+// are links (32 bit), `stride` apart.  Hits are decided by ray_triangle / closer alone (raytri.h), so the result equals the
+// binary walk's and the brute-force rule's whatever the order of the visits.
+template <bool ANY>
+RT_HD inline Hit traverse_wide(const BvhD &bvh, const float o[3], const float d[3], float tnear, float tfar,
+                              int *stack, int stride, Counters *cnt) {
+    Hit best{tfar, -1, -1};
+    if (bvh.num_wide == 0) return best;
+    const float inv[3] = {1.f / d[0], 1.f / d[1], 1.f / d[2]};
+    unsigned long long nn = 0, nt = 0;
+    int sp = 0, cur = 0;
+    typedef float F2 __attribute__((vector_size(8)));
+    const F2 oo[3] = {F2{o[0], o[0]}, F2{o[1], o[1]}, F2{o[2], o[2]}}, ii[3] = {F2{inv[0], inv[0]}, F2{inv[1], inv[1]}, F2{inv[2], inv[2]}};
+    for (;;) {
+        if (cur >= 0) {
+            const Node4 nd = bvh.wide[cur];          // eight 16-byte loads, issued together
+            ++nn;
+            const float lim = best.shape < 0 ? tfar : best.t * 1.0000004f + 1e-30f;      // closed at best.t (tie-break by id)
+            float t[4]; int l[4] = {nd.link[0], nd.link[1], nd.link[2], nd.link[3]};
+            int nh = 0;
+            // slab distances of the four children, two children per operation: on gfx950 a two-float vector subtract /
+            // multiply is ONE packed instruction (v_pk_add_f32 / v_pk_mul_f32), the same IEEE result per component
+            float ax4[4], bx4[4], ay4[4], by4[4], az4[4], bz4[4];
+#define RT_SLAB(dst, src, k)                                                                              \
+            { const F2 p0 = (F2{src[0], src[1]} - oo[k]) * ii[k], p1 = (F2{src[2], src[3]} - oo[k]) * ii[k]; \
+              dst[0] = p0[0]; dst[1] = p0[1]; dst[2] = p1[0]; dst[3] = p1[1]; }
+            RT_SLAB(ax4, nd.lox, 0) RT_SLAB(bx4, nd.hix, 0) RT_SLAB(ay4, nd.loy, 1) RT_SLAB(by4, nd.hiy, 1) RT_SLAB(az4, nd.loz, 2) RT_SLAB(bz4, nd.hiz, 2)
+#undef RT_SLAB
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float ax = ax4[c], bx = bx4[c], ay = ay4[c], by = by4[c], az = az4[c], bz = bz4[c];
+                // NaN (0 * inf) must not cull: fmaxf / fminf return the non-NaN operand (raytri.h: ray_box_once)
+                float en = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+                float ex = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+                en -= fabsf(en) * 4e-7f;
+                ex *= 1.0000004f;
+                const float t0 = fmaxf(tnear, en), t1 = fminf(lim, ex);
+                const bool hit = l[c] != kEmptyLink && t0 <= t1;
+                t[c] = hit ? t0 : INFINITY;
+                nh += hit ? 1 : 0;
+            }
+            if (nh > 0) {
+                {                                       // misses carry t = inf and sink to the end
+#define RT_CSWAP(a, b) { const bool sw = t[b] < t[a]; const float ta = sw ? t[b] : t[a], tb = sw ? t[a] : t[b]; \
+                         const int la = sw ? l[b] : l[a], lb = sw ? l[a] : l[b]; t[a] = ta; t[b] = tb; l[a] = la; l[b] = lb; }
+                    RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+                    if (nh > 3) { stack[sp * stride] = l[3]; ++sp; }
+                    if (nh > 2) { stack[sp * stride] = l[2]; ++sp; }
+                    if (nh > 1) { stack[sp * stride] = l[1]; ++sp; }
+                }
+                cur = l[0];
+                continue;
+            }
+        } else {
+            const int first = (int)(((unsigned)cur & 0x7fffffffu) >> 2), count = (cur & 3) + 1;
+            for (int k = 0; k < count; ++k) {
+                const int slot = first + k;
+                const float *tv = bvh.tris + 9 * (size_t)slot;
+                float th;
+                ++nt;
+                if (ray_triangle(o, d, tnear, tfar, tv, tv + 3, tv + 6, &th)) {
+                    const int s = bvh.ids[2 * slot], p = bvh.ids[2 * slot + 1];
+                    if (ANY) { if (cnt) { cnt->nodes += nn; cnt->tris += nt; } return Hit{th, s, p}; }
+                    if (closer(th, s, p, best)) best = Hit{th, s, p};
+                }
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = stack[sp * stride];
+    }
+    if (cnt) { cnt->nodes += nn; cnt->tris += nt; }
+    return best;
+}
+
 } // namespace rt
 
 #include <vector>
@@ -122,6 +221,8 @@ struct BvhHost {
     std::vector<float> tris;
     std::vector<int> ids;
     int depth = 0;
+    std::vector<Node4> wide;          // collapse_wide(): the 4-wide records over the same leaves (triangle hierarchy only)
+    int wide_stack_need = 0;
 };
 struct MeshView { const float *vertices; const int *indices; int num_triangles; };
 // Binned-SAH top-down build over all triangles of all shapes (shape id = position in `meshes`).
@@ -134,4 +235,8 @@ BvhHost build_box_bvh(const float *boxes, int n);
 // nodes' half-areas over what it was when the hierarchy was built -- the caller rebuilds when that ratio drifts.
 double refit_bvh(BvhHost &h, const std::vector<MeshView> &meshes);
 double refit_box_bvh(BvhHost &h, const float *boxes);
+// (Re)derives h.wide / h.wide_stack_need from the binary records: every interior record adopts the children of its
+// largest-area interior child until it has four (or only leaves are left).  Linear in the node count; called after a build
+// and after a refit (the boxes are copies of the binary records' boxes).
+void collapse_wide(BvhHost &h);
 }

@@ -85,6 +85,7 @@ void rdr_trace_stats_get(rdr_trace_stats *out) {
     out->closest_rays = s.closest_rays; out->any_rays = s.any_rays;
     out->closest_nodes = s.nodes[0]; out->closest_tris = s.tris[0];
     out->any_nodes = s.nodes[1]; out->any_tris = s.tris[1];
+    out->closest_wide_nodes = s.wide_nodes[0]; out->any_wide_nodes = s.wide_nodes[1];
 }
 
 uint64_t rdr_trim_cache(void) {

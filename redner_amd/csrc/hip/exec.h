@@ -512,7 +512,7 @@ inline int read_count(Count c) {
 // ---- traversal kernels (trace.hip) --------------------------------------------------------------
 struct TraceStats {
     double closest_ms = 0, any_ms = 0;
-    uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes[2] = {0, 0}, tris[2] = {0, 0};
+    uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes[2] = {0, 0}, tris[2] = {0, 0}, wide_nodes[2] = {0, 0};   // node records: 32-byte binary / 128-byte 4-wide
     bool timing = false, counting = false;
 };
 TraceStats &trace_stats();

@@ -250,6 +250,34 @@ __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayR
     hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};
 }
 
+// ---- the walk over the 4-wide records (bvh.h: Node4) ---------------------------------------------------------------------
+// One ray per lane; a step fetches ONE 128-byte record (eight 16-byte loads issued together, one dependent round trip),
+// tests its four child boxes, orders the children that are hit by entry distance (a five-exchange network), pushes the
+// farther ones and descends into the nearest; a leaf child carries its triangle range in the link, so its triangles are
+// tested without another fetch.  Stack entries are links (32 bit) in an LDS column.  Hits are decided by rt::ray_triangle /
+// rt::closer alone (raytri.h), so the result equals the binary walk's and the brute-force rule's whatever the order.
+template <bool ANY, bool COUNT, int STACK>
+__global__ void __launch_bounds__(256) trace_wide_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays, rt::HitRec *__restrict__ hits,
+                                                         int n, const int *count, unsigned long long *counters) {
+    if (count) { const int c = *count; n = c < n ? c : n; }
+    if ((int)(blockIdx.x * 256) >= n) return;
+    __shared__ int stack_tile[STACK * 256];
+    int *stack = stack_tile + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const rt::RayRec r = rays[i];
+    rt::Hit h{0.f, -1, -1};
+    if (COUNT) atomicAdd(&counters[ANY ? 3 : 4], 1ull);
+    if (!(r.tmax < 0.f)) {
+        const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+        rt::Counters c{0, 0};
+        h = rt::traverse_wide<ANY>(bvh, o, d, r.tmin, r.tmax, stack, 256, COUNT ? &c : nullptr);
+        // counters = base of this query kind ({nodes, tris} at [0, 1]); the 4-wide records are tallied at g_counters[6] / [7]
+        if (COUNT) { atomicAdd(&counters[ANY ? 5 : 6], c.nodes); atomicAdd(&counters[1], c.tris); }
+    }
+    hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};
+}
+
 hipStream_t side_stream(int k) {
     // k = 0, 1: two non-blocking streams; k = 2, 3: two more at the LOWEST priority.  Where a kernel of the calling stream (a
     // sample's critical path: the continuation-ray traversal, the bounce adjoints) and one of a low-priority side stream
@@ -333,9 +361,10 @@ void trace_stats_collect() {           // call between render() calls: every wor
         g_pending.clear();
     }
     if (g_counters) {
-        unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         download(c, g_counters, sizeof(c));
         st.nodes[0] += c[0]; st.tris[0] += c[1]; st.nodes[1] += c[2]; st.tris[1] += c[3];
+        st.wide_nodes[0] += c[6]; st.wide_nodes[1] += c[7];
         st.closest_rays += c[4]; st.any_rays += c[5];          // queue lengths live on the device: the counting kernels tally them
         zero(g_counters, sizeof(c));
         sync();
@@ -359,6 +388,46 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count 
     // 256 rays costs more than the L1-hot top levels save (optimisation-loop iteration +2 ms).  RDR_TRACE_NO_LDS_TOP=1: never.
     static const bool stage_allowed = std::getenv("RDR_TRACE_NO_LDS_TOP") == nullptr;
     const bool stage_top = stage_allowed && n >= (1 << 18);
+    // Which form of the hierarchy: occlusion queries walk the 4-wide records, closest-hit queries do so on queues below
+    // RDR_WIDE_CLOSEST_MAX rays (measured, tools/trace_ab.py, profiles/r3_notes.md: half the dependent steps per ray pays where
+    // a launch is one or two waves per SIMD; on a million-ray queue the binary records are a few per cent ahead).
+    // RDR_TRACE_BINARY=1: never the wide records.
+    static const bool wide_allowed = std::getenv("RDR_TRACE_BINARY") == nullptr;
+    static const int wide_closest_max = [] { const char *e = std::getenv("RDR_WIDE_CLOSEST_MAX"); return e ? std::atoi(e) : (1 << 19); }();
+    if (wide_allowed && bvh.wide != nullptr && bvh.wide_stack_need <= 48 && (any || n < wide_closest_max)) {
+        unsigned long long *ctr = nullptr;
+        if (st.counting) {
+            std::lock_guard<std::mutex> lk(g_stats_lock);
+            if (!g_counters) {
+                g_counters = (unsigned long long *)dmalloc(64);
+                check(hipMemset(g_counters, 0, 64), "hipMemset");
+            }
+            ctr = any ? g_counters + 2 : g_counters;
+        }
+#define RDR_WIDE_LAUNCH(ANY_, COUNT_, STACK_) \
+        hipLaunchKernelGGL((trace_wide_kernel<ANY_, COUNT_, STACK_>), dim3(blocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, ctr)
+        const int wneed = bvh.wide_stack_need;
+#define RDR_WIDE_BY_STACK(ANY_, COUNT_)                                        \
+        do {                                                                   \
+            if (wneed <= 12) RDR_WIDE_LAUNCH(ANY_, COUNT_, 12);  \
+            else if (wneed <= 16) RDR_WIDE_LAUNCH(ANY_, COUNT_, 16); \
+            else if (wneed <= 20) RDR_WIDE_LAUNCH(ANY_, COUNT_, 20); \
+            else if (wneed <= 24) RDR_WIDE_LAUNCH(ANY_, COUNT_, 24); \
+            else if (wneed <= 32) RDR_WIDE_LAUNCH(ANY_, COUNT_, 32); \
+            else RDR_WIDE_LAUNCH(ANY_, COUNT_, 48);                            \
+        } while (0)
+        if (st.counting) { if (any) RDR_WIDE_BY_STACK(true, true); else RDR_WIDE_BY_STACK(false, true); }
+        else { if (any) RDR_WIDE_BY_STACK(true, false); else RDR_WIDE_BY_STACK(false, false); }
+#undef RDR_WIDE_BY_STACK
+#undef RDR_WIDE_LAUNCH
+        check(hipGetLastError(), "trace launch");
+        if (st.timing) check(hipEventRecord(p.b, s), "hipEventRecord");
+        std::lock_guard<std::mutex> lk(g_stats_lock);
+        if (st.timing) g_pending.push_back(p);
+        (any ? st.any_launches : st.closest_launches)++;
+        if (!st.counting) (any ? st.any_rays : st.closest_rays) += (uint64_t)n;
+        return;
+    }
 #define RDR_TRACE_LAUNCH(ANY_, COUNT_, STACK_, ctr)                                                                          \
     do {                                                                                                                     \
         if (bvh.num_nodes < 65536 && stage_top)                                                                              \
@@ -381,8 +450,8 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count 
         {
             std::lock_guard<std::mutex> lk(g_stats_lock);
             if (!g_counters) {
-                g_counters = (unsigned long long *)dmalloc(48);
-                check(hipMemset(g_counters, 0, 48), "hipMemset");        // synchronous: another worker's launch may be next
+                g_counters = (unsigned long long *)dmalloc(64);
+                check(hipMemset(g_counters, 0, 64), "hipMemset");        // synchronous: another worker's launch may be next
             }
         }
         // counters: {nodes, tris} of this query type at [0, 1], its ray tally at [4] (closest) / [3] relative to base + 2 (any)

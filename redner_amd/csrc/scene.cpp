@@ -453,6 +453,9 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         s.bvh.nodes = to_device(s, s.bvh_host.nodes.data(), s.bvh_host.nodes.size());
         s.bvh.tris = to_device(s, s.bvh_host.tris.data(), s.bvh_host.tris.size());
         s.bvh.ids = to_device(s, s.bvh_host.ids.data(), s.bvh_host.ids.size());
+        s.bvh.num_wide = (int)s.bvh_host.wide.size();
+        s.bvh.wide_stack_need = s.bvh_host.wide_stack_need;
+        s.bvh.wide = s.bvh.num_wide > 0 ? to_device(s, s.bvh_host.wide.data(), s.bvh_host.wide.size()) : nullptr;
         timer.lap("triangle hierarchy (wait)");
     }
     exec::upload_flush();

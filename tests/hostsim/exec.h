@@ -105,12 +105,12 @@ inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const 
     if (dyn && n_in > 0) *dyn += inc;
     return Count(result, n.upper + (append_at ? append_at->upper : 0));
 }
-struct TraceStats { double closest_ms = 0, any_ms = 0; uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes[2] = {0, 0}, tris[2] = {0, 0}; bool timing = false, counting = false; };
+struct TraceStats { double closest_ms = 0, any_ms = 0; uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes[2] = {0, 0}, tris[2] = {0, 0}, wide_nodes[2] = {0, 0}; bool timing = false, counting = false; };
 inline TraceStats &trace_stats() { static TraceStats s; return s; }
 inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count cnt_n, bool any) {
     const int n = cnt_n.value();
     TraceStats &st = trace_stats();
-    rt::Counters cnt{0, 0};
+    rt::Counters cnt{0, 0}, wcnt{0, 0};
     static const bool sim = std::getenv("RDR_TRACE_SIM") != nullptr;
     if (sim) tracesim::launch(bvh, rays, n, any);
     for (int i = 0; i < n; ++i) {
@@ -119,6 +119,13 @@ inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits,
         if (!(r.tmax < 0.f)) {
             float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
             int stack[rt::kTraverseStack];
+            static const bool binary = std::getenv("RDR_TRACE_BINARY") != nullptr;
+            if (bvh.wide && !binary) {            // like the GPU build: the 4-wide records when the hierarchy has them
+                int wstack[64];
+                if (bvh.wide_stack_need > 64) throw std::runtime_error("wide hierarchy deeper than the harness stack");
+                h = any ? rt::traverse_wide<true>(bvh, o, d, r.tmin, r.tmax, wstack, 1, st.counting ? &wcnt : nullptr)
+                        : rt::traverse_wide<false>(bvh, o, d, r.tmin, r.tmax, wstack, 1, st.counting ? &wcnt : nullptr);
+            } else
             h = any ? rt::traverse<true>(bvh, o, d, r.tmin, r.tmax, stack, 1, st.counting ? &cnt : nullptr)
                     : rt::traverse<false>(bvh, o, d, r.tmin, r.tmax, stack, 1, st.counting ? &cnt : nullptr);
         }
@@ -126,7 +133,7 @@ inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits,
     }
     (any ? st.any_launches : st.closest_launches)++;
     (any ? st.any_rays : st.closest_rays) += n;
-    st.nodes[any ? 1 : 0] += cnt.nodes; st.tris[any ? 1 : 0] += cnt.tris;
+    st.nodes[any ? 1 : 0] += cnt.nodes; st.tris[any ? 1 : 0] += cnt.tris + wcnt.tris; st.wide_nodes[any ? 1 : 0] += wcnt.nodes;
 }
 } // namespace exec
 namespace exec {

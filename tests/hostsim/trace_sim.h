@@ -61,7 +61,7 @@ inline Path record(const rt::BvhD &bvh, const float o[3], const float d[3], floa
 
 constexpr double Ci = 110, Ct = 190, Cr = 150;
 
-struct Tot { double multi_s[3] = {0, 0, 0}, multi_d[3] = {0, 0, 0}; double vote[4] = {0, 0, 0, 0}, vote_sorted[4] = {0, 0, 0, 0}; double useful = 0, ifif = 0, whilewhile = 0, ww_sorted = 0, refill8 = 0, refill24 = 0, refill_sorted = 0; long rays = 0, live = 0; };
+struct Tot { double rep[8] = {0}; double bud[12] = {0}; double vw[6] = {0, 0, 0, 0, 0, 0}; double multi_s[3] = {0, 0, 0}, multi_d[3] = {0, 0, 0}; double vote[4] = {0, 0, 0, 0}, vote_sorted[4] = {0, 0, 0, 0}; double useful = 0, ifif = 0, whilewhile = 0, ww_sorted = 0, refill8 = 0, refill24 = 0, refill_sorted = 0; long rays = 0, live = 0; };
 inline Tot &tot(bool any) { static Tot t[2]; return t[any ? 1 : 0]; }
 
 inline double useful_of(const Path &p) { double c = 0; for (const Seg &s : p) c += Ci * s.inner + Ct * s.tris; return c; }
@@ -207,6 +207,129 @@ inline double sim_vote(const std::vector<const Path *> &q, int idle_min, int par
     return cost;
 }
 
+// one wave, one ray per lane, NO refill: lanes park on leaves; an iteration is either one inner step (for the lanes that are
+// not parked) or one triangle test per parked lane, by vote: triangles when >= park_min lanes are parked or nobody can do an
+// inner step.  `overhead`: extra instructions per iteration for the vote.
+inline double sim_vote_wave(const Path *const *lanes, int n, int park_min, double overhead) {
+    std::vector<size_t> seg(n, 0); std::vector<int> inner_left(n, 0), tris_left(n, 0); std::vector<char> live(n, 0);
+    auto load_seg = [&](int l) {
+        for (;;) {
+            if (seg[l] >= lanes[l]->size()) { live[l] = 0; return; }
+            inner_left[l] = (*lanes[l])[seg[l]].inner; tris_left[l] = (*lanes[l])[seg[l]].tris;
+            if (inner_left[l] == 0 && tris_left[l] == 0) { ++seg[l]; continue; }
+            return;
+        }
+    };
+    for (int l = 0; l < n; ++l) { live[l] = 1; load_seg(l); }
+    double cost = 0;
+    for (;;) {
+        int want_inner = 0, parked = 0;
+        for (int l = 0; l < n; ++l) if (live[l]) { if (inner_left[l] > 0) ++want_inner; else ++parked; }
+        if (want_inner == 0 && parked == 0) break;
+        cost += overhead;
+        if (parked >= park_min || want_inner == 0) {
+            cost += Ct;
+            for (int l = 0; l < n; ++l) if (live[l] && inner_left[l] == 0) { if (--tris_left[l] == 0) { ++seg[l]; load_seg(l); } }
+        } else {
+            cost += Ci;
+            for (int l = 0; l < n; ++l) if (live[l] && inner_left[l] > 0) { --inner_left[l]; if (inner_left[l] == 0 && tris_left[l] == 0) { ++seg[l]; load_seg(l); } }
+        }
+    }
+    return cost;
+}
+
+// Work budget + continuation queue: pass k runs every wave (64 consecutive queue entries, if-if body; vote = true: parked
+// lanes + vote instead) for at most budget[k] iterations; the lanes that are not finished by then are appended, in order, to
+// the queue of the next pass (compacted: long rays end up together, in full waves), where they resume.  `hand_off`: instructions
+// per wave and pass for saving / restoring the state of the continuing lanes.
+struct LaneState { const Path *p; size_t seg; int done_inner; int tris_done; };
+inline double sim_budget(const std::vector<const Path *> &q0, const int *budget, int passes, bool vote, int park_min, double hand_off) {
+    std::vector<LaneState> q;
+    for (const Path *p : q0) q.push_back(LaneState{p, 0, 0, 0});
+    double cost = 0;
+    for (int pass = 0; pass < passes && !q.empty(); ++pass) {
+        std::vector<LaneState> next;
+        const int B = pass == passes - 1 ? 1 << 30 : budget[pass];
+        for (size_t w = 0; w < q.size(); w += 64) {
+            const int n = (int)std::min<size_t>(64, q.size() - w);
+            LaneState *L = q.data() + w;
+            bool handed = false;
+            for (int it = 0; it < B; ++it) {
+                bool any_i = false, alive = false; int max_t = 0, want_inner = 0, parked = 0;
+                for (int l = 0; l < n; ++l) {
+                    if (L[l].seg >= L[l].p->size()) continue;
+                    alive = true;
+                    const Seg &sg = (*L[l].p)[L[l].seg];
+                    if (L[l].done_inner < sg.inner) ++want_inner; else ++parked;
+                }
+                if (!alive) break;
+                if (!vote) {
+                    for (int l = 0; l < n; ++l) {
+                        if (L[l].seg >= L[l].p->size()) continue;
+                        const Seg &sg = (*L[l].p)[L[l].seg];
+                        if (L[l].done_inner < sg.inner) { any_i = true; ++L[l].done_inner; if (L[l].done_inner == sg.inner && sg.tris == 0) { ++L[l].seg; L[l].done_inner = 0; } }
+                        else { max_t = std::max(max_t, sg.tris); ++L[l].seg; L[l].done_inner = 0; }
+                    }
+                    cost += (any_i ? Ci : 0) + Ct * max_t;
+                } else {
+                    cost += 8;
+                    const bool do_tris = parked >= park_min || want_inner == 0;
+                    cost += do_tris ? Ct : Ci;
+                    for (int l = 0; l < n; ++l) {
+                        if (L[l].seg >= L[l].p->size()) continue;
+                        const Seg &sg = (*L[l].p)[L[l].seg];
+                        const bool inner = L[l].done_inner < sg.inner;
+                        if (do_tris && !inner) { if (++L[l].tris_done >= sg.tris) { ++L[l].seg; L[l].done_inner = 0; L[l].tris_done = 0; } }
+                        else if (!do_tris && inner) { ++L[l].done_inner; if (L[l].done_inner == sg.inner && sg.tris == 0) { ++L[l].seg; L[l].done_inner = 0; } }
+                    }
+                }
+            }
+            for (int l = 0; l < n; ++l) if (L[l].seg < L[l].p->size()) { next.push_back(L[l]); handed = true; }
+            if (handed) cost += hand_off;
+            if (pass > 0) cost += hand_off;
+        }
+        q.swap(next);
+    }
+    return cost;
+}
+
+// Workgroup-local re-packing: a workgroup of `wg` consecutive rays (wg / 64 waves, if-if body); every `every` iterations the
+// rays that are still alive are packed densely into the first waves of the workgroup (waves without rays issue nothing).
+// `repack_cost`: instructions per live wave and re-pack.
+inline double sim_repack(const std::vector<const Path *> &q0, int wg, int every, double repack_cost) {
+    double cost = 0;
+    for (size_t base = 0; base < q0.size(); base += wg) {
+        std::vector<LaneState> L;
+        for (size_t i = base; i < std::min(q0.size(), base + (size_t)wg); ++i) L.push_back(LaneState{q0[i], 0, 0, 0});
+        for (;;) {
+            // drop finished rays (re-pack), keep order
+            std::vector<LaneState> live;
+            for (const LaneState &l : L) if (l.seg < l.p->size()) live.push_back(l);
+            L.swap(live);
+            if (L.empty()) break;
+            const int waves = ((int)L.size() + 63) / 64;
+            cost += repack_cost * waves;
+            for (int w = 0; w < waves; ++w) {
+                LaneState *W = L.data() + (size_t)w * 64;
+                const int n = std::min(64, (int)L.size() - w * 64);
+                for (int it = 0; it < every; ++it) {
+                    bool any_i = false, alive = false; int max_t = 0;
+                    for (int l = 0; l < n; ++l) {
+                        if (W[l].seg >= W[l].p->size()) continue;
+                        alive = true;
+                        const Seg &sg = (*W[l].p)[W[l].seg];
+                        if (W[l].done_inner < sg.inner) { any_i = true; ++W[l].done_inner; if (W[l].done_inner == sg.inner && sg.tris == 0) { ++W[l].seg; W[l].done_inner = 0; } }
+                        else { max_t = std::max(max_t, sg.tris); ++W[l].seg; W[l].done_inner = 0; }
+                    }
+                    if (!alive) break;
+                    cost += (any_i ? Ci : 0) + Ct * max_t;
+                }
+            }
+        }
+    }
+    return cost;
+}
+
 // RDR_TRACE_SIM_KEY: "<bits per axis of the origin grid><o|n: with / without the direction octant><f|l: octant first / last>"
 inline unsigned sort_key(const rt::BvhD &bvh, const rt::RayRec &r) {
     static const char *mode = std::getenv("RDR_TRACE_SIM_KEY") ? std::getenv("RDR_TRACE_SIM_KEY") : "4ol";
@@ -240,6 +363,12 @@ inline void report() {
         const int parks[4] = {8, 16, 32, 48};
         for (int i = 0; i < 4; ++i) { char nm[64]; std::snprintf(nm, sizeof nm, "vote park>=%d", parks[i]); line(nm, t.vote[i]); }
         for (int i = 0; i < 4; ++i) { char nm[64]; std::snprintf(nm, sizeof nm, "vote park>=%d, sorted", parks[i]); line(nm, t.vote_sorted[i]); }
+        { const int pk[6] = {1, 4, 8, 16, 24, 32}; for (int i = 0; i < 6; ++i) { char nm[64]; std::snprintf(nm, sizeof nm, "vote, no refill, park>=%d", pk[i]); line(nm, t.vw[i]); } }
+        { const char *nm[12] = {"budget 16,inf", "budget 24,inf", "budget 32,inf", "budget 16,32,inf", "budget 24,48,inf", "budget 12,24,48,inf",
+                                "budget 24,inf vote8", "budget 32,inf vote8", "budget 24,48,inf vote8", "budget 32,64,inf vote8", "budget 32,64,inf vote16", "budget 48,96,inf vote8"};
+          for (int i = 0; i < 12; ++i) line(nm[i], t.bud[i]); }
+        { const char *nm[8] = {"repack wg 256 every 8", "repack wg 512 every 8", "repack wg 1024 every 8", "repack wg 1024 every 4", "repack wg 1024 every 16", "repack wg 1024 every 12", "repack wg 2048 every 8", "repack wg 1024 every 8 (free)"};
+          for (int i = 0; i < 8; ++i) line(nm[i], t.rep[i]); }
         line("refill (>= 8 idle)", t.refill8); line("refill (>= 24 idle)", t.refill24); line("refill (>= 8), sorted", t.refill_sorted);
     }
 }
@@ -261,6 +390,12 @@ inline void launch(const rt::BvhD &bvh, const rt::RayRec *rays, int n, bool any)
     std::vector<const Path *> q(n);
     for (int i = 0; i < n; ++i) q[i] = &paths[i];
     for (int w = 0; w < n; w += 64) { int m = std::min(64, n - w); t.ifif += sim_ifif(q.data() + w, m); t.whilewhile += sim_ww(q.data() + w, m); }
+    { const int pk[6] = {1, 4, 8, 16, 24, 32}; for (int i = 0; i < 6; ++i) for (int w = 0; w < n; w += 64) { int m = std::min(64, n - w); t.vw[i] += sim_vote_wave(q.data() + w, m, pk[i], 8); } }
+    { const int b[12][3] = {{16, 0, 0}, {24, 0, 0}, {32, 0, 0}, {16, 32, 0}, {24, 48, 0}, {12, 24, 48}, {24, 0, 0}, {32, 0, 0}, {24, 48, 0}, {32, 64, 0}, {32, 64, 0}, {48, 96, 0}};
+      const int np[12] = {2, 2, 2, 3, 3, 4, 2, 2, 3, 3, 3, 3}; const bool vt[12] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1}; const int pm[12] = {0, 0, 0, 0, 0, 0, 8, 8, 8, 8, 16, 8};
+      for (int i = 0; i < 12; ++i) t.bud[i] += sim_budget(q, b[i], np[i], vt[i], pm[i], 80); }
+    { const int wg[8] = {256, 512, 1024, 1024, 1024, 1024, 2048, 1024}, ev[8] = {8, 8, 8, 4, 16, 12, 8, 8}; const double rc[8] = {100, 100, 100, 100, 100, 100, 100, 0};
+      for (int i = 0; i < 8; ++i) t.rep[i] += sim_repack(q, wg[i], ev[i], rc[i]); }
     { const int ks[3] = {2, 4, 8};
       for (int i = 0; i < 3; ++i) for (int w = 0; w < n; w += 64 * ks[i]) { int m = std::min(64 * ks[i], n - w); t.multi_s[i] += sim_multi(q.data() + w, m, ks[i], false); t.multi_d[i] += sim_multi(q.data() + w, m, ks[i], true); } }
     t.refill8 += sim_refill(q, 8); t.refill24 += sim_refill(q, 24);
