@@ -27,7 +27,9 @@ Extra objects in the JSON line:
                    dominate the backward pass (`kernels`: fp64 VALU lane-operations/s against the 39.3 T/s the
                    chip can issue, HBM bytes/s against 8 TB/s).
   cpu_baseline  -- the reference's own C++ core (oracle/_ref, Embree stand-in) on this box's host
-                   cores, on a bounded sample of the same workload (rank 0, N = 1 only).
+                   cores, on bounded samples of the same workload (rank 0, N = 1 only); `gpu_vs_reference`: the full frame
+                   at 1 spp rendered by both and compared (image + every gradient tensor).
+  self_check    -- untimed: the frame in 8 sample blocks (what 8 ranks render) against one call.
 """
 import argparse
 import collections
@@ -111,27 +113,77 @@ def build_scene(a, device, res):
     return scenes.bunny_box(device, resolution=(res, res))
 
 
-def cpu_baseline(a):
-    """The reference's C++ core (oracle/_ref) on the host cores, bounded sample of the workload."""
+def _rel_l2(x, y):
+    x, y = x.double().cpu().flatten(), y.double().cpu().flatten()
+    n = float(torch.linalg.norm(y))
+    return float(torch.linalg.norm(x - y)) / n if n > 0 else float(torch.linalg.norm(x))
+
+
+def cpu_baseline(a, gpu_rd=None, gpu_dev=None):
+    """The reference's C++ core (oracle/_ref) on the host cores, bounded samples of the workload: a small frame at several spp
+    and the benchmark's own 1024 x 1024 frame at 1 spp (4 096 chunks of 256 pixels for the reference's thread pool,
+    src/parallel.cpp:228-255: enough work for every core of a 256-thread box).  The better rate is reported.  The full-frame
+    sample is also rendered by the GPU library with the same seeds and compared -- the checker used as a checker: the job the
+    benchmark times, validated at its own resolution (forward image and every gradient tensor)."""
     import oracle_util
     if not oracle_util.oracle_available():
         return None
     ref = oracle_util.load_oracle()
-    res, spp = 256, 4
     cpu = torch.device('cpu')
-    p = Prepared(ref, build_scene(a, cpu, res), spp, spp, 0, a.max_bounces, cpu)
-    p.step(0)                                   # warm-up (thread pool, page faults)
-    t0 = time.time()
-    reps = 0
-    while time.time() - t0 < 12.0:
-        p.step(reps + 1)
-        reps += 1
-    dt = time.time() - t0
-    return {'value': res * res * spp * reps / dt / 1e6, 'unit': 'Msamples/s', 'cores': os.cpu_count(),
-            'kind': 'reference',
-            'sample': '%s %dx%d, %d spp fwd+bwd, max_bounces %d, Sobol, %d repetitions in %.1f s; '
-                      'reference C++ core (oracle/_ref) with the BVH Embree stand-in, all host threads'
-                      % (a.workload, res, res, spp, a.max_bounces, reps, dt)}
+    lines, best, check = [], None, None
+    for res, spp, budget in ((256, 4, 6.0), (a.res, 1, 9.0)):
+        p = Prepared(ref, build_scene(a, cpu, res), spp, spp, 0, a.max_bounces, cpu)
+        p.step(0)                                   # warm-up (thread pool, page faults); also the step the GPU is compared with
+        if gpu_rd is not None and res == a.res:
+            g = Prepared(gpu_rd, build_scene(a, gpu_dev, res), spp, spp, 0, a.max_bounces, gpu_dev)
+            g.step(0)
+            torch.cuda.synchronize(gpu_dev)
+            worst = max((_rel_l2(x, y) for x, y in zip(g.grads, p.grads) if float(y.abs().sum()) > 0), default=0.0)
+            check = {'job': '%s %dx%d, %d spp fwd+bwd' % (a.workload, res, res, spp), 'image_rel_l2': _rel_l2(g.img, p.img),
+                     'worst_gradient_rel_l2': worst, 'tensors': len(p.grads)}
+            del g
+        t0 = time.time()
+        reps = 0
+        while time.time() - t0 < budget:
+            p.step(reps + 1)
+            reps += 1
+        dt = time.time() - t0
+        rate = res * res * spp * reps / dt / 1e6
+        lines.append({'sample': '%dx%d, %d spp' % (res, res, spp), 'value': rate, 'repetitions': reps, 'seconds': dt})
+        if best is None or rate > best[0]:
+            best = (rate, res, spp, reps, dt)
+        del p
+    rate, res, spp, reps, dt = best
+    return {'value': rate, 'unit': 'Msamples/s', 'cores': os.cpu_count(), 'kind': 'reference',
+            'sample': '%s %dx%d, %d spp fwd+bwd, max_bounces %d, Sobol, %d repetitions in %.1f s; reference C++ core '
+                      '(oracle/_ref) with the BVH Embree stand-in, all host threads; the better of the two samples in `samples`'
+                      % (a.workload, res, res, spp, a.max_bounces, reps, dt),
+            'samples': lines, 'gpu_vs_reference': check}
+
+
+def sharded_self_check(a, rd, dev):
+    """Untimed: the benchmark's frame rendered as 8 sample blocks (sample_offset = b, total_samples = 8: what 8 ranks would
+    render) against the same 8 samples in one call -- image to fp32 summation order, every gradient tensor to 1e-4."""
+    spp, blocks = 8, 8
+    whole = Prepared(rd, build_scene(a, dev, a.res), spp, spp, 0, a.max_bounces, dev)
+    whole.step(0)
+    torch.cuda.synchronize(dev)
+    img = whole.img.clone()
+    grads = [g.clone() for g in whole.grads]
+    acc_img = torch.zeros_like(img)
+    acc = [torch.zeros_like(g) for g in grads]
+    for b in range(blocks):
+        part = Prepared(rd, build_scene(a, dev, a.res), spp // blocks, spp, b * (spp // blocks), a.max_bounces, dev)
+        part.step(0)
+        torch.cuda.synchronize(dev)
+        acc_img += part.img
+        for x, y in zip(acc, part.grads):
+            x += y
+        del part
+    e_img = _rel_l2(acc_img, img)
+    e_grad = max((_rel_l2(x, y) for x, y in zip(acc, grads) if float(y.abs().sum()) > 0), default=0.0)
+    return {'job': '%s %dx%d, %d spp in %d sample blocks vs one call' % (a.workload, a.res, a.res, spp, blocks),
+            'image_rel_l2': e_img, 'worst_gradient_rel_l2': e_grad, 'ok': bool(e_img < 2e-6 and e_grad < 1e-4)}
 
 
 def alone_leg(st, alg_bytes_launch):
@@ -281,6 +333,7 @@ def main():
     ap.add_argument('--max-bounces', type=int, default=None)
     ap.add_argument('--workload', default='bunny_box', choices=['bunny_box', 'living_room_standin', 'living_room_standin_envmap'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-self-check', action='store_true', help='skip the untimed sample-block self-check')
     ap.add_argument('--no-alone-leg', action='store_true', help='skip the extra single-stream step behind roofline.alone')
     ap.add_argument('--no-profile', action='store_true', help='skip the rocprofv3 counter passes behind roofline.kernels')
     ap.add_argument('--inner', action='store_true', help=argparse.SUPPRESS)
@@ -419,9 +472,14 @@ def main():
                                  'so this is an L2-served rate; hbm_frac_measured is what reaches HBM (counters), and the '
                                  'kernels are bound by vector-ALU issue at valu_lane_util (DESIGN.md section 3)'},
         }
+        if world == 1 and not a.no_self_check:
+            try:
+                out['self_check'] = sharded_self_check(a, redner, dev)
+            except Exception as e:
+                out['self_check'] = {'error': repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             try:
-                out['cpu_baseline'] = cpu_baseline(a)
+                out['cpu_baseline'] = cpu_baseline(a, redner, dev)
             except Exception as e:   # the baseline must never take the GPU number down with it
                 out['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(out), flush=True)

@@ -177,7 +177,9 @@ RDR_FN Ray primary_ray(const CameraD &cam, V2 screen_in) {
 // Screen position of sample `s` in pixel `pixel` of the viewport.
 RDR_FN V2 pixel_to_screen(const CameraD &cam, int pixel, V2 s) {
     int vw = cam.vp_x1 - cam.vp_x0;
-    int px = pixel % vw + cam.vp_x0, py = pixel / vw + cam.vp_y0;
+    int row = pixel / vw;
+    if (cam.batch_rows > 0) row %= cam.batch_rows;          // a lane of a sample batch: the pixel of its own sample
+    int px = pixel % vw + cam.vp_x0, py = row + cam.vp_y0;
     return v2((px + s.x) / double(cam.width), (py + s.y) / double(cam.height));
 }
 

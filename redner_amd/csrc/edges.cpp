@@ -481,6 +481,11 @@ EdgeData *compute_edge_data(const Scene &scene) {
     static const bool cache_allowed = std::getenv("RDR_NO_REFIT") == nullptr;
     if ((int)merged_cache->indices.size() != ns) { merged_cache->indices.assign(ns, {}); merged_cache->merged.assign(ns, {}); }
     std::vector<EdgeD> &edges = ed->edges;
+    // The CANONICAL edges: every shape's merged edges in id order -- a function of the index buffers alone.  The final list is a
+    // position-dependent permutation of a position-dependent subset of them (coplanar faces drop their edge); `can_of[i]` =
+    // canonical index of final edge i.  The billboard hierarchy of the gather is kept over the canonical edges (below).
+    std::vector<EdgeD> canon;
+    std::vector<int> can_of;
     for (int sid = 0; sid < ns; ++sid) {
         const ShapeD &sh = hs[sid];
         std::vector<EdgeD> merged;
@@ -509,16 +514,19 @@ EdgeData *compute_edge_data(const Scene &scene) {
         if (cache_allowed && sh.num_triangles >= 256) { merged_cache->indices[sid] = scene.h_indices[sid]; merged_cache->merged[sid] = merged; }
         }
         // sort by endpoint positions so duplicated (e.g. UV-seam) edges become neighbours
+        const int can_base = (int)canon.size();
+        canon.insert(canon.end(), merged.begin(), merged.end());
+        std::vector<int> can_local(merged.size());
         {
-            struct Keyed { SortedEnds ends; EdgeD e; };
+            struct Keyed { SortedEnds ends; EdgeD e; int can; };
             std::vector<Keyed> keyed(merged.size());
-            for (size_t i = 0; i < merged.size(); ++i) keyed[i] = Keyed{sorted_ends(sh, merged[i]), merged[i]};
+            for (size_t i = 0; i < merged.size(); ++i) keyed[i] = Keyed{sorted_ends(sh, merged[i]), merged[i], can_base + (int)i};
             merge_sort_seq(keyed.data(), keyed.data() + keyed.size(), [](const Keyed &a, const Keyed &b) {
                 if (f3_ne(a.ends.lo, b.ends.lo)) return f3_less_eq(a.ends.lo, b.ends.lo);
                 if (f3_ne(a.ends.hi, b.ends.hi)) return f3_less_eq(a.ends.hi, b.ends.hi);
                 return true;
             });
-            for (size_t i = 0; i < merged.size(); ++i) merged[i] = keyed[i].e;
+            for (size_t i = 0; i < merged.size(); ++i) { merged[i] = keyed[i].e; can_local[i] = keyed[i].can; }
         }
         const int ne = (int)merged.size();
         std::vector<int> f1(ne);
@@ -535,7 +543,7 @@ EdgeData *compute_edge_data(const Scene &scene) {
                 if (f3_eq(me.lo, o.lo) && f3_eq(me.hi, o.hi)) f1[i] = merged[i + 1].f0;
             }
         }
-        for (int i = 0; i < ne; ++i) { merged[i].f1 = f1[i]; edges.push_back(merged[i]); }
+        for (int i = 0; i < ne; ++i) { merged[i].f1 = f1[i]; edges.push_back(merged[i]); can_of.push_back(can_local[i]); }
     }
     // drop edges between coplanar faces
     {
@@ -551,9 +559,10 @@ EdgeData *compute_edge_data(const Scene &scene) {
             }
         });
         std::vector<EdgeD> kept;
-        kept.reserve(edges.size());
-        for (size_t i = 0; i < edges.size(); ++i) if (!remove[i]) kept.push_back(edges[i]);
-        edges.swap(kept);
+        std::vector<int> kept_can;
+        kept.reserve(edges.size()); kept_can.reserve(edges.size());
+        for (size_t i = 0; i < edges.size(); ++i) if (!remove[i]) { kept.push_back(edges[i]); kept_can.push_back(can_of[i]); }
+        edges.swap(kept); can_of.swap(kept_can);
     }
     const int ne = (int)edges.size();
     const CameraD &cam = scene.d.cam;
@@ -620,11 +629,16 @@ EdgeData *compute_edge_data(const Scene &scene) {
         // Boxes: each edge's own spatial bounds grown by the half-width (rounded outwards; the builder pads on top).
         // (the billboard hierarchy only has to be conservative: with the edge list of the previous Scene its topology is kept
         //  and its boxes are refitted; rebuilt when the inner surface area has grown by more than 30 %)
-        struct GatherCache { std::vector<EdgeD> edges; rt::BvhHost bvh; };
+        // The hierarchy is kept over the CANONICAL edges (every merged edge of every shape, whether the current positions
+        // keep it in the list or not): its topology then depends on the index buffers alone, and a Scene with the connectivity
+        // of the previous one refits it -- whatever the motion did to the order of the list and to which coplanar edges
+        // dropped out.  A canonical edge that is not in the current list keeps its place and its box (it is a real edge of
+        // the mesh) but gets a leaf record no query accepts (GatherLeaf with an empty Hough interval).
+        struct GatherCache { std::vector<EdgeD> canon; rt::BvhHost bvh; };
         static GatherCache *gather_cache = new GatherCache();            // one build at a time (build_lock above; scene.cpp: EdgeBuilder)
         rt::BvhHost gather_built;
         double &expand_out = ed->edge_bounds_expand;
-        auto gather_job = hostpool::run([&gather_built, &bounds, &edges, &cs_ids, &ncs_ids, shapes, ne, &expand_out] {
+        auto gather_job = hostpool::run([&gather_built, &edges, &canon, &can_of, &cs_ids, &ncs_ids, shapes, ne, &expand_out] {
             // mean absolute deviation of the endpoints -> billboard half-width
             std::vector<int> all_ids(cs_ids);
             all_ids.insert(all_ids.end(), ncs_ids.begin(), ncs_ids.end());
@@ -645,24 +659,32 @@ EdgeData *compute_edge_data(const Scene &scene) {
             const double e = 0.01f * len(mad);
             expand_out = e;
 
-            std::vector<float> boxes((size_t)6 * ne);
-            for (int i = 0; i < ne; ++i) {
-                const double lo[3] = {bounds[i].p_min.x - e, bounds[i].p_min.y - e, bounds[i].p_min.z - e};
-                const double hi[3] = {bounds[i].p_max.x + e, bounds[i].p_max.y + e, bounds[i].p_max.z + e};
+            const int nc = (int)canon.size();
+            std::vector<float> boxes((size_t)6 * nc);
+            for (int i = 0; i < nc; ++i) {
+                const F3 a = edge_v0f(shapes, canon[i]), b = edge_v1f(shapes, canon[i]);       // (the spatial bounds of edges.cpp: Box6::p_min / p_max)
+                const double lo[3] = {(double)std::min(a.x, b.x) - e, (double)std::min(a.y, b.y) - e, (double)std::min(a.z, b.z) - e};
+                const double hi[3] = {(double)std::max(a.x, b.x) + e, (double)std::max(a.y, b.y) + e, (double)std::max(a.z, b.z) + e};
                 for (int k = 0; k < 3; ++k) {
                     boxes[6 * (size_t)i + k] = std::nextafterf((float)lo[k], -std::numeric_limits<float>::infinity());
                     boxes[6 * (size_t)i + 3 + k] = std::nextafterf((float)hi[k], std::numeric_limits<float>::infinity());
                 }
             }
-            const bool same = cache_allowed && !gather_cache->bvh.nodes.empty() && gather_cache->edges.size() == edges.size() &&
-                              std::memcmp(gather_cache->edges.data(), edges.data(), sizeof(EdgeD) * edges.size()) == 0;
-            if (same) {
+            bool have = false;
+            if (cache_allowed && !gather_cache->bvh.nodes.empty() && gather_cache->canon.size() == canon.size() &&
+                std::memcmp(gather_cache->canon.data(), canon.data(), sizeof(EdgeD) * canon.size()) == 0) {
                 gather_built = gather_cache->bvh;
-                if (rt::refit_box_bvh(gather_built, boxes.data()) <= 1.3) return;
+                have = rt::refit_box_bvh(gather_built, boxes.data()) <= 1.3;
             }
-            gather_built = rt::build_box_bvh(boxes.data(), ne);
-            gather_cache->edges = edges;
-            gather_cache->bvh = gather_built;
+            if (!have) {
+                gather_built = rt::build_box_bvh(boxes.data(), nc);
+                gather_cache->canon = canon;
+                gather_cache->bvh = gather_built;
+            }
+            // leaf slots name CURRENT edges from here on (-1: the slot's canonical edge is not in the list)
+            std::vector<int> cur_of((size_t)nc, -1);
+            for (int i = 0; i < ne; ++i) cur_of[can_of[i]] = i;
+            for (size_t sl = 0; sl + 1 < gather_built.ids.size(); sl += 2) gather_built.ids[sl + 1] = cur_of[gather_built.ids[sl + 1]];
         });
         if (ed->device_trees) {
             // The two reference hierarchies are built by kernels on the stream of the first gradient render (edges_gpu.cpp);
@@ -759,6 +781,7 @@ EdgeData *compute_edge_data(const Scene &scene) {
             for (size_t sl = (size_t)sl_begin; sl < (size_t)sl_end; ++sl) {
                 const int eid = ed->gather.ids[2 * sl + 1];
                 GatherLeaf &gl = ed->gleaf[sl];
+                if (eid < 0) { gl = dead_gather_leaf(); continue; }
                 gl.dx_lo = leaf_dx[2 * (size_t)eid]; gl.dx_hi = leaf_dx[2 * (size_t)eid + 1];
                 F3 a = edge_v0f(shapes, edges[eid]), b = edge_v1f(shapes, edges[eid]);
                 const EdgeD &e = edges[eid];

@@ -87,6 +87,16 @@ struct GatherLeaf {
     int has_normals;
 };
 static_assert(sizeof(GatherLeaf) == 80, "GatherLeaf must stay 80 bytes");
+// The record of a leaf slot whose (canonical) edge is not in the current edge list: its Hough interval is empty, so the test
+// every candidate passes first (sphere_box_x against the edge's own leaf interval) rejects it for every query; its end points
+// lie where no NEE segment reaches.
+RDR_FN GatherLeaf dead_gather_leaf() {
+    GatherLeaf gl;
+    gl.dx_lo = 1e300 * 1e300; gl.dx_hi = -gl.dx_lo;            // (+inf, -inf)
+    for (int k = 0; k < 3; ++k) { gl.v0[k] = gl.v1[k] = gl.o0[k] = gl.o1[k] = 1e30f; }
+    gl.eid = -1; gl.rank = 0x7fffffff; gl.f0 = gl.f1 = -1; gl.has_normals = 0;
+    return gl;
+}
 
 // One positive-weight leaf found by the NEE-mode gather (stages_edge.h: SecEdgeGatherN), replayed in `rank` order.
 struct GatherCand { int rank, eid; double w; };

@@ -550,6 +550,7 @@ __global__ void __launch_bounds__(256) gather_leaf_kernel(const int *slot_ids, i
     const int sl = blockIdx.x * 256 + threadIdx.x;
     if (sl >= slots) return;
     const int eid = slot_ids[2 * sl + 1];
+    if (eid < 0) { out[sl] = dead_gather_leaf(); return; }      // the slot's canonical edge is not in the current list (edges.cpp)
     const EdgeGeom g = geom[eid];
     GatherLeaf gl;
     gl.dx_lo = leaf_dx[2 * (size_t)eid]; gl.dx_hi = leaf_dx[2 * (size_t)eid + 1];

@@ -162,6 +162,9 @@ inline void download(void *dst, const void *src, size_t bytes) {
     if (bytes) check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().stream), "download");
     check(hipStreamSynchronize(ctx().stream), "download sync");
 }
+inline void copy_dev(void *dst, const void *src, size_t bytes) {          // device -> device, stream-ordered
+    if (bytes) check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx().stream), "copy_dev");
+}
 inline void sync() { check(hipStreamSynchronize(ctx().stream), "sync"); }
 inline void device_sync() { (void)hipDeviceSynchronize(); }        // every stream of the device (error paths; never throws)
 // Batched transfers for the Scene build (trace.hip): every array goes through one pinned staging buffer, the copies are
@@ -519,9 +522,11 @@ TraceStats &trace_stats();
 void trace_stats_collect();     // folds pending hipEvent pairs / device counters into trace_stats()
 void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count n, bool any);
 // Host threads render() may drive samples from (RDR_WORKERS=1 turns the second one off).
-inline int sample_workers(int lanes, int samples) {
+inline int sample_workers(int lanes, int samples, bool batches = false) {
     static const int forced = [] { const char *e = std::getenv("RDR_WORKERS"); return e ? std::min(1 + kMaxHelpers, std::max(1, std::atoi(e))) : 0; }();
     if (forced) return forced;
+    // sample batches (render.cpp): two chains of launches in flight, more do not help (tools/gpu_batch_grid.sh)
+    if (batches) return samples >= 2 ? 2 : 1;
     // measured (bunny_box backward, round 2): 256x256x4 spp 13.8 / 14.6 / 15.2 ms with 2 / 3 / 4 workers, 256x256x16 spp
     // 52.1 / 47.9 / 46.7 / 48.7 ms with 3 / 4 / 6 / 8; 512x512x8 spp 92 -> 83 ms with a second worker; at 1024x1024 the second
     // worker adds 2-4 % and stretches every kernel it shares the GPU with

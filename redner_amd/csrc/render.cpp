@@ -133,11 +133,11 @@ inline int side_index(int k, int lanes) { return lanes >= (1 << 19) ? k + 2 : k;
 
 // One NEE + BSDF bounce over the live lanes of `v`; fills `vn` and the next live-lane list.  The lane count stays on the
 // device (exec::Count); `dyn` / `dyn_inc`: the dimension counter that advances if this bounce had lanes to run.
-exec::Count run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng_shift,
+exec::Count run_bounce(const Scene &scene, const SceneD &sd, const SamplerD &rng, int dim, int rng_shift,
                        const int *active, exec::Count num_active, const VSlice &v, const VSlice &vn,
                        const Queues &q, const Sink &sink, int *next_active, int *dyn = nullptr, int dyn_inc = 0) {
     const int lean = scene_kind(scene, sink.ch);
-    launch_v(lean, num_active, BounceSample{scene.d, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
+    launch_v(lean, num_active, BounceSample{sd, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
     // the shadow-ray and the continuation-ray queue are traced side by side: both kernels wait on dependent loads
     // with a fraction of their lanes active (profiles/r1_notes.md), so they fill each other's gaps
     const bool side = g_overlap.load(std::memory_order_relaxed);
@@ -160,7 +160,7 @@ exec::Count run_bounce(const Scene &scene, const SamplerD &rng, int dim, int rng
         exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true);
         exec::trace(scene.bvh, q.bsdf, q.h_bsdf, num_active, false);
     }
-    launch_v(lean, num_active, BounceContrib{scene.d, rng, dim, rng_shift, active, v, vn, q.h_nee, q.h_bsdf, sink});
+    launch_v(lean, num_active, BounceContrib{sd, rng, dim, rng_shift, active, v, vn, q.h_nee, q.h_bsdf, sink});
     return exec::compact_dev(active, num_active, next_active, KeepHit{vn.shape}, nullptr, dyn, dyn_inc);
 }
 
@@ -298,9 +298,21 @@ struct GradStore {
 };
 
 // ---- backward sweep of one sample (src/pathtracer.cpp:392-944) ------------------------------------
+// Sample batches (small frames, gradient renders of plain scenes with the Sobol' sampler): `S` consecutive samples are
+// rendered as ONE set of lanes -- lane v = pixel v % P0 of the batch's sample v / P0 -- so that a launch covers S x P0 lanes
+// instead of P0.  At 256 x 256 a sample is a chain of ~280 dependent launches that each last as long as their longest
+// lane (one wave per SIMD); four samples per launch take barely longer.  Nothing in the stage bodies changes: per-lane state
+// is indexed by the lane id as before; the samplers map a slot to (sample, slot of that sample) (sobol.h), the camera maps a
+// lane to its pixel (CameraD::batch_rows), the upstream image gradient is replicated per sample, and what the reference
+// decides per sample -- compacted ranks of the secondary-edge sampler's slots, dimension counters that advance only for
+// samples whose lists are not empty -- is kept per sample (`seg` tables, edge_dyn[s]).
+struct BatchView { int S = 1, P0 = 0, rows = 0; bool on = false; };
+
 struct Backward {
     const Scene &scene; const rdr_render_options &opt;
     int P, B; const float *d_image; float *screen_grad; double weight; int nd, radiance_dim;
+    BatchView batch;               // P = batch.S * batch.P0 lanes when batch.on
+    SceneD sd;                     // scene.d (+ the batch's camera mapping)
     GradStore &grads;              // shared by the sample workers: every add is an atomic
     Arena arena;
     AdjState adj;
@@ -313,9 +325,11 @@ struct Backward {
     double *multipliers = nullptr;     // [2P x nd], primary-edge channel weights (non-radiance channels only)
 
     Backward(const Scene &scene_, const rdr_render_options &opt_, GradStore &grads_, int P_, int B_,
-             const float *d_image_, float *screen_grad_, double weight_, int nd_, int radiance_dim_, const ChannelsD &ch_)
+             const float *d_image_, float *screen_grad_, double weight_, int nd_, int radiance_dim_, const ChannelsD &ch_,
+             const BatchView &batch_)
         : scene(scene_), opt(opt_), P(P_), B(B_), d_image(d_image_), screen_grad(screen_grad_), weight(weight_),
-          nd(nd_), radiance_dim(radiance_dim_), grads(grads_), ch(ch_) {
+          nd(nd_), radiance_dim(radiance_dim_), batch(batch_), sd(scene_.d), grads(grads_), ch(ch_) {
+        if (batch.on) sd.cam.batch_rows = batch.rows;
         lean = scene_kind(scene, ch);
         adj.n = P; adj.plain = 0;
         adj.thr = arena.get<double>((size_t)3 * P);
@@ -324,8 +338,8 @@ struct Backward {
         const bool edges_on = scene.edges && scene.edges->d.num_edges > 0 &&
                               (scene.use_primary_edges || scene.use_secondary_edges);
         if (edges_on) {
-            edge_dyn = arena.get<int>(1);
-            hoist_dyn = arena.get<int>(1);
+            edge_dyn = arena.get<int>(kMaxBatch);
+            hoist_dyn = arena.get<int>(kMaxBatch);
             const int L = 2 * P;                      // edge lanes: two rays per sample slot
             ea = make_slice(arena, L, false);
             eb = make_slice(arena, L, false);
@@ -390,12 +404,22 @@ struct Backward {
     }
     void edge_rng_consumed_n(exec::Count n, int count) { edge_rng_consumed(n, count, nullptr); }
     // The edge sampler at dimension `edim` + what the device-side counter holds (see SamplerD::dyn)
-    SamplerD edge_rng_at(const SamplerD &rng_edge, int edim, const int *dyn = nullptr) const {
-        SamplerD r = rng_edge; r.pcg_base = edim; r.dyn = dyn ? dyn : edge_dyn; return r;
+    // `seg`: the slots are compacted ranks of the batch's samples (secondary-edge passes); otherwise, in a batch, every sample
+    // owns P0 consecutive slots (primary-edge pass)
+    SamplerD edge_rng_at(const SamplerD &rng_edge, int edim, const int *dyn = nullptr, const int *seg = nullptr) const {
+        SamplerD r = rng_edge; r.pcg_base = edim; r.dyn = dyn ? dyn : edge_dyn;
+        if (batch.on) { r.batch = cur_S; r.seg = seg; r.batch_lanes = seg ? 0 : batch.P0; }
+        return r;
     }
-    // A secondary-edge pass at a depth that had lanes has drawn its four numbers per slot (`n`: that depth's live-lane count)
-    void secondary_pass_consumed(exec::Count n) {
-        exec::launch(1, BumpDyn{edge_dyn, n.dev, 4});
+    // per path depth of the current batch: where each sample's part of the live-lane list starts (device, kMaxBatch + 1 ints)
+    const int *seg_tables = nullptr;
+    int cur_S = 1;                 // samples in the batch that is being rendered
+    const int *seg_of(int d) const { return batch.on ? seg_tables + (size_t)d * (kMaxBatch + 1) : nullptr; }
+    // A secondary-edge pass at a depth that had lanes has drawn its four numbers per slot (`n`: that depth's live-lane count;
+    // in a batch: per sample whose part of the list is not empty)
+    void secondary_pass_consumed(exec::Count n, int d) {
+        if (batch.on) exec::launch(cur_S, BumpDynSeg{edge_dyn, seg_of(d), 4});
+        else exec::launch(1, BumpDyn{edge_dyn, n.dev, 4});
         edge_rng_consumed_n(n, 4);
     }
 
@@ -434,26 +458,36 @@ struct Backward {
     // `ea`.  The reference runs a bounce while lanes are left and advances the edge sampler by 7 dimensions per bounce it ran
     // (src/pathtracer.cpp:590-706); here every bounce up to max_bounces is queued -- one without lanes does nothing -- and the
     // device-side counter advances in the compaction that closes a bounce which had lanes (`edim` is the host-known part).
+    // `seg`: the edge lanes are 2 x compacted rank (+ side) of the samples' live-lane lists (secondary-edge pass of that depth);
+    // null: 2 x slot (+ side) with P0 slots per sample (primary-edge pass).
     void trace_edge_paths(const SamplerD &rng_edge, int edim, exec::Count n_act, exec::Count n_slots, int first_depth, const Queues &q,
-                          const Sink &sink, bool need_lights) {
-        const bool has_lights = scene.d.num_lights > 0;
+                          const Sink &sink, bool need_lights, const int *seg = nullptr) {
+        const bool has_lights = sd.num_lights > 0;
         if (need_lights && !has_lights) return;
         int cur = 1;
         for (int depth = first_depth, k = 0; depth < B && n_act.upper > 0; ++depth, ++k) {
             const VSlice &m = (k % 2 == 0) ? ea : eb;
             const VSlice &nx = (k % 2 == 0) ? eb : ea;
             int nxt = (cur == 1) ? 2 : 1;
-            exec::Count next = run_bounce(scene, edge_rng_at(rng_edge, edim), edim, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt], edge_dyn, 7);
+            exec::Count next = run_bounce(scene, sd, edge_rng_at(rng_edge, edim, nullptr, seg), edim, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt],
+                                          batch.on ? nullptr : edge_dyn, 7);
+            // a batch: the counter of every sample that had lanes in this bounce (the list is ascending in the lane id)
+            if (batch.on) exec::launch(cur_S, BumpDynList{edge_dyn, elist[cur], n_act.dev, n_act.upper, seg, 2 * batch.P0, 7});
             edge_rng_consumed(n_slots, 7, n_act.dev);
             n_act = next;
             cur = nxt;
         }
     }
 
-    void run_sample(int sample_id, const SamplerD &main_rng, std::vector<VSlice> &vs, int *active, std::vector<exec::Count> &num_active, const Queues &q) {
+    // One sample -- or one batch of `S_now` samples on `lanes` = S_now x P0 lanes (`stride`: lanes the buffers were made for;
+    // `seg`: the batch's per-depth segment tables)
+    void run_sample(int sample_id, const SamplerD &main_rng, std::vector<VSlice> &vs, int *active, std::vector<exec::Count> &num_active, const Queues &q,
+                    int n_lanes, int stride, int S_now, const int *seg) {
+        const int P = n_lanes;                        // (shadows the member: the buffers' capacity)
+        cur_S = S_now; seg_tables = seg;
         SamplerD rng = main_rng;
         SamplerD rng_edge{scene.sobol_table, opt.seed + 131071U, sample_id, pcg_edge, 0};   // src/pathtracer.cpp:221-227
-        const bool has_lights = scene.d.num_lights > 0;
+        const bool has_lights = sd.num_lights > 0;
         const bool edges_on = prim_recs != nullptr;
         Sink esink{nullptr, edge_contrib, nd, radiance_dim, weight, ch, nullptr};
         Sink psink{nullptr, edge_contrib, nd, radiance_dim, weight, ch, multipliers};
@@ -462,7 +496,7 @@ struct Backward {
         // before its sampler draws, src/pathtracer.cpp:432-436 -- and 7 per bounce of an edge sub-path that had lanes to run,
         // see trace_edge_paths)
         int edim = 0;
-        if (edge_dyn) exec::zero(edge_dyn, sizeof(int));
+        if (edge_dyn) exec::zero(edge_dyn, sizeof(int) * kMaxBatch);
         exec::zero(adj.thr, sizeof(double) * 3 * P);
         exec::zero(adj.ray_dir, sizeof(double) * 3 * P);
         exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * P);
@@ -477,9 +511,9 @@ struct Backward {
         PickPhase picks_phase;
         auto start_picks = [&](int d, int edim_d, const int *dyn, bool early, bool side) -> SecEdgeArgs {
             const exec::Count nA = num_active[d];
-            const int *act = active + (size_t)d * P;
+            const int *act = active + (size_t)d * stride;
             const EdgeSceneD &es = scene.edges->d;
-            SecEdgeArgs sa{scene.d, es, rng, dim0 + 7 * d, edge_rng_at(rng_edge, edim_d, dyn), edim_d, act, vs[d]};
+            SecEdgeArgs sa{sd, es, rng, dim0 + 7 * d, edge_rng_at(rng_edge, edim_d, dyn, seg_of(d)), edim_d, act, vs[d]};
             hipStream_t main_stream = exec::ctx().stream;
             const int need = es.max_stack;
             exec::Count nH(0), nN(0);
@@ -544,6 +578,18 @@ struct Backward {
         static const bool hoist_allowed = std::getenv("RDR_NO_HOIST") == nullptr;          // A/B
         if (hoist_allowed && secondary_on && overlap && scene.diffuse_only && pcg_edge == nullptr && has_lights && B >= 2 && num_active[0].upper > 0) {
             // the dimension the sweep will have reached at the first vertex: 4 per deeper depth that has lanes (device counts)
+            if (batch.on) {
+                int k = 0;
+                bool first = true;
+                CountLiveDepthsSeg cl{hoist_dyn, {}, 0, 4, 0};
+                auto flush_tables = [&] { cl.n = k; cl.add = first ? 0 : 1; exec::launch(cur_S, cl); first = false; k = 0; };
+                for (int d = B - 1; d >= 1; --d) {
+                    if (num_active[d].upper <= 0) continue;
+                    cl.seg[k++] = seg_of(d);
+                    if (k == kDepthGates) flush_tables();
+                }
+                if (k > 0 || first) flush_tables();
+            } else {
             int host_part = 0, k = 0;
             bool first = true;
             CountLiveDepths cl{hoist_dyn, {}, 0, 4, 0};
@@ -560,21 +606,22 @@ struct Backward {
             }
             if (k > 0 || first) flush_gates();
             if (host_part) exec::launch(1, BumpDyn{hoist_dyn, nullptr, host_part});
+            }
             early_sa = start_picks(0, 0, hoist_dyn, true, true);
             hoisted = true;
         }
         for (int d = B - 1; d >= 0 && has_lights; --d) {
             const exec::Count nA = num_active[d];
             if (nA.upper <= 0) continue;
-            const int *act = active + (size_t)d * P;
-            AdjBounceArgs ba{scene.d, grads.g, rng, dim0 + 7 * d, act, vs[d], vs[d + 1], d_image, nd, radiance_dim, weight, adj};
+            const int *act = active + (size_t)d * stride;
+            AdjBounceArgs ba{sd, grads.g, rng, dim0 + 7 * d, act, vs[d], vs[d + 1], d_image, nd, radiance_dim, weight, adj};
             bool with_edges = secondary_on;
             if (with_edges && d > 0 && scene.diffuse_only) {
                 // Every material is purely diffuse: a path that has left its first vertex carries min_roughness 1 (src/material.h:750-752)
                 // and the sampler returns at once for every slot (src/edge.cpp:1396-1401).  Nothing of the pass remains but its
                 // sampler bookkeeping: four numbers drawn per slot.
                 with_edges = false;
-                secondary_pass_consumed(nA);
+                secondary_pass_consumed(nA, d);
             }
             // The bounce adjoint of this depth, the hierarchical edge pick and the NEE-mode gather do not depend on each other
             // (the edge pass touches the adjoint records only in SecondaryEdgeDerivatives); each of them keeps a fraction of
@@ -602,19 +649,19 @@ struct Backward {
                 debug_dump("sec_picks", sample_id, d, sec_picks, sizeof(SecPick) * (size_t)nA.upper);
                 launch_v(lean, nA, SecEdgeFinish{sa, sec_mode, sec_picks, d_image, nd, radiance_dim, sec_recs, ea, edge_tmin});
                 debug_dump("sec_recs", sample_id, d, sec_recs, sizeof(SecondaryEdgeRec) * (size_t)nA.upper);
-                secondary_pass_consumed(nA);
+                secondary_pass_consumed(nA, d);
                 const exec::Count n0 = exec::compact_dev((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
                 exec::launch(n0, QueueRays{elist[0], ea, edge_tmin, q.bsdf});
                 exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
                 exec::launch(n0, RecordHits{elist[0], ea, q.h_bsdf});
-                if (ea.erd) exec::launch(n0, MirrorSurfDiff{scene.d, elist[0], ea});
-                launch_v(lean, nA, SecondaryEdgeWeights{scene.d, sec_recs, ea, hit_pos});
+                if (ea.erd) exec::launch(n0, MirrorSurfDiff{sd, elist[0], ea});
+                launch_v(lean, nA, SecondaryEdgeWeights{sd, sec_recs, ea, hit_pos});
                 exec::zero(edge_contrib, sizeof(double) * lanes.upper);
-                launch_v(lean, n0, ShadeRecorded{scene.d, elist[0], ea, esink});
+                launch_v(lean, n0, ShadeRecorded{sd, elist[0], ea, esink});
                 const exec::Count n1 = exec::compact_dev(elist[0], n0, elist[1], KeepHit{ea.shape});
-                trace_edge_paths(rng_edge, edim, n1, nA, d + 1, q, esink, false);
+                trace_edge_paths(rng_edge, edim, n1, nA, d + 1, q, esink, false, seg_of(d));
                 if (side) adjoint_done.gate(main_stream);          // the only stage of the edge pass that touches the adjoint records
-                exec::launch(nA, SecondaryEdgeDerivatives{scene.d, grads.g, act, sec_recs, hit_pos, ea.n, edge_contrib, adj});
+                exec::launch(nA, SecondaryEdgeDerivatives{sd, grads.g, act, sec_recs, hit_pos, ea.n, edge_contrib, adj});
             }
         }
         // the camera-vertex adjoint runs beside the primary-edge pass unless both would add to the screen-gradient image
@@ -624,11 +671,11 @@ struct Backward {
             depth_begin.after(main_stream);
             exec::StreamScope on(exec::side_stream(side_index(0, P)));
             depth_begin.gate(exec::ctx().stream);
-            launch_v(lean, P, AdjPrimary{scene.d, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
+            launch_v(lean, P, AdjPrimary{sd, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
                                        adj, screen_grad, ch});
             adjoint_done.after(exec::ctx().stream);
         } else {
-            launch_v(lean, P, AdjPrimary{scene.d, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
+            launch_v(lean, P, AdjPrimary{sd, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
                                        adj, screen_grad, ch});
         }
         if (edges_on && scene.use_primary_edges) {
@@ -636,18 +683,18 @@ struct Backward {
             const EdgeSceneD &es = scene.edges->d;
             const int lanes = 2 * P;
             exec::zero(edge_contrib, sizeof(double) * lanes);
-            launch_v(lean, P, SamplePrimaryEdges{scene.d, es, edge_rng_at(rng_edge, edim), edim, d_image, nd, radiance_dim, prim_recs, ea, multipliers});
+            launch_v(lean, P, SamplePrimaryEdges{sd, es, edge_rng_at(rng_edge, edim), edim, d_image, nd, radiance_dim, prim_recs, ea, multipliers});
             edim += 2;
             edge_rng_consumed_n(P, 2);
             const exec::Count n0 = exec::compact_dev((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
             if (ea.erd) exec::launch(n0, LoadLaneDiff{elist[0], ea});
             exec::launch(n0, QueueRays{elist[0], ea, nullptr, q.bsdf});
             exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
-            launch_v(lean, n0, ShadePrimary{scene.d, elist[0], ea, q.h_bsdf, psink});
-            if (ea.erd) exec::launch(n0, MirrorSurfDiff{scene.d, elist[0], ea});
+            launch_v(lean, n0, ShadePrimary{sd, elist[0], ea, q.h_bsdf, psink});
+            if (ea.erd) exec::launch(n0, MirrorSurfDiff{sd, elist[0], ea});
             const exec::Count n1 = exec::compact_dev(elist[0], n0, elist[1], KeepHit{ea.shape});
             trace_edge_paths(rng_edge, edim, n1, P, 0, q, esink, true);
-            launch_v(lean, P, PrimaryEdgeDerivatives{scene.d, grads.g, prim_recs, edge_contrib, screen_grad});
+            launch_v(lean, P, PrimaryEdgeDerivatives{sd, grads.g, prim_recs, edge_contrib, screen_grad});
         }
         if (adj_primary_aside) adjoint_done.gate(exec::ctx().stream);      // the next sample clears the adjoint records
     }
@@ -693,43 +740,103 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     }
     const int lean = scene_kind(scene, lay.ch);
 
-    // Everything one sample needs between its camera rays and its last gradient add.
+    // Several samples in flight (backward pass, lean scenes, Sobol' sampler): the samples of a gradient render are
+    // independent -- no image is written, the sampler is stateless, gradient adds are atomics -- and at the sizes
+    // optimisation loops run at (256x256, a few spp) one sample is a chain of short, latency-bound launches.  So (i) up to
+    // kMaxBatch consecutive samples are rendered as one set of lanes (a "sample batch", see BatchView) while that set stays
+    // below 2^19 lanes, and (ii) helper host threads drive batches k, k + workers, ... on their own streams with their own
+    // buffers.  The forward image needs its fp32 adds in sample order and stays one sample at a time on one stream.
+    // (the camera-vertex adjoint adds to the screen-gradient image with plain read-modify-writes: one worker, no batches, then)
+    const bool batchable = screen_gradient_image == nullptr && lean == kLean && opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on;
+    const bool samples_independent = batchable && d_image != nullptr && image == nullptr;
+    // A forward render is batched too: its launches deposit per lane into staging planes and ResolveBatchImage adds them to
+    // the image in the reference's order (one stream, batches in sample order).
+    const bool forward_batches = batchable && d_image == nullptr && image != nullptr;
+    BatchView batch;
+    batch.P0 = P; batch.rows = cam.vp_y1 - cam.vp_y0;
+    if (samples_independent || forward_batches) {
+        // Measured (tools/gpu_batch_grid.sh, bunny_box backward, profiles/r3_notes.md): a batch costs about the same up to
+        // ~131 k lanes and little more up to 524 k; two batches in flight on two host threads beat one of twice the size
+        // from 262 k lanes on.  So: everything in one batch while that is <= 2^17 lanes, otherwise batches of up to 2^19 lanes,
+        // at least two of them, driven by two workers.
+        static const int batch_cap = [] { const char *e = std::getenv("RDR_BATCH"); return e ? std::max(1, std::min(kMaxBatch, std::atoi(e))) : kMaxBatch; }();
+        const long long total = (long long)opt.num_samples * P;
+        int want = opt.num_samples;
+        if (total > (1 << 17) && samples_independent) want = (opt.num_samples + 1) / 2;
+        batch.S = std::max(1, std::min(std::min(batch_cap, want), std::max(1, (1 << 19) / P)));
+        batch.on = batch.S > 1;
+    }
+    const int S = batch.S;
+    const int PL = S * P;                         // lanes per launch set
+    static const bool tell = std::getenv("RDR_DEBUG_BATCH") != nullptr;
+    if (tell) std::fprintf(stderr, "[render] %s: %d samples of %d lanes in batches of %d\n", d_image ? "backward" : "forward", opt.num_samples, P, S);
+    const int num_batches = (opt.num_samples + S - 1) / S;
+    const float *d_image_lanes = d_image;         // the upstream gradient, indexed by lane: one copy per sample of a batch
+    if (batch.on && d_image) {
+        float *rep = arena.get<float>((size_t)PL * lay.nd);
+        for (int k = 0; k < S; ++k)
+            exec::copy_dev(rep + (size_t)k * P * lay.nd, d_image, sizeof(float) * (size_t)P * lay.nd);
+        d_image_lanes = rep;
+    }
+    int workers = 1;
+    if (samples_independent) workers = std::max(1, std::min(exec::sample_workers(PL, num_batches, batch.on), num_batches));
+
+    // Everything one sample (or sample batch) needs between its camera rays and its last gradient add.
     struct Worker {
         Arena arena;
         std::vector<VSlice> vs;
         int *active = nullptr;
         Queues q;
-        std::vector<exec::Count> num_active;   // live lanes per depth: device-side counts (upper bound P)
+        std::vector<exec::Count> num_active;   // live lanes per depth: device-side counts (upper bound PL)
         int *main_dyn = nullptr;               // PCG only: 7 x (bounces that had lanes), counted on the device
+        int *seg = nullptr;                    // sample batches: per depth, where each sample's part of the live-lane list starts
+        float *stage = nullptr;                // forward batches: B + 1 planes of PL x nd floats (see ResolveBatchImage)
         std::unique_ptr<Backward> bwd;
     };
     auto make_worker = [&](Worker &w) {
         w.vs.resize(B + 1);
-        for (int d = 0; d <= B; ++d) w.vs[d] = make_slice(w.arena, P, d < B);
-        w.active = w.arena.get<int>((size_t)(B + 1) * P);
-        w.q.nee = w.arena.get<rt::RayRec>((size_t)2 * P); w.q.bsdf = w.arena.get<rt::RayRec>((size_t)2 * P);
-        w.q.h_nee = w.arena.get<rt::HitRec>((size_t)2 * P); w.q.h_bsdf = w.arena.get<rt::HitRec>((size_t)2 * P);
+        for (int d = 0; d <= B; ++d) w.vs[d] = make_slice(w.arena, PL, d < B);
+        w.active = w.arena.get<int>((size_t)(B + 1) * PL);
+        w.q.nee = w.arena.get<rt::RayRec>((size_t)2 * PL); w.q.bsdf = w.arena.get<rt::RayRec>((size_t)2 * PL);
+        w.q.h_nee = w.arena.get<rt::HitRec>((size_t)2 * PL); w.q.h_bsdf = w.arena.get<rt::HitRec>((size_t)2 * PL);
         w.num_active.assign(B + 2, exec::Count(0));
         if (pcg_main) w.main_dyn = w.arena.get<int>(1);
-        if (d_image) w.bwd.reset(new Backward(scene, opt, *grads, P, B, d_image, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch));
+        if (batch.on) w.seg = w.arena.get<int>((size_t)(B + 1) * (kMaxBatch + 1));
+        if (batch.on && forward_batches) w.stage = w.arena.get<float>((size_t)(B + 1) * PL * lay.nd);
+        if (d_image) w.bwd.reset(new Backward(scene, opt, *grads, PL, B, d_image_lanes, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch, batch));
     };
-    // samples first, first + stride, ... on the calling thread's stream
+    // batches first, first + stride, ... on the calling thread's stream (a batch = S consecutive samples; S = 1: samples)
     auto run_samples = [&](Worker &w, int first, int stride) {
         std::vector<VSlice> &vs = w.vs;
         int *active = w.active;
         const Queues &q = w.q;
         std::vector<exec::Count> &num_active = w.num_active;
-        for (int s = first; s < opt.num_samples; s += stride) {
+        SceneD sd = scene.d;
+        if (batch.on) sd.cam.batch_rows = batch.rows;
+        for (int b = first; b < num_batches; b += stride) {
+            const int s = b * S;
+            const int S_now = std::min(S, opt.num_samples - s);
+            const int lanes = S_now * P;
             const int sample_id = opt.sample_offset + s;
             SamplerD rng{scene.sobol_table, opt.seed, sample_id, pcg_main, 0};
+            if (batch.on) { rng.batch = S_now; rng.batch_lanes = P; }
             Sink sink{image, nullptr, lay.nd, lay.radiance_dim, weight, lay.ch, nullptr};
+            const size_t plane = (size_t)PL * lay.nd;
+            auto sink_of = [&](int launch) { Sink k = sink; if (w.stage) k.image = w.stage + (size_t)launch * plane; return k; };
+            if (w.stage) exec::zero(w.stage, sizeof(float) * plane * (B + 1));
+            // a batch: where each sample's lanes start in the live-lane list of depth d (the list ascends in the lane id)
+            auto segments = [&](int d) {
+                if (batch.on) exec::launch(S_now + 1, SegOffsets{active + (size_t)d * PL, num_active[d].dev, num_active[d].upper, P, S_now,
+                                                                 w.seg + (size_t)d * (kMaxBatch + 1)});
+            };
 
             // ---- camera vertex ----
-            launch_v(lean, P, GenPrimary{scene.d, rng, opt.sample_pixel_center, vs[0], q.bsdf});
-            exec::trace(scene.bvh, q.bsdf, q.h_bsdf, P, false);
-            launch_v(lean, P, ShadePrimary{scene.d, nullptr, vs[0], q.h_bsdf, sink});
+            launch_v(lean, lanes, GenPrimary{sd, rng, opt.sample_pixel_center, vs[0], q.bsdf});
+            exec::trace(scene.bvh, q.bsdf, q.h_bsdf, lanes, false);
+            launch_v(lean, lanes, ShadePrimary{sd, nullptr, vs[0], q.h_bsdf, sink_of(0)});
             std::fill(num_active.begin(), num_active.end(), exec::Count(0));
-            num_active[0] = exec::compact_dev((const int *)nullptr, P, active, KeepHit{vs[0].shape});
+            num_active[0] = exec::compact_dev((const int *)nullptr, lanes, active, KeepHit{vs[0].shape});
+            if (w.bwd) segments(0);
             if (w.main_dyn) exec::zero(w.main_dyn, sizeof(int));
 
             // ---- bounces (src/pathtracer.cpp:292-390).  The reference stops when no lane is left; here every bounce is
@@ -737,27 +844,19 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
             int dim = opt.sample_pixel_center ? 0 : 2;
             const int dim_first = dim;
             for (int d = 0; d < B && num_active[d].upper > 0 && has_lights; ++d) {
-                num_active[d + 1] = run_bounce(scene, rng, dim, 0, active + (size_t)d * P, num_active[d],
-                                               vs[d], vs[d + 1], q, sink, active + (size_t)(d + 1) * P, w.main_dyn, 7);
+                num_active[d + 1] = run_bounce(scene, sd, rng, dim, 0, active + (size_t)d * PL, num_active[d],
+                                               vs[d], vs[d + 1], q, sink_of(d + 1), active + (size_t)(d + 1) * PL, w.main_dyn, 7);
+                if (num_active[d + 1].dev && w.bwd) segments(d + 1);
                 dim += 7;
             }
+            if (w.stage) exec::launch(P * lay.nd, ResolveBatchImage{image, w.stage, P, lay.nd, S_now, B + 1, plane});
 
-            if (w.bwd) w.bwd->run_sample(sample_id, rng, vs, active, num_active, q);
+            if (w.bwd) w.bwd->run_sample(sample_id, rng, vs, active, num_active, q, lanes, PL, S_now, w.seg);
             // every slot drew dim_first + 7 x (bounces that ran) numbers this sample
             if (pcg_main) exec::launch(P, PcgAdvance{pcg_main, dim_first, w.main_dyn, nullptr});
         }
     };
 
-    // Several samples in flight (backward pass, lean scenes, Sobol' sampler): the samples of a gradient render are
-    // independent -- no image is written, the sampler is stateless, gradient adds are atomics -- and at the sizes
-    // optimisation loops run at (256x256, a few spp) one sample is a chain of short, latency-bound launches, so helper
-    // host threads drive samples k, k + workers, ... on their own streams with their own buffers.  The forward image
-    // needs its fp32 adds in sample order and stays on one stream.
-    int workers = 1;
-    // (the camera-vertex adjoint adds to the screen-gradient image with plain read-modify-writes: one worker then)
-    if (d_image != nullptr && image == nullptr && screen_gradient_image == nullptr && lean == kLean &&
-        opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on)
-        workers = std::max(1, std::min(exec::sample_workers(P, opt.num_samples), opt.num_samples));
     Worker w0;
     make_worker(w0);
     if (timer.on) exec::sync();

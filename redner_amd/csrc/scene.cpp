@@ -60,9 +60,10 @@ namespace {
 class EdgeBuilder {
 public:
     static EdgeBuilder &get() { static EdgeBuilder *b = new EdgeBuilder(); return *b; }      // never destroyed
-    std::future<EdgeData *> submit(std::function<EdgeData *()> fn) {
-        std::packaged_task<EdgeData *()> task(std::move(fn));
-        std::future<EdgeData *> fut = task.get_future();
+    typedef std::shared_ptr<EdgeData> Result;
+    std::future<Result> submit(std::function<Result()> fn) {
+        std::packaged_task<Result()> task(std::move(fn));
+        std::future<Result> fut = task.get_future();
         {
             std::lock_guard<std::mutex> lk(m_);
             q_.push_back(std::move(task));
@@ -84,7 +85,7 @@ private:
     }
     void loop() {
         for (;;) {
-            std::packaged_task<EdgeData *()> task;
+            std::packaged_task<Result()> task;
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return !q_.empty(); });
@@ -102,19 +103,24 @@ private:
     }
     std::mutex m_;
     std::condition_variable cv_;
-    std::deque<std::packaged_task<EdgeData *()>> q_;
+    std::deque<std::packaged_task<Result()>> q_;
     bool running_ = false;
 };
 }
 
 const EdgeData *Scene::edge_data() const {
-    if (edge_build.valid()) edges = edge_build.get();             // rethrows what the build threw
+    if (edge_build.valid()) {
+        edges_ref = edge_build.get();             // rethrows what the build threw
+        edge_build = std::shared_future<std::shared_ptr<EdgeData>>();
+        edges = edges_ref.get();
+    }
     return edges;
 }
 
 Scene::~Scene() {
-    if (edge_build.valid()) { try { edges = edge_build.get(); } catch (...) {} }
-    delete_edge_data(edges);
+    // a build that is still running reads this Scene's host arrays: wait for it (the structures themselves may live on in
+    // the cache / in other Scenes and are released with their last owner)
+    if (edge_build.valid()) { try { edge_build.wait(); } catch (...) {} }
     for (void *p : owned) exec::pool_free(p);
 }
 
@@ -426,21 +432,46 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     // ---- edge sampling structures ----
     if (s.use_primary_edges || s.use_secondary_edges) {
         static const bool sync_edges = std::getenv("RDR_SYNC_EDGES") != nullptr;
-        const Scene *sc = &s;
-        s.edge_build = EdgeBuilder::get().submit([sc]() -> EdgeData * {
-            EdgeData *ed = compute_edge_data(*sc);
-            try {
-                exec::select_device(1, sc->gpu_index);
-                exec::StreamScope on(exec::side_stream(0));             // this thread's own stream
-                publish_edge_data(*ed);
-                exec::upload_flush();
-            } catch (...) {
-                exec::device_sync();          // the builder's kernels may still be running: no block returns to the pool before
-                delete_edge_data(ed);
-                throw;
+        // Everything the edge structures are computed from (edges.cpp: compute_edge_data): if it equals what the previous
+        // Scene's were computed from, that result -- finished or still in the builder's hands -- is this Scene's too.
+        struct EdgeCache {
+            int gpu_index = -1; bool primary = false, secondary = false;
+            CameraD cam;
+            std::vector<std::vector<float>> vertices, normals;
+            std::vector<std::vector<int>> indices;
+            std::shared_future<std::shared_ptr<EdgeData>> result;
+        };
+        static EdgeCache *cache = new EdgeCache();            // guarded by the API lock (capi.cpp)
+        static const bool cache_allowed = std::getenv("RDR_NO_EDGE_CACHE") == nullptr && std::getenv("RDR_NO_REFIT") == nullptr;
+        const bool hit = cache_allowed && cache->result.valid() && cache->gpu_index == s.gpu_index &&
+                         cache->primary == s.use_primary_edges && cache->secondary == s.use_secondary_edges &&
+                         std::memcmp(&cache->cam, &s.d.cam, sizeof(CameraD)) == 0 && cache->indices == s.h_indices &&
+                         cache->vertices == s.h_vertices && cache->normals == s.h_normals;
+        if (hit) {
+            s.edge_build = cache->result;
+        } else {
+            const Scene *sc = &s;
+            s.edge_build = EdgeBuilder::get().submit([sc]() -> std::shared_ptr<EdgeData> {
+                EdgeData *ed = compute_edge_data(*sc);
+                try {
+                    exec::select_device(1, sc->gpu_index);
+                    exec::StreamScope on(exec::side_stream(0));             // this thread's own stream
+                    publish_edge_data(*ed);
+                    exec::upload_flush();
+                } catch (...) {
+                    exec::device_sync();          // the builder's kernels may still be running: no block returns to the pool before
+                    delete_edge_data(ed);
+                    throw;
+                }
+                return std::shared_ptr<EdgeData>(ed, [](EdgeData *e) { delete_edge_data(e); });
+            }).share();
+            if (cache_allowed) {
+                cache->gpu_index = s.gpu_index; cache->primary = s.use_primary_edges; cache->secondary = s.use_secondary_edges;
+                cache->cam = s.d.cam;
+                cache->vertices = s.h_vertices; cache->normals = s.h_normals; cache->indices = s.h_indices;
+                cache->result = s.edge_build;
             }
-            return ed;
-        });
+        }
         if (sync_edges || timer.on) s.edge_data();
     }
     timer.lap("edge structures");

@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 #include <future>
+#include <memory>
 
 #include <chrono>
 #include <cstdio>
@@ -70,9 +71,14 @@ struct Scene {
     // edge_data() joins (the first gradient render calls it), and so does the destructor.  (The reference builds them inside
     // the Scene constructor, src/scene.cpp:63-307, i.e. in front of every forward render, pyredner/render_pytorch.py:609.)
     // RDR_SYNC_EDGES=1 / RDR_DEBUG_DUMP: joined inside create_scene().  RDR_EDGE_HOST_BUILD=1: hierarchies by the host builder.
+    // The structures depend on positions, connectivity, shading normals and the camera only: a Scene whose inputs equal the
+    // previous Scene's in all of those (a loop that moves materials, lights or textures) SHARES that Scene's structures --
+    // or its build, if that is still running -- instead of building them again (scene.cpp: EdgeCache; RDR_NO_EDGE_CACHE=1 /
+    // RDR_NO_REFIT=1: always build).
     const EdgeData *edge_data() const;
     mutable EdgeData *edges = nullptr;            // valid after edge_data()
-    mutable std::future<EdgeData *> edge_build;   // pending build, if any
+    mutable std::shared_ptr<EdgeData> edges_ref;  // keeps `edges` alive (shared with the cache and with other Scenes)
+    mutable std::shared_future<std::shared_ptr<EdgeData>> edge_build;   // pending (possibly shared) build, if any
 
     std::vector<void *> owned;   // device allocations released in the destructor
     ~Scene();

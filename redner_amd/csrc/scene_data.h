@@ -72,6 +72,9 @@ struct CameraD {
     int kind;
     int vp_x0, vp_y0, vp_x1, vp_y1;   // viewport_beg / viewport_end
     DistortD distortion;
+    // Several samples of a small frame rendered as ONE set of lanes (render.cpp "sample batches"): lane v is pixel
+    // v % (pixels of the viewport) of the batch's sample v / pixels; > 0: the viewport's row count.  0: one sample per launch.
+    int batch_rows = 0;
 };
 
 struct EnvmapD {

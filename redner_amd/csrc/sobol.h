@@ -73,6 +73,11 @@ RDR_FN double pcg_output_double(uint64_t oldstate) {
 // `dyn` (optional, device memory): the part of the dimension counter the host does not know -- the edge sampler advances by
 // 7 per EXECUTED bounce of an edge sub-path, and how many are executed depends on live-lane counts that stay on the device
 // (render.cpp).  A draw's dimension is `dim + *dyn`; PCG draws are relative to the draw group's start, so they ignore it.
+// Sample batches (Sobol' only; render.cpp): the slots of `batch` consecutive samples in one view.  Either every sample owns
+// `batch_lanes` consecutive slots (slot v = slot v % batch_lanes of sample sample_id + v / batch_lanes: pixels, primary-edge
+// slots), or -- `seg` set -- the slots are the concatenated compacted lists of the samples (seg[s] = where sample s's list
+// starts: the secondary-edge sampler numbers its slots by compacted rank WITHIN a sample, src/pathtracer.cpp:504-505).  `dyn`
+// then holds one counter per sample of the batch.
 struct SamplerD {
     const uint64_t *matrices;
     uint64_t seed;
@@ -80,9 +85,19 @@ struct SamplerD {
     const uint64_t *pcg_state;
     int pcg_base;
     const int *dyn = nullptr;
+    int batch = 0, batch_lanes = 0;
+    const int *seg = nullptr;
     RDR_FN double draw(int slot, int dim) const {
         if (pcg_state) return pcg_output_double(pcg_advance(pcg_state[slot], pcg_inc(slot), (uint32_t)(dim - pcg_base)));
-        return sobol_value(matrices, (uint64_t)sample_id, (uint32_t)(dim + (dyn ? *dyn : 0)), sobol_scramble(seed, slot));
+        int s = 0;
+        if (seg) {
+            for (int k = 1; k < batch; ++k) if (slot >= seg[k]) s = k;
+            slot -= seg[s];
+        } else if (batch_lanes > 0) {
+            s = slot / batch_lanes;
+            slot -= s * batch_lanes;
+        }
+        return sobol_value(matrices, (uint64_t)(sample_id + s), (uint32_t)(dim + (dyn ? dyn[s] : 0)), sobol_scramble(seed, slot));
     }
 };
 
@@ -116,6 +131,65 @@ struct CountLiveDepths {            // *out (+)= inc x #{gates whose count is po
         int c = add ? *out : 0;
         for (int i = 0; i < kDepthGates; ++i) if (i < n && *gate[i] > 0) c += inc;
         *out = c;
+    }
+};
+
+// ---- sample batches: per-sample bookkeeping over sorted lane lists (launched with batch (+ 1) lanes) -----------------------
+constexpr int kMaxBatch = 16;
+// out[s] = position of the first entry >= s * lanes_per_sample in the ascending list (out[batch] = its length)
+struct SegOffsets {
+    const int *list; const int *count; int upper, lanes_per_sample, batch; int *out;
+    RDR_FN void operator()(int s) const {
+        int n = *count; n = n < upper ? n : upper;
+        const int key = s * lanes_per_sample;
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (list[mid] < key) lo = mid + 1; else hi = mid; }
+        out[s] = s >= batch ? n : lo;
+    }
+};
+// dyn[s] += inc for every sample whose segment of `seg` is not empty
+struct BumpDynSeg {
+    int *dyn; const int *seg; int inc;
+    RDR_FN void operator()(int s) const { if (seg[s + 1] > seg[s]) dyn[s] += inc; }
+};
+// dyn[s] += inc for every sample that owns an entry of the ascending edge-lane list: sample s owns the lanes
+// [2 seg[s], 2 seg[s + 1]) (two lanes per slot of its compacted list) or, seg null, [s * lanes_per_sample, (s + 1) * lanes_per_sample)
+struct BumpDynList {
+    int *dyn; const int *list; const int *count; int upper; const int *seg; int lanes_per_sample, inc;
+    RDR_FN int first_at_least(int key, int n) const {
+        int lo = 0, hi = n;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (list[mid] < key) lo = mid + 1; else hi = mid; }
+        return lo;
+    }
+    RDR_FN void operator()(int s) const {
+        int n = *count; n = n < upper ? n : upper;
+        const int b0 = seg ? 2 * seg[s] : s * lanes_per_sample, b1 = seg ? 2 * seg[s + 1] : (s + 1) * lanes_per_sample;
+        if (first_at_least(b1, n) > first_at_least(b0, n)) dyn[s] += inc;
+    }
+};
+// Forward image of a sample batch: every launch of the batch wrote its contributions per LANE into its own plane of `stage`
+// (plane k = launch k of the sample: first hit, bounce 1, ...; lanes_stride x nd floats each, zero where nothing was added);
+// one lane per pixel component adds them to the image in the order the reference's launches add them -- sample by sample,
+// launch by launch (src/pathtracer.cpp:283,378) -- so the fp32 sums round exactly as they do one sample at a time.
+struct ResolveBatchImage {
+    float *image; const float *stage; int pixels, nd, samples, planes; size_t plane_stride;
+    RDR_FN void operator()(int i) const {
+        const int pixel = i / nd, c = i - pixel * nd;
+        float acc = image[i];
+        for (int s = 0; s < samples; ++s)
+            for (int k = 0; k < planes; ++k)
+                acc += stage[(size_t)k * plane_stride + ((size_t)s * pixels + pixel) * nd + c];
+        image[i] = acc;
+    }
+};
+
+// out[s] = inc x #{tables whose segment s is not empty}
+struct CountLiveDepthsSeg {
+    int *out; const int *seg[kDepthGates]; int n, inc, add;
+    RDR_FN void operator()(int s) const {
+        int c = add ? out[s] : 0;
+        for (int i = 0; i < kDepthGates; ++i) if (i < n && seg[i][s + 1] > seg[i][s]) c += inc;
+        out[s] = c;
     }
 };
 

@@ -39,6 +39,7 @@ inline size_t host_count_reads() { return 0; }
 inline void zero(void *p, size_t bytes) { memset(p, 0, bytes); }
 inline void upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void download(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
+inline void copy_dev(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void sync() {}
 inline void device_sync() {}
 inline size_t pool_cached_bytes() { return 0; }
@@ -56,7 +57,7 @@ inline Context &ctx() { static Context c; return c; }
 inline hipStream_t side_stream(int) { return nullptr; }
 struct StreamScope { explicit StreamScope(hipStream_t) {} ~StreamScope() {} };
 struct Fence { void after(hipStream_t) {} void gate(hipStream_t) {} };
-inline int sample_workers(int, int) { return 1; }
+inline int sample_workers(int, int, bool = false) { return 1; }
 struct SecondThread {          // never used: sample_workers() == 1
     static SecondThread &get(int = 0) { static SecondThread t; return t; }
     template <class F> void start(F) {}

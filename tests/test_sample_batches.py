@@ -1,0 +1,64 @@
+"""Sample batches (render.cpp: BatchView): small frames render several Sobol' samples as ONE set of lanes -- lane = sample x
+pixel -- in forward and in gradient renders of plain scenes.  What the reference decides per sample (the live-lane
+compaction whose ranks number the secondary-edge sampler's slots, src/pathtracer.cpp:504-505; the dimension counters that
+advance only for samples whose lists are not empty, :432-436, 590-706; the order in which a pixel's fp32 image sums take the
+launches' contributions, :283,378) is kept per sample, so a batched render must equal the one-sample-at-a-time render:
+the image bit for bit, the gradients bit for bit on the sequential CPU harness and to the order of fp64 atomics on the GPU.
+RDR_BATCH=1 switches batching off (read once per process, hence the subprocesses)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = ('bunny_box_32x32x4', 'two_triangles_64x64x16', 'bunny_box_96x96x8')
+
+CODE = r'''
+import sys
+sys.path[:0] = [%(root)r, %(root)r + '/tests']
+import numpy as np, torch
+from redner_amd import _capi
+_capi.load(%(lib)r)
+from redner_amd import redner
+from golden.make_golden import render_case, CASES
+dev = torch.device(%(dev)r)
+out = {}
+for name in %(cases)r:
+    for k, v in render_case(redner, *CASES[name], device=dev).items():
+        out[name + '/' + k] = v
+np.savez(sys.argv[1], **out)
+'''
+
+
+def _both(tmp_path, lib, dev):
+    code = CODE % {'root': ROOT, 'lib': lib, 'dev': dev, 'cases': CASES}
+    paths = []
+    for tag, env in (('one', {'RDR_BATCH': '1'}), ('batched', {})):
+        p = str(tmp_path / (tag + '.npz'))
+        e = dict(os.environ, **env)
+        e.pop('RDR_BATCH', None) if tag == 'batched' else None
+        subprocess.check_call([sys.executable, '-c', code, p], env=e, timeout=900)
+        paths.append(np.load(p))
+    return paths
+
+
+def test_batches_equal_single_samples_hostsim(hostsim_backend, tmp_path):
+    from conftest import HOSTSIM_LIB
+    one, batched = _both(tmp_path, HOSTSIM_LIB, 'cpu')
+    for k in one.files:
+        assert np.array_equal(one[k], batched[k]), k           # sequential harness: every tensor bit for bit
+
+
+@pytest.mark.gpu
+def test_batches_equal_single_samples_gpu(gpu_backend, tmp_path):
+    from redner_amd import _capi
+    one, batched = _both(tmp_path, _capi.library_path(), 'cuda:0')
+    for k in one.files:
+        if k.endswith('/image'):
+            assert np.array_equal(one[k], batched[k]), k       # the image: fp32 sums in the reference's order
+        else:
+            a, b = one[k].astype(np.float64), batched[k].astype(np.float64)
+            n = np.linalg.norm(a)
+            assert np.linalg.norm(a - b) <= 2e-6 * n + 1e-30, (k, np.linalg.norm(a - b) / max(n, 1e-300))

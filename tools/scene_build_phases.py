@@ -10,7 +10,7 @@ import scenes
 dev = torch.device('cuda:0')
 sc = scenes.bunny_box(dev, resolution=(32, 32))
 for it in range(4):
-    for s in sc.shapes: s.vertices = s.vertices + 1e-4
+    for s in sc.shapes: s.vertices = s.vertices + 1e-4 * torch.sin(torch.arange(s.vertices.numel(), device=dev, dtype=torch.float32) + it).reshape(s.vertices.shape)
     args = RenderFunction.serialize_scene(sc, 1, 1, sampler_type=rd.SamplerType.sobol, device=dev, backend=rd)
     sys.stderr.write('--- iteration %d\n' % it)
     t0 = time.time()

@@ -15,8 +15,15 @@ sc = scenes.bunny_box(dev, resolution=(res, res))
 verts = [s.vertices for s in sc.shapes]
 for v in verts:
     v.requires_grad_(True)
+# `move`: the vertices change every iteration (a geometry optimisation: every Scene builds its edge structures);
+# otherwise only what does not enter them could change (materials / lights: the structures are shared, scene.h)
+move = len(sys.argv) > 3 and sys.argv[3] == 'move'
 times = []
 for it in range(12):
+    if move:
+        with torch.no_grad():
+            for v in verts:
+                v.add_(1e-4 * torch.sin(torch.arange(v.numel(), device=v.device, dtype=torch.float32) + it).reshape(v.shape))
     torch.cuda.synchronize()
     t0 = time.time()
     args = RenderFunction.serialize_scene(sc, spp, 4, sampler_type=rd.SamplerType.sobol, device=dev, backend=rd)
@@ -32,4 +39,4 @@ for name, k in (('serialize', 0), ('forward (Scene + render)', 1), ('backward', 
     xs = sorted(t[k] for t in times[2:])
     print('%-26s median %.2f ms  min %.2f ms' % (name, xs[len(xs) // 2] * 1e3, xs[0] * 1e3))
 tot = sorted(sum(t) for t in times[2:])
-print('iteration                  median %.2f ms  (%dx%d, %d spp: %.2f Msamples/s)' % (tot[len(tot) // 2] * 1e3, res, res, spp, res * res * spp / tot[len(tot) // 2] / 1e6))
+print('iteration%s         median %.2f ms  (%dx%d, %d spp: %.2f Msamples/s)' % (' (moving)' if move else '         ', tot[len(tot) // 2] * 1e3, res, res, spp, res * res * spp / tot[len(tot) // 2] / 1e6))
