@@ -53,6 +53,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9     # CUs x SIMDs x lanes/clk x clock = 39.3 T lane-operations/s (79 TFLOP/s fp64 FMA)
 RAY_BYTES, HIT_BYTES, NODE_BYTES, WIDE_NODE_BYTES, TRI_BYTES = 32, 8, 32, 128, 36
+INNER_SPP = 8                  # samples of the job the rocprofv3 passes run (forms the same sample batches as the timed job at 1024 x 1024)
 
 
 class Prepared:
@@ -138,9 +139,14 @@ def cpu_baseline(a, gpu_rd=None, gpu_dev=None):
             g = Prepared(gpu_rd, build_scene(a, gpu_dev, res), spp, spp, 0, a.max_bounces, gpu_dev)
             g.step(0)
             torch.cuda.synchronize(gpu_dev)
-            worst = max((_rel_l2(x, y) for x, y in zip(g.grads, p.grads) if float(y.abs().sum()) > 0), default=0.0)
+            errs = [(_rel_l2(x, y), y.numel()) for x, y in zip(g.grads, p.grads) if float(y.abs().sum()) > 0]
+            big = [e for e, n in errs if n > 64]          # per-vertex / per-texel tensors
+            few = [e for e, n in errs if n <= 64]         # few-element accumulators: the reference sums them with fp32 atomics
             check = {'job': '%s %dx%d, %d spp fwd+bwd' % (a.workload, res, res, spp), 'image_rel_l2': _rel_l2(g.img, p.img),
-                     'worst_gradient_rel_l2': worst, 'tensors': len(p.grads)}
+                     'worst_per_vertex_gradient_rel_l2': max(big, default=0.0),
+                     'worst_few_element_gradient_rel_l2': max(few, default=0.0), 'tensors': len(errs),
+                     'note': 'single reference pass: its few-element tensors (light, reflectances, camera) carry the fp32-atomics '
+                             'error the ref64 fixtures take out (tests/golden/make_golden.py)'}
             del g
         t0 = time.time()
         reps = 0
@@ -197,6 +203,7 @@ def alone_leg(st, alg_bytes_launch):
 # ---- hardware counters, collected from inside the run ------------------------------------------------------------------
 PROFILE_KERNELS = collections.OrderedDict([       # short name -> substring of the rocprofv3 kernel name
     ('trace_closest', 'trace_kernel<false, false'), ('trace_any', 'trace_kernel<true, false'),
+    ('trace_closest_wide', 'trace_wide_kernel<false, false'), ('trace_any_wide', 'trace_wide_kernel<true, false'),
     ('SecEdgePickH', 'SecEdgePickH'), ('SecEdgeGatherN', 'SecEdgeGatherN'), ('AdjBounceScatter', 'AdjBounceScatter'),
     ('AdjBounceNee', 'AdjBounceNee'), ('BounceContrib', 'BounceContrib'), ('BounceSample', 'BounceSample'),
     ('AdjPrimary', 'AdjPrimary')])
@@ -297,7 +304,7 @@ def profile_kernels(a):
             lane_util = v['SQ_THREAD_CYCLES_VALU'] / (64.0 * v['SQ_ACTIVE_INST_VALU']) if v['SQ_ACTIVE_INST_VALU'] else 0.0
             hbm = (fe[k]['FETCH_SIZE'] * 2.0 / max(len(fe_n[k]), 1) + wr[k]['WRITE_SIZE'] / max(len(wr_n[k]), 1)) * 1024.0
             out[k] = {
-                'launches_per_sample': n / 2.0,      # the inner run renders 2 spp
+                'launches_per_sample': n / float(INNER_SPP),
                 'mean_launch_ms_alone': ms,
                 'mean_launch_ms_overlapped': dur_over.get(k, (0, None))[1],
                 'valu_lane_util': lane_util,
@@ -314,11 +321,11 @@ def profile_kernels(a):
 
 
 def inner_run(a):
-    """Body of the rocprofv3 passes: one forward+backward of 2 spp, nothing printed."""
+    """Body of the rocprofv3 passes: one forward+backward of INNER_SPP spp (the sample batches of the timed job), nothing printed."""
     dev = torch.device('cuda:0')
     torch.cuda.set_device(0)
     from redner_amd import redner
-    prep = Prepared(redner, build_scene(a, dev, a.res), 2, 2, 0, a.max_bounces, dev)
+    prep = Prepared(redner, build_scene(a, dev, a.res), INNER_SPP, INNER_SPP, 0, a.max_bounces, dev)
     prep.step(0)
     torch.cuda.synchronize(dev)
 
@@ -403,7 +410,9 @@ def main():
     value = samples / dt / 1e6
 
     # everything below is untimed and works on a short job (the counters do not depend on the sample count)
-    short = Prepared(redner, build_scene(a, dev, a.res), min(spp_rank, 8), min(spp_rank, 8), 0, a.max_bounces, dev)
+    # (32 spp: enough samples for the library to form the same sample batches as in the timed job, so that launches of the
+    #  counted job and of the timed job cover the same number of rays)
+    short = Prepared(redner, build_scene(a, dev, a.res), min(spp_rank, 32), min(spp_rank, 32), 0, a.max_bounces, dev)
     scene_build_warm_ms = short.scene_build_s * 1e3      # second Scene of the process: allocator, staging buffer, topology caches warm
     # instrumented traversal variant: node / triangle records per launch
     lib.rdr_trace_stats_enable(0, 1)

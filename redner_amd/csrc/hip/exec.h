@@ -526,7 +526,7 @@ inline int sample_workers(int lanes, int samples, bool batches = false) {
     static const int forced = [] { const char *e = std::getenv("RDR_WORKERS"); return e ? std::min(1 + kMaxHelpers, std::max(1, std::atoi(e))) : 0; }();
     if (forced) return forced;
     // sample batches (render.cpp): two chains of launches in flight, more do not help (tools/gpu_batch_grid.sh)
-    if (batches) return samples >= 2 ? 2 : 1;
+    if (batches) return samples >= 2 && lanes < (1 << 20) ? 2 : 1;
     // measured (bunny_box backward, round 2): 256x256x4 spp 13.8 / 14.6 / 15.2 ms with 2 / 3 / 4 workers, 256x256x16 spp
     // 52.1 / 47.9 / 46.7 / 48.7 ms with 3 / 4 / 6 / 8; 512x512x8 spp 92 -> 83 ms with a second worker; at 1024x1024 the second
     // worker adds 2-4 % and stretches every kernel it shares the GPU with
