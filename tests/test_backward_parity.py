@@ -34,15 +34,14 @@ def test_backward_gpu(gpu_backend, name):
     _check(gpu_backend, torch.device('cuda:0'), name, 'gpu')
 
 
-@pytest.mark.parametrize('budget,caps', [('4', None), ('2', '3,5'), ('1', '0,0'), ('6', '100000,2')])
-def test_gather_overflow_paths_hostsim(budget, caps, tmp_path):
+def _gather_overflow(budget, caps, lib, dev, cases):
     """The NEE-mode gather hands work over in three ways -- subtrees to SecEdgeGatherSub when a lane's pop budget is spent,
     candidates to the 256-entry lists when a slot has more than 8, and the slot to the reference-order walk when even those
     lists (or the heavy / work registries) are full.  Tiny budgets and registry sizes force every one of them; the picks
     must not change (bit-identical fixtures).  Run in a subprocess: the switches are read once per process."""
     import subprocess
     import sys
-    from conftest import HOSTSIM_LIB, ROOT
+    from conftest import ROOT
     code = r'''
 import os, sys
 sys.path[:0] = [%r, %r + '/tests']
@@ -52,12 +51,26 @@ _capi.load(%r)
 from redner_amd import redner
 from golden.make_golden import CASES, render_case
 from parity_util import GOLD, assert_parity, compare
-for name in ('bunny_box_32x32x4', 'bunny_box_96x96x8', 'envmap_sphere_48x48x4'):
-    rep = compare(render_case(redner, *CASES[name]), np.load(os.path.join(GOLD, name + '.npz')))
+for name in %r:
+    rep = compare(render_case(redner, *CASES[name], device=torch.device(%r)), np.load(os.path.join(GOLD, name + '.npz')))
     assert_parity(rep, name)
     assert sum(e['flipped_rows'] for e in rep.values()) == 0, name
-''' % (ROOT, ROOT, HOSTSIM_LIB)
+''' % (ROOT, ROOT, lib, cases, dev)
     env = dict(os.environ, RDR_GATHER_BUDGET=budget)
     if caps is not None:
         env['RDR_GATHER_CAPS'] = caps
     subprocess.check_call([sys.executable, '-c', code], env=env, timeout=900)
+
+
+@pytest.mark.parametrize('budget,caps', [('4', None), ('2', '3,5'), ('1', '0,0'), ('6', '100000,2')])
+def test_gather_overflow_paths_hostsim(budget, caps, tmp_path):
+    from conftest import HOSTSIM_LIB
+    _gather_overflow(budget, caps, HOSTSIM_LIB, 'cpu', ('bunny_box_32x32x4', 'bunny_box_96x96x8', 'envmap_sphere_48x48x4'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('budget,caps', [('2', '3,5'), ('1', '0,0')])
+def test_gather_overflow_paths_gpu(gpu_backend, budget, caps, tmp_path):
+    """The same hand-over paths on the GPU build (subtree hand-off across lanes, the 256-entry lists, the fallback walk)."""
+    from redner_amd import _capi
+    _gather_overflow(budget, caps, _capi.library_path(), 'cuda:0', ('bunny_box_32x32x4', 'bunny_box_96x96x8'))

@@ -66,6 +66,15 @@ def test_degenerate_gpu(gpu_backend, name):
         assert not img.any()
     for g in grads:
         assert g is None or np.isfinite(g).all()
+    if oracle_util.oracle_available():                 # oracle/_ref travels to the GPU box with the snapshot
+        cpu = torch.device('cpu')
+        ref_img, ref_grads = _run(oracle_util.load_oracle(), cpu, _variants(cpu)[name][0](), mb=mb)
+        assert np.array_equal(img, ref_img)
+        for g, r in zip(grads, ref_grads):
+            if r is None:
+                continue
+            n = np.linalg.norm(r)
+            assert np.linalg.norm(g - r) <= 1e-4 * n + 1e-12
 
 
 def test_empty_scene_hostsim(hostsim_backend):
@@ -104,14 +113,14 @@ def test_steady_state_render_allocates_nothing_and_reads_no_counts(gpu_backend):
     assert reads1 == reads0, (reads0, reads1)
 
 
-def test_refit_after_vertices_moved_equals_fresh_build(hostsim_backend, tmp_path):
+def _refit_vs_fresh(tmp_path, lib, dev):
     """A Scene whose index buffers equal the previous Scene's reuses the triangle hierarchy's and the billboard hierarchy's
     topology and the id-sorted half of the edge list, refitting boxes to the moved vertices (scene.cpp / edges.cpp).  Hits and
     edge picks must not depend on that: the result equals a process that builds everything from scratch (RDR_NO_REFIT=1), bit
     for bit on the image and to fp32-atomics noise on the gradients."""
     import subprocess
     import sys
-    from conftest import HOSTSIM_LIB, ROOT
+    from conftest import ROOT
     code = r'''
 import os, sys
 sys.path[:0] = [%r, %r + '/tests']
@@ -121,20 +130,21 @@ _capi.load(%r)
 from redner_amd import redner
 from redner_amd.render_pytorch import RenderFunction
 import scenes
+dev = torch.device(%r)
 def run(shift):
-    sc = scenes.bunny_box(torch.device('cpu'), (40, 40))
-    v = sc.shapes[6].vertices.detach()
+    sc = scenes.bunny_box(dev, (40, 40))
+    v = sc.shapes[6].vertices.detach().cpu()
     g = torch.Generator().manual_seed(7)
-    moved = (v * (1.0 + 0.15 * shift) + shift * torch.tensor([0.12, 0.05, -0.2]) + 0.01 * shift * torch.randn(v.shape, generator=g)).requires_grad_(True)
+    moved = (v * (1.0 + 0.15 * shift) + shift * torch.tensor([0.12, 0.05, -0.2]) + 0.01 * shift * torch.randn(v.shape, generator=g)).to(dev).requires_grad_(True)
     sc.shapes[6].vertices = moved
-    args = RenderFunction.serialize_scene(sc, 4, 3, sampler_type=redner.SamplerType.sobol, device=torch.device('cpu'), backend=redner)
+    args = RenderFunction.serialize_scene(sc, 4, 3, sampler_type=redner.SamplerType.sobol, device=dev, backend=redner)
     img = RenderFunction.apply(1, *args)
     img.sum().backward()
-    return img.detach().numpy(), moved.grad.numpy()
+    return img.detach().cpu().numpy(), moved.grad.cpu().numpy()
 run(0.0)                       # the Scene whose topology the next one inherits (unless RDR_NO_REFIT)
 img, grad = run(1.0)
 np.savez(sys.argv[1], image=img, grad=grad)
-''' % (ROOT, ROOT, HOSTSIM_LIB)
+''' % (ROOT, ROOT, lib, dev)
     outs = {}
     for tag, env in (('refit', {}), ('fresh', {'RDR_NO_REFIT': '1'})):
         out = str(tmp_path / (tag + '.npz'))
@@ -144,6 +154,17 @@ np.savez(sys.argv[1], image=img, grad=grad)
     a, b = outs['refit']['grad'].astype(np.float64), outs['fresh']['grad'].astype(np.float64)
     assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b)
     assert np.abs(b).sum() > 0
+
+
+def test_refit_after_vertices_moved_equals_fresh_build(hostsim_backend, tmp_path):
+    from conftest import HOSTSIM_LIB
+    _refit_vs_fresh(tmp_path, HOSTSIM_LIB, 'cpu')
+
+
+@pytest.mark.gpu
+def test_refit_after_vertices_moved_equals_fresh_build_gpu(gpu_backend, tmp_path):
+    from redner_amd import _capi
+    _refit_vs_fresh(tmp_path, _capi.library_path(), 'cuda:0')
 
 
 def test_edge_build_beside_the_caller_equals_build_in_place(hostsim_backend, tmp_path):
