@@ -388,14 +388,14 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count 
     // 256 rays costs more than the L1-hot top levels save (optimisation-loop iteration +2 ms).  RDR_TRACE_NO_LDS_TOP=1: never.
     static const bool stage_allowed = std::getenv("RDR_TRACE_NO_LDS_TOP") == nullptr;
     const bool stage_top = stage_allowed && n >= (1 << 18);
-    // Which form of the hierarchy: queues below RDR_WIDE_MAX rays (default 2^18) walk the 4-wide records (measured,
+    // Which form of the hierarchy: queues of up to RDR_WIDE_MAX rays (default 2^19) walk the 4-wide records (measured,
     // tools/trace_ab.py, profiles/r3_notes.md: half the dependent steps per ray pays where a launch is one or two waves per
     // SIMD -- closest-hit 0.119 -> 0.102 ms, any-hit 0.078 -> 0.066 ms per 65 k / 50 k rays; on queues of a million rays and
     // more both forms issue the same number of vector instructions per wave and the binary records, at 8 instead of 5 waves
     // per SIMD, are 0-10 % ahead).  RDR_TRACE_BINARY=1: never the wide records.
     static const bool wide_allowed = std::getenv("RDR_TRACE_BINARY") == nullptr;
-    static const int wide_max = [] { const char *e = std::getenv("RDR_WIDE_MAX"); return e ? std::atoi(e) : (1 << 18); }();
-    if (wide_allowed && bvh.wide != nullptr && bvh.wide_stack_need <= 48 && n < wide_max) {
+    static const int wide_max = [] { const char *e = std::getenv("RDR_WIDE_MAX"); return e ? std::atoi(e) : (1 << 19); }();
+    if (wide_allowed && bvh.wide != nullptr && bvh.wide_stack_need <= 48 && n <= wide_max) {
         unsigned long long *ctr = nullptr;
         if (st.counting) {
             std::lock_guard<std::mutex> lk(g_stats_lock);

@@ -707,7 +707,8 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     if (opt.sampler_type != RDR_SAMPLER_SOBOL && opt.sampler_type != RDR_SAMPLER_INDEPENDENT)
         throw std::runtime_error("render: unknown sampler type");
     if (d_image && !d_scene) throw std::runtime_error("render: d_rendered_image given without d_scene");
-    if (d_image) scene.edge_data();          // joins the edge build create_scene() started (scene.h); a forward render never waits for it
+    // (the edge build create_scene() started is joined where a worker first needs the structures -- after it has queued the
+    //  camera-to-light stages of its first sample, which do not: see run_samples; a forward render never waits for it)
     const CameraD &cam = scene.d.cam;
     const int P = (cam.vp_x1 - cam.vp_x0) * (cam.vp_y1 - cam.vp_y0);
     if (P <= 0) return;
@@ -808,7 +809,10 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         if (pcg_main) w.main_dyn = w.arena.get<int>(1);
         if (batch.on) w.seg = w.arena.get<int>((size_t)(B + 1) * (kMaxBatch + 1));
         if (batch.on && forward_batches) w.stage = w.arena.get<float>((size_t)(B + 1) * PL * lay.nd);
-        if (d_image) w.bwd.reset(new Backward(scene, opt, *grads, PL, B, d_image_lanes, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch, batch));
+    };
+    auto make_backward = [&](Worker &w) {          // needs the edge structures (their sizes decide what is allocated)
+        scene.edge_data();
+        w.bwd.reset(new Backward(scene, opt, *grads, PL, B, d_image_lanes, screen_gradient_image, weight, lay.nd, lay.radiance_dim, lay.ch, batch));
     };
     // batches first, first + stride, ... on the calling thread's stream (a batch = S consecutive samples; S = 1: samples)
     auto run_samples = [&](Worker &w, int first, int stride) {
@@ -841,7 +845,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
             launch_v(lean, lanes, ShadePrimary{sd, nullptr, vs[0], q.h_bsdf, sink_of(0)});
             std::fill(num_active.begin(), num_active.end(), exec::Count(0));
             num_active[0] = exec::compact_dev((const int *)nullptr, lanes, active, KeepHit{vs[0].shape});
-            if (w.bwd) segments(0);
+            if (d_image) segments(0);
             if (w.main_dyn) exec::zero(w.main_dyn, sizeof(int));
 
             // ---- bounces (src/pathtracer.cpp:292-390).  The reference stops when no lane is left; here every bounce is
@@ -851,11 +855,12 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
             for (int d = 0; d < B && num_active[d].upper > 0 && has_lights; ++d) {
                 num_active[d + 1] = run_bounce(scene, sd, rng, dim, 0, active + (size_t)d * PL, num_active[d],
                                                vs[d], vs[d + 1], q, sink_of(d + 1), active + (size_t)(d + 1) * PL, w.main_dyn, 7);
-                if (num_active[d + 1].dev && w.bwd) segments(d + 1);
+                if (num_active[d + 1].dev && d_image) segments(d + 1);
                 dim += 7;
             }
             if (w.stage) exec::launch(P * lay.nd, ResolveBatchImage{image, w.stage, P, lay.nd, S_now, B + 1, plane});
 
+            if (d_image && !w.bwd) make_backward(w);       // first sample of this worker: the GPU is busy with the stages queued above
             if (w.bwd) w.bwd->run_sample(sample_id, rng, vs, active, num_active, q, lanes, PL, S_now, w.seg);
             // every slot drew dim_first + 7 x (bounces that ran) numbers this sample
             if (pcg_main) exec::launch(P, PcgAdvance{pcg_main, dim_first, w.main_dyn, nullptr});

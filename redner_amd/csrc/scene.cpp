@@ -109,6 +109,7 @@ private:
 }
 
 const EdgeData *Scene::edge_data() const {
+    std::lock_guard<std::mutex> lk(edge_join);
     if (edge_build.valid()) {
         edges_ref = edge_build.get();             // rethrows what the build threw
         edge_build = std::shared_future<std::shared_ptr<EdgeData>>();

@@ -15,6 +15,7 @@
 #include <vector>
 #include <future>
 #include <memory>
+#include <mutex>
 
 #include <chrono>
 #include <cstdio>
@@ -79,6 +80,7 @@ struct Scene {
     mutable EdgeData *edges = nullptr;            // valid after edge_data()
     mutable std::shared_ptr<EdgeData> edges_ref;  // keeps `edges` alive (shared with the cache and with other Scenes)
     mutable std::shared_future<std::shared_ptr<EdgeData>> edge_build;   // pending (possibly shared) build, if any
+    mutable std::mutex edge_join;                 // edge_data() may be called by several sample workers at once
 
     std::vector<void *> owned;   // device allocations released in the destructor
     ~Scene();

@@ -18,6 +18,7 @@ unmodified pyredner package can be used instead: `redner_amd.install()` (see INT
 tests pass the oracle build of the reference here to render the same scene with both.
 """
 import math
+import weakref
 from typing import List, Optional
 
 import torch
@@ -133,6 +134,26 @@ class _Unpacked:
     pass
 
 
+# serialize_scene() asserts that every floating-point scene tensor is finite, like pyredner (render_pytorch.py:194-270: one
+# torch.isfinite(...).all() -- two kernels and a synchronisation -- per tensor and call).  An optimisation loop passes the same
+# tensor OBJECTS every iteration and changes a few of them in place; a tensor that was finite at its current version is not
+# looked at again (weak references: a new tensor object is always checked, whatever storage it reuses).
+_finite_seen = {}            # id(tensor) -> (weak reference to it, version at which it was found finite)
+
+
+def _known_finite(t):
+    e = _finite_seen.get(id(t))
+    return e is not None and e[0]() is t and e[1] == t._version
+
+
+def _remember_finite(t):
+    key = id(t)
+    try:
+        _finite_seen[key] = (weakref.ref(t, lambda _r, k=key: _finite_seen.pop(k, None)), t._version)
+    except TypeError:
+        pass
+
+
 class RenderFunction(torch.autograd.Function):
     """torch.autograd.Function around redner.render (pyredner/render_pytorch.py:62-1177)."""
 
@@ -156,16 +177,17 @@ class RenderFunction(torch.autograd.Function):
             scene.shapes[light.shape_id].light_id = light_id
 
         tensors = []
-        finite_flags = []       # device tensors are checked together at the end: one synchronisation instead of one per tensor
+        to_check = []           # device tensors are checked together at the end: one multi-tensor kernel, one synchronisation
 
         def put(t, dev):
             if t is None:
                 return -1
-            if t.is_floating_point():
+            if t.is_floating_point() and not _known_finite(t):
                 if t.device.type == 'cpu':
                     assert torch.isfinite(t).all()
+                    _remember_finite(t)
                 else:
-                    finite_flags.append(torch.isfinite(t).all())
+                    to_check.append(t)
             tensors.append(t.to(dev).contiguous())
             return len(tensors) - 1
 
@@ -222,8 +244,14 @@ class RenderFunction(torch.autograd.Function):
                               'pdf_norm': em.pdf_norm, 'directly_visible': em.directly_visible}
         meta['use_primary_edge_sampling'] = bool(use_primary_edge_sampling and needs_visibility)
         meta['use_secondary_edge_sampling'] = bool(use_secondary_edge_sampling and needs_visibility)
-        if finite_flags:
-            assert bool(torch.stack(finite_flags).all()), 'serialize_scene: a scene tensor holds non-finite values'
+        if to_check:
+            # max |x| per tensor in one multi-tensor launch (NaN propagates through max, inf stays inf), one read-back
+            live = [t.detach() for t in to_check if t.numel() > 0]
+            if live:
+                peaks = torch.stack(torch._foreach_norm(live, float('inf')))
+                assert bool(torch.isfinite(peaks).all()), 'serialize_scene: a scene tensor holds non-finite values'
+            for t in to_check:
+                _remember_finite(t)
         return [meta] + tensors
 
     @staticmethod
@@ -323,11 +351,17 @@ class RenderFunction(torch.autograd.Function):
         rd = meta['backend']
         device = meta['device']
         grads = [None] * len(tensors)
+        # one zero-filled allocation for all of them (a scene has ~70 tensors: one fill instead of ~70), 64-byte aligned slices
+        sizes = [((t.numel() + 15) // 16) * 16 for t in tensors]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+        starts = [0] * len(tensors)
+        for k in range(1, len(tensors)):
+            starts[k] = starts[k - 1] + sizes[k - 1]
 
         def zeros_like_arg(i):
             if i < 0:
                 return None
-            g = torch.zeros(tensors[i].shape, dtype=torch.float32, device=device)
+            g = flat[starts[i]:starts[i] + tensors[i].numel()].view(tensors[i].shape)
             grads[i] = g
             return g
 
