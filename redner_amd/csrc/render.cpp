@@ -748,7 +748,11 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     // below 2^19 lanes, and (ii) helper host threads drive batches k, k + workers, ... on their own streams with their own
     // buffers.  The forward image needs its fp32 adds in sample order and stays one sample at a time on one stream.
     // (the camera-vertex adjoint adds to the screen-gradient image with plain read-modify-writes: one worker, no batches, then)
-    const bool batchable = screen_gradient_image == nullptr && lean == kLean && opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on;
+    // Not batched: scenes with mip-mapped textures or an environment light (the reference's stale-scratch reads reach from one
+    // sample into the next there, DESIGN.md section 1 -- samples of a batch run side by side), the PCG sampler (stateful), a
+    // screen-gradient image (plain read-modify-writes per pixel).
+    const bool batchable = screen_gradient_image == nullptr && opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on &&
+                           (lean == kLean || (!scene.has_mipmaps && scene.d.envmap == nullptr));
     const bool samples_independent = batchable && d_image != nullptr && image == nullptr;
     // A forward render is batched too: its launches deposit per lane into staging planes and ResolveBatchImage adds them to
     // the image in the reference's order (one stream, batches in sample order).

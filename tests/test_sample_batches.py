@@ -13,7 +13,10 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = ('bunny_box_32x32x4', 'two_triangles_64x64x16', 'bunny_box_96x96x8')
+# plain scenes (the lean kernels) and the general kernels: orthographic / lens-distorted cameras, two lights + separate uv /
+# normal indices + viewport + pixel-centre samples, the dead-depth case is not batched (environment light)
+CASES = ('bunny_box_32x32x4', 'two_triangles_64x64x16', 'bunny_box_96x96x8', 'two_triangles_ortho_64x64x4',
+         'two_triangles_distorted_64x64x4', 'misc_features_40x56x4', 'misc_features_viewport_40x56x4')
 
 CODE = r'''
 import sys
