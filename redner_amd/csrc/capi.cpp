@@ -110,12 +110,10 @@ int rdr_debug_dump_edges(const rdr_scene *scene, const char *path) {
         try { s.edge_data(); } catch (const std::exception &e) { set_error(e.what()); fclose(f); return 1; }
     }
     if (!s.edges) { fprintf(f, "edges 0\n"); fclose(f); return 0; }
-#ifndef RDR_HOSTSIM
     if (s.edges->device_trees) {
         std::lock_guard<std::recursive_mutex> lk(g_api_lock);
         try { rdr::download_edge_trees(*s.edges); } catch (const std::exception &e) { set_error(e.what()); fclose(f); return 1; }
     }
-#endif
     const rdr::EdgeData &ed = *s.edges;
     fprintf(f, "edges %d\n", (int)ed.edges.size());
     for (const rdr::EdgeD &e : ed.edges) fprintf(f, "%d %d %d %d %d\n", e.shape_id, e.v0, e.v1, e.f0, e.f1);

@@ -592,12 +592,8 @@ EdgeData *compute_edge_data(const Scene &scene) {
 
     // ---- secondary edges: the two hierarchies (src/edge_tree.cpp:724-882) ----
     if (scene.use_secondary_edges && ne > 0) {
-#ifdef RDR_HOSTSIM
-        ed->device_trees = false;                 // the CPU debugging harness has no kernels: host builder below
-#else
         static const bool host_trees = std::getenv("RDR_EDGE_HOST_BUILD") != nullptr;      // A/B, and the check of one against the other
-        ed->device_trees = !host_trees;
-#endif
+        ed->device_trees = exec::kDeviceEdgeTrees && !host_trees;
         const bool spatial_only = ed->device_trees;      // the kernels compute the Hough-space bounds themselves (edges_gpu.cpp)
         std::vector<int> cs_ids, ncs_ids;
         std::vector<unsigned char> is_sil(ne, 0);
@@ -887,7 +883,6 @@ void publish_edge_data(EdgeData &ed) {
         d.gather.num_tris = (int)(ed.gather.ids.size() / 2);
         d.gather.stack_need = ed.gather.depth + 2;
     }
-#ifndef RDR_HOSTSIM
     if (ed.device_trees) {
         if (d.gather.num_tris > 0) d.gather.ids = (const int *)up(ed.gather.ids.data(), sizeof(int) * ed.gather.ids.size());
         timer.lap("device copies");
@@ -895,7 +890,6 @@ void publish_edge_data(EdgeData &ed) {
         timer.lap("hierarchies (device)");
         return;
     }
-#endif
     d.cs_nodes = ed.cs_fat.empty() ? nullptr : (const EdgeNodeP *)up(ed.cs_fat.data(), sizeof(EdgeNodeP) * ed.cs_fat.size());
     d.ncs_nodes = ed.ncs_fat.empty() ? nullptr : (const EdgeNodeP *)up(ed.ncs_fat.data(), sizeof(EdgeNodeP) * ed.ncs_fat.size());
     if (!ed.gather.nodes.empty()) d.gleaf = (const GatherLeaf *)up(ed.gleaf.data(), sizeof(GatherLeaf) * ed.gleaf.size());

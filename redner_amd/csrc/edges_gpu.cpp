@@ -24,7 +24,6 @@
 #include "edges.h"
 #include "scene.h"
 
-#ifndef RDR_HOSTSIM
 #include <algorithm>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -721,4 +720,3 @@ void download_edge_trees(EdgeData &ed) {
 }
 
 }  // namespace rdr
-#endif  // !RDR_HOSTSIM

@@ -166,6 +166,8 @@ inline void copy_dev(void *dst, const void *src, size_t bytes) {          // dev
     if (bytes) check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx().stream), "copy_dev");
 }
 inline void sync() { check(hipStreamSynchronize(ctx().stream), "sync"); }
+constexpr bool kDeviceEdgeTrees = true;         // the edge hierarchies are built by kernels (edges_gpu.cpp)
+__host__ __device__ inline void gather_stats_add(long, long, int, int) {}      // a hook of the CPU debugging harness
 inline void device_sync() { (void)hipDeviceSynchronize(); }        // every stream of the device (error paths; never throws)
 // Batched transfers for the Scene build (trace.hip): every array goes through one pinned staging buffer, the copies are
 // queued on the stream and ONE synchronisation ends the batch -- a pageable hipMemcpy + sync per array cost 30-200 us each,

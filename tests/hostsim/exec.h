@@ -41,6 +41,7 @@ inline void upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, 
 inline void download(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void copy_dev(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void sync() {}
+constexpr bool kDeviceEdgeTrees = false;      // the harness has no kernels: the host builder of edges.cpp builds the edge hierarchies
 inline void device_sync() {}
 inline size_t pool_cached_bytes() { return 0; }
 inline int current_device() { return 0; }
@@ -143,3 +144,35 @@ inline int choose_replicas(size_t) { return 1; }
 inline void set_replicas(size_t, int) {}
 }
 namespace rdr { inline void accum_f32(float *p, float v) { *p += v; } }
+
+namespace exec {
+// debugging harness only: how much work the gather does per slot (printed at exit when RDR_GATHER_STATS is set)
+struct GatherStats {
+    long slots = 0, nodes = 0, edges = 0, cands = 0, overflow = 0, hist[12] = {0};
+    long wave_max_nodes = 0, wave_max_edges = 0, cur_n = 0, cur_e = 0, in_wave = 0, waves = 0, nhist[16] = {0};
+    long surv = 0, cur_s = 0, wave_max_surv = 0, shist[16] = {0};
+    ~GatherStats() {
+        if (!getenv("RDR_GATHER_STATS") || slots == 0) return;
+        fprintf(stderr, "[gather] per-wave(64) max nodes %.1f  max edge tests %.1f ; node-count histogram (log2 buckets):", (double)wave_max_nodes / (waves ? waves : 1), (double)wave_max_edges / (waves ? waves : 1));
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %ld", nhist[i]);
+        fprintf(stderr, "\n");
+        fprintf(stderr, "[gather] survivors of the cheap tests/slot %.3f, per-wave max %.2f, hist:", (double)surv / slots, (double)wave_max_surv / (waves ? waves : 1));
+        for (int i = 0; i < 16; ++i) fprintf(stderr, " %ld", shist[i]);
+        fprintf(stderr, "\n");
+        fprintf(stderr, "[gather] slots %ld nodes/slot %.1f edge tests/slot %.2f positive leaves/slot %.4f overflow %ld  hist:", slots,
+                (double)nodes / slots, (double)edges / slots, (double)cands / slots, overflow);
+        for (int i = 0; i < 12; ++i) fprintf(stderr, " %ld", hist[i]);
+        fprintf(stderr, "\n");
+    }
+};
+inline void gather_stats_add(long nodes, long edges, int ncand, int surv) {
+    static GatherStats st;
+    st.surv += surv; if (surv > st.cur_s) st.cur_s = surv; st.shist[surv < 15 ? surv : 15]++;
+    st.slots++; st.nodes += nodes; st.edges += edges; st.cands += ncand; st.overflow += ncand > 8; st.hist[ncand < 11 ? ncand : 11]++;
+    int b = 0; while ((1L << b) <= nodes && b < 15) b++;
+    st.nhist[b]++;
+    if (nodes > st.cur_n) st.cur_n = nodes;
+    if (edges > st.cur_e) st.cur_e = edges;
+    if (++st.in_wave == 64) { st.wave_max_nodes += st.cur_n; st.wave_max_edges += st.cur_e; st.wave_max_surv += st.cur_s; st.waves++; st.cur_n = st.cur_e = st.cur_s = 0; st.in_wave = 0; }
+}
+}
