@@ -751,12 +751,13 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     // Not batched: scenes with mip-mapped textures or an environment light (the reference's stale-scratch reads reach from one
     // sample into the next there, DESIGN.md section 1 -- samples of a batch run side by side), the PCG sampler (stateful), a
     // screen-gradient image (plain read-modify-writes per pixel).
-    const bool batchable = screen_gradient_image == nullptr && opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on &&
-                           (lean == kLean || (!scene.has_mipmaps && scene.d.envmap == nullptr));
+    const bool sobol_plain = screen_gradient_image == nullptr && opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on;
+    const bool batchable = sobol_plain && (lean == kLean || (!scene.has_mipmaps && scene.d.envmap == nullptr));
     const bool samples_independent = batchable && d_image != nullptr && image == nullptr;
-    // A forward render is batched too: its launches deposit per lane into staging planes and ResolveBatchImage adds them to
-    // the image in the reference's order (one stream, batches in sample order).
-    const bool forward_batches = batchable && d_image == nullptr && image != nullptr;
+    // A forward render is batched too -- of any scene: the stale scratch belongs to the edge passes -- : its launches deposit
+    // per lane into staging planes and ResolveBatchImage adds them to the image in the reference's order (one stream, batches
+    // in sample order).
+    const bool forward_batches = sobol_plain && d_image == nullptr && image != nullptr;
     BatchView batch;
     batch.P0 = P; batch.rows = cam.vp_y1 - cam.vp_y0;
     if (samples_independent || forward_batches) {
@@ -787,6 +788,24 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         for (int k = 0; k < S; ++k)
             exec::copy_dev(rep + (size_t)k * P * lay.nd, d_image, sizeof(float) * (size_t)P * lay.nd);
         d_image_lanes = rep;
+    }
+    // forward batches with id channels in the output: which components are assigned rather than accumulated
+    const int *assign_flags = nullptr;
+    if (batch.on && forward_batches && !lay.ch.radiance_only) {
+        std::vector<int> flags((size_t)lay.nd, 0);
+        int at = 0;
+        bool any_id = false;
+        for (int k = 0; k < opt.num_channels; ++k) {
+            int one = opt.channels[k];
+            const int w = compute_num_channels(&one, 1, scene.max_generic_texture_dimension);
+            if (one >= RDR_CH_SHAPE_ID) { for (int j = 0; j < w; ++j) flags[at + j] = 1; any_id = true; }
+            at += w;
+        }
+        if (any_id) {
+            int *d_flags = arena.get<int>(flags.size());
+            exec::upload(d_flags, flags.data(), sizeof(int) * flags.size());
+            assign_flags = d_flags;
+        }
     }
     int workers = 1;
     if (samples_independent) workers = std::max(1, std::min(exec::sample_workers(PL, num_batches, batch.on), num_batches));
@@ -862,7 +881,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
                 if (num_active[d + 1].dev && d_image) segments(d + 1);
                 dim += 7;
             }
-            if (w.stage) exec::launch(P * lay.nd, ResolveBatchImage{image, w.stage, P, lay.nd, S_now, B + 1, plane});
+            if (w.stage) exec::launch(P * lay.nd, ResolveBatchImage{image, w.stage, P, lay.nd, S_now, B + 1, plane, assign_flags, vs[0].shape});
 
             if (d_image && !w.bwd) make_backward(w);       // first sample of this worker: the GPU is busy with the stages queued above
             if (w.bwd) w.bwd->run_sample(sample_id, rng, vs, active, num_active, q, lanes, PL, S_now, w.seg);

@@ -171,14 +171,23 @@ struct BumpDynList {
 // (plane k = launch k of the sample: first hit, bounce 1, ...; lanes_stride x nd floats each, zero where nothing was added);
 // one lane per pixel component adds them to the image in the order the reference's launches add them -- sample by sample,
 // launch by launch (src/pathtracer.cpp:283,378) -- so the fp32 sums round exactly as they do one sample at a time.
+// Components of the id channels (shape / triangle / material id) are ASSIGNED by the first-hit stage of every sample whose
+// camera ray hits something (src/primary_contribution.cpp: the last sample wins): `assign[c]` != 0 marks them, `first_shape`
+// (the batch's first-hit shape ids per lane) says which samples wrote.
 struct ResolveBatchImage {
     float *image; const float *stage; int pixels, nd, samples, planes; size_t plane_stride;
+    const int *assign; const int *first_shape;
     RDR_FN void operator()(int i) const {
         const int pixel = i / nd, c = i - pixel * nd;
         float acc = image[i];
-        for (int s = 0; s < samples; ++s)
-            for (int k = 0; k < planes; ++k)
-                acc += stage[(size_t)k * plane_stride + ((size_t)s * pixels + pixel) * nd + c];
+        if (assign && assign[c]) {
+            for (int s = 0; s < samples; ++s)
+                if (first_shape[(size_t)s * pixels + pixel] >= 0) acc = stage[((size_t)s * pixels + pixel) * nd + c];
+        } else {
+            for (int s = 0; s < samples; ++s)
+                for (int k = 0; k < planes; ++k)
+                    acc += stage[(size_t)k * plane_stride + ((size_t)s * pixels + pixel) * nd + c];
+        }
         image[i] = acc;
     }
 };
