@@ -74,10 +74,10 @@ RDR_FN void adj_bilerp(const TexD &tex, double *const *gtexels, int li, V2 uv, i
     double f00 = tx[ch * b.i00 + c], f10 = tx[ch * b.i10 + c], f01 = tx[ch * b.i01 + c], f11 = tx[ch * b.i11 + c];
     double *g = gtexels[li];
     if (g) {
-        accum(g + ch * b.i00 + c, o_bar * (1.f - b.u) * (1.f - b.v));
-        accum(g + ch * b.i10 + c, o_bar * b.u * (1.f - b.v));
-        accum(g + ch * b.i01 + c, o_bar * (1.f - b.u) * b.v);
-        accum(g + ch * b.i11 + c, o_bar * b.u * b.v);
+        accum_texel(g + ch * b.i00 + c, o_bar * (1.f - b.u) * (1.f - b.v));
+        accum_texel(g + ch * b.i10 + c, o_bar * b.u * (1.f - b.v));
+        accum_texel(g + ch * b.i01 + c, o_bar * (1.f - b.u) * b.v);
+        accum_texel(g + ch * b.i11 + c, o_bar * b.u * b.v);
     }
     u_bar += o_bar * (-f00 * (1.f - b.v) + f10 * (1.f - b.v) + -f01 * b.v + f11 * b.v);
     v_bar += o_bar * (-f00 * (1.f - b.u) + -f10 * b.u + f01 * (1.f - b.u) + f11 * b.u);

@@ -80,7 +80,13 @@ __device__ inline double wave_sum(double x) {
     return (r0 + r1) + (r2 + r3);
 }
 
-__device__ inline void accum(double *p, double v) {
+__device__ inline void accum_rounds(double *p, double v, int ROUNDS);
+__device__ inline void accum(double *p, double v) { accum_rounds(p, v, kAccumRounds); }
+// Texel gradients: the lanes of a wave (64 neighbouring pixels) fall on a handful of texels of a magnified or coarse level,
+// several lanes each: more distinct addresses are worth summing across the wave than for per-material / per-vertex data.
+static __device__ int g_texel_rounds = 8;                    // (set_replicas uploads RDR_TEXEL_ROUNDS when it is set: experiments)
+__device__ inline void accum_texel(double *p, double v) { accum_rounds(p, v, g_texel_rounds); }
+__device__ inline void accum_rounds(double *p, double v, int ROUNDS) {
     p += (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & g_replica_mask) * g_replica_stride;
     const unsigned long long act = __ballot(1);
     const unsigned long long addr = (unsigned long long)p;
@@ -88,7 +94,7 @@ __device__ inline void accum(double *p, double v) {
     const int vlo = __double2loint(v), vhi = __double2hiint(v);
     unsigned long long rem = act;
     bool mine = true;                         // this lane's value has not been added yet
-    for (int round = 0; round < kAccumRounds && rem != 0; ++round) {      // wave-uniform trip count
+    for (int round = 0; round < ROUNDS && rem != 0; ++round) {      // wave-uniform trip count
         const int l = __ffsll((long long)rem) - 1;
         const unsigned lo = __builtin_amdgcn_readlane((unsigned)addr, l);
         const unsigned hi = __builtin_amdgcn_readlane((unsigned)(addr >> 32), l);
@@ -114,6 +120,7 @@ __device__ inline void accum(double *p, double v) {
     if (mine) unsafeAtomicAdd(p, v);
 }
 __host__ inline void accum(double *p, double v) { *p += v; }   // host instantiation is never executed
+__host__ inline void accum_texel(double *p, double v) { *p += v; }
 // The same add without the search for lanes that share the address: for per-vertex / per-texel data of large meshes the lanes
 // of a wave almost never do, and the three search rounds cost ~25 scalar + vector instructions each, 18 times per lane in the
 // bounce adjoint (6 000 of its 13 500 instructions per wave, profiles/r2_pmc_sq2.csv).
@@ -265,6 +272,8 @@ inline void set_replicas(size_t stride_doubles, int replicas) {
     unsigned mask = (unsigned)(replicas - 1);
     check(hipMemcpyToSymbolAsync(HIP_SYMBOL(rdr::g_replica_stride), &st, sizeof(st), 0, hipMemcpyHostToDevice, ctx().stream), "set_replicas");
     check(hipMemcpyToSymbolAsync(HIP_SYMBOL(rdr::g_replica_mask), &mask, sizeof(mask), 0, hipMemcpyHostToDevice, ctx().stream), "set_replicas");
+    static const int texel_rounds = [] { const char *e = std::getenv("RDR_TEXEL_ROUNDS"); return e ? std::atoi(e) : 0; }();
+    if (texel_rounds > 0) check(hipMemcpyToSymbolAsync(HIP_SYMBOL(rdr::g_texel_rounds), &texel_rounds, sizeof(int), 0, hipMemcpyHostToDevice, ctx().stream), "set_replicas");
     check(hipStreamSynchronize(ctx().stream), "set_replicas sync");
 }
 

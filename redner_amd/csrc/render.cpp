@@ -116,6 +116,8 @@ bool scene_is_lean(const Scene &scene, const ChannelsD &ch) {
 // Which specialisation of the stages a scene can use (stages_fwd.h): kLean / kMid / kGeneral.
 constexpr int kGeneral = 0, kLean = 1, kMid = 2;
 int scene_kind(const Scene &scene, const ChannelsD &ch) {
+    static const bool force_general = std::getenv("RDR_FORCE_GENERAL") != nullptr;       // A/B: what the specialisations buy
+    if (force_general) return kGeneral;
     if (scene_is_lean(scene, ch)) return kLean;
     const CameraD &c = scene.d.cam;
     if (scene.d.envmap == nullptr && c.kind == kCamPerspective && !c.distortion.defined && ch.radiance_only) return kMid;
