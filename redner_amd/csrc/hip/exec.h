@@ -531,7 +531,8 @@ struct TraceStats {
 };
 TraceStats &trace_stats();
 void trace_stats_collect();     // folds pending hipEvent pairs / device counters into trace_stats()
-void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count n, bool any);
+// `coherent`: neighbouring queue slots hold neighbouring rays that finish together (camera rays): the plain kernel, whatever the size
+void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count n, bool any, bool coherent = false);
 // Host threads render() may drive samples from (RDR_WORKERS=1 turns the second one off).
 inline int sample_workers(int lanes, int samples, bool batches = false) {
     static const int forced = [] { const char *e = std::getenv("RDR_WORKERS"); return e ? std::min(1 + kMaxHelpers, std::max(1, std::atoi(e))) : 0; }();

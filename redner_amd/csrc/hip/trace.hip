@@ -278,6 +278,108 @@ __global__ void __launch_bounds__(256) trace_wide_kernel(rt::BvhD bvh, const rt:
     hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};
 }
 
+// ---- lanes that take the next ray when theirs is done -----------------------------------------------------------------------
+// A wave owns 64 x K consecutive rays of the queue.  A lane whose ray is finished idles only until `idle_min` lanes of the wave
+// are idle; then the idle lanes take the next unclaimed rays of the wave's chunk (a ballot and a popcount: no atomics, no
+// barrier, nothing moves -- the stack column of a lane is reused by its next ray).  Between two such checks every live lane
+// advances `steps` steps.  Every ray takes the same steps in the same order as in the plain kernel; hits are written by ray.
+// Measured (tools/trace_ab.py 2048: queues of 2.6-4.2 M rays, profiles/r3_notes.md), 4 rays per lane / 24 idle lanes / 4 steps:
+// closest-hit on bounce rays 0.948 -> 0.818 ms and 0.750 -> 0.629 ms (-14 ... -16 %), any-hit on bounce rays -13 % / -2 %; on
+// COHERENT queues (camera rays, their shadow rays) +25 % / +19 % -- the lanes of a wave start neighbours and finish together,
+// refilling only mixes them; and on a million rays there are too few waves left to fill the GPU (+13 % with two rays per lane,
+// +28 % with four).  So: queues sized for >= 2^22 lanes that the caller does not mark coherent, four rays per lane; in the
+// 1024 x 1024 benchmark 60.4 -> 62.8 (closest-hit queues) -> 63.5 Msamples/s (shadow-ray queues of bounce vertices too).
+template <bool ANY, class IDX, class Fetch>
+__device__ inline bool traverse_some(const rt::BvhD &bvh, const float o[3], const float d[3], const float inv[3], float tnear, float tfar,
+                                     IDX *stack, rt::Hit &best, int &cur, int &sp, int budget, const Fetch &fetch) {
+    using namespace rt;
+    for (int it = 0; it < budget; ++it) {
+        const Node n = fetch(cur);
+        if (n.b > 0) {
+            for (int k = 0; k < n.b; ++k) {
+                const int slot = n.a + k;
+                const float *t = bvh.tris + 9 * slot;
+                float th;
+                if (ray_triangle(o, d, tnear, tfar, t, t + 3, t + 6, &th)) {
+                    const int s = bvh.ids[2 * slot], p = bvh.ids[2 * slot + 1];
+                    if (ANY) { best = Hit{th, s, p}; return true; }
+                    if (closer(th, s, p, best)) best = Hit{th, s, p};
+                }
+            }
+        } else {
+            const Node l = fetch(n.a), r = fetch(n.a + 1);
+            const float lim = best.shape < 0 ? tfar : best.t * 1.0000004f + 1e-30f;     // closed at best.t: equal-t candidates are still visited
+            float tl, tr;
+            const bool hl = ray_box_once(o, inv, tnear, lim, l.lo, l.hi, &tl);
+            const bool hr = ray_box_once(o, inv, tnear, lim, r.lo, r.hi, &tr);
+            if (hl && hr) {
+                int near = n.a, far = n.a + 1;
+                if (tr < tl) { near = n.a + 1; far = n.a; }
+                stack[sp * 256] = (IDX)far; ++sp;
+                cur = near;
+                continue;
+            } else if (hl) { cur = n.a; continue; }
+            else if (hr) { cur = n.a + 1; continue; }
+        }
+        if (sp == 0) return true;
+        --sp;
+        cur = (int)stack[sp * 256];
+    }
+    return false;
+}
+
+template <bool ANY, int STACK, class IDX>
+__global__ void __launch_bounds__(256) trace_refill_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays, rt::HitRec *__restrict__ hits,
+                                                           int n, const int *count, int rays_per_lane, int idle_min, int steps) {
+    if (count) { const int c = *count; n = c < n ? c : n; }
+    const int chunk = 64 * rays_per_lane;
+    if ((long long)blockIdx.x * 4 * chunk >= n) return;
+    __shared__ IDX stack_tile[STACK * 256];
+    IDX *stack = stack_tile + threadIdx.x;
+    __shared__ rt::Node top[kTopNodes + 1];
+    const int ntop = bvh.num_nodes < kTopNodes ? bvh.num_nodes : kTopNodes;
+    if ((int)threadIdx.x < ntop) top[threadIdx.x] = bvh.nodes[threadIdx.x];
+    __syncthreads();
+    const FetchStaged fetch{bvh.nodes, (LdsFloats)(const float *)top, ntop};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long first = ((long long)blockIdx.x * 4 + wave) * chunk;
+    if (first >= n) return;
+    const int end = (int)(first + chunk < n ? first + chunk : n);
+    int next = (int)first;                                  // wave-uniform
+    bool live = false;
+    int slot = 0, cur = 0, sp = 0;
+    rt::Hit best{0.f, -1, -1};
+    float o[3] = {0, 0, 0}, d[3] = {1, 1, 1}, inv[3] = {1, 1, 1}, tmin = 0, tmax = -1;
+    for (;;) {
+        const unsigned long long idle = __ballot(!live);
+        const int nidle = __popcll(idle);
+        if (next < end && (nidle >= idle_min || nidle == 64)) {
+            if (!live) {
+                const int r = next + __popcll(idle & ((1ull << lane) - 1ull));
+                if (r < end) {
+                    const rt::RayRec ray = rays[r];
+                    slot = r; cur = 0; sp = 0;
+                    o[0] = ray.ox; o[1] = ray.oy; o[2] = ray.oz; d[0] = ray.dx; d[1] = ray.dy; d[2] = ray.dz;
+                    inv[0] = 1.f / d[0]; inv[1] = 1.f / d[1]; inv[2] = 1.f / d[2];
+                    tmin = ray.tmin; tmax = ray.tmax;
+                    best = rt::Hit{tmax, -1, -1};
+                    bool miss = tmax < 0.f || bvh.num_nodes == 0;
+                    if (!miss) { float tn; const rt::Node root = fetch(0); miss = !rt::ray_box(o, inv, tmin, tmax, root.lo, root.hi, &tn); }
+                    if (miss) hits[r] = rt::HitRec{-1, -1}; else live = true;
+                }
+            }
+            next += nidle;
+        }
+        if (__ballot(live) == 0ull) { if (next >= end) break; continue; }
+        if (live) {
+            if (traverse_some<ANY, IDX>(bvh, o, d, inv, tmin, tmax, stack, best, cur, sp, steps, fetch)) {
+                hits[slot] = rt::HitRec{best.shape, best.shape >= 0 ? best.prim : -1};
+                live = false;
+            }
+        }
+    }
+}
+
 hipStream_t side_stream(int k) {
     // k = 0, 1: two non-blocking streams; k = 2, 3: two more at the LOWEST priority.  Where a kernel of the calling stream (a
     // sample's critical path: the continuation-ray traversal, the bounce adjoints) and one of a low-priority side stream
@@ -371,7 +473,7 @@ void trace_stats_collect() {           // call between render() calls: every wor
     }
 }
 
-void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count cnt, bool any) {
+void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count cnt, bool any, bool coherent) {
     const int n = cnt.upper;
     const int *n_dev = cnt.dev;
     if (n <= 0) return;
@@ -427,6 +529,44 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count 
         if (st.timing) g_pending.push_back(p);
         (any ? st.any_launches : st.closest_launches)++;
         if (!st.counting) (any ? st.any_rays : st.closest_rays) += (uint64_t)n;
+        return;
+    }
+    // lanes refilled from the wave's own chunk of the queue (see trace_refill_kernel): queues sized for >= 2^22 lanes that the
+    // caller does not mark coherent.  (The queue's host-side bound decides: a launch sized for 2^22 lanes -- four samples of a
+    // 1024 x 1024 frame, the edge sub-paths' two lanes per slot -- still holds 1.5-3.3 M rays after the compactions; choosing the
+    // rays per lane in the kernel from the actual count was measured too and is slower, 61.8 vs 62.5 Msamples/s.)
+    // RDR_TRACE_REFILL=0: never; ="k,idle,steps": those parameters; RDR_TRACE_REFILL_ALL=1: every queue (tools/trace_ab.py).
+    struct RefillSetup { int k = 4, idle = 24, steps = 4; bool off = false, all = false; };
+    static const RefillSetup rf = [] {
+        RefillSetup r;
+        if (const char *e = std::getenv("RDR_TRACE_REFILL")) {
+            int k = 0, idle = 0, steps = 0;
+            const int got = std::sscanf(e, "%d,%d,%d", &k, &idle, &steps);
+            if (got >= 1 && k <= 0) r.off = true;
+            if (got >= 1 && k > 0) r.k = k;
+            if (got >= 2 && idle > 0) r.idle = idle;
+            if (got >= 3 && steps > 0) r.steps = steps;
+        }
+        r.all = std::getenv("RDR_TRACE_REFILL_ALL") != nullptr;
+        return r;
+    }();
+    const int refill_k = rf.off ? 0 : ((rf.all || (!coherent && n >= (1 << 22))) ? rf.k : 0);
+    if (refill_k >= 1 && !st.counting && bvh.stack_need <= rt::kTraverseStack) {
+        const int idle_min = rf.idle, steps = rf.steps;
+        const int wg_rays = 4 * 64 * refill_k;
+        const int rblocks = (int)(((long long)n + wg_rays - 1) / wg_rays);
+        const int k_arg = refill_k;
+        const bool small = bvh.num_nodes < 65536 && bvh.stack_need <= 24;
+        if (any && small) hipLaunchKernelGGL((trace_refill_kernel<true, 24, unsigned short>), dim3(rblocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, k_arg, idle_min, steps);
+        else if (any) hipLaunchKernelGGL((trace_refill_kernel<true, rt::kTraverseStack, int>), dim3(rblocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, k_arg, idle_min, steps);
+        else if (small) hipLaunchKernelGGL((trace_refill_kernel<false, 24, unsigned short>), dim3(rblocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, k_arg, idle_min, steps);
+        else hipLaunchKernelGGL((trace_refill_kernel<false, rt::kTraverseStack, int>), dim3(rblocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, k_arg, idle_min, steps);
+        check(hipGetLastError(), "trace launch");
+        if (st.timing) check(hipEventRecord(p.b, s), "hipEventRecord");
+        std::lock_guard<std::mutex> lk(g_stats_lock);
+        if (st.timing) g_pending.push_back(p);
+        (any ? st.any_launches : st.closest_launches)++;
+        (any ? st.any_rays : st.closest_rays) += (uint64_t)n;
         return;
     }
 #define RDR_TRACE_LAUNCH(ANY_, COUNT_, STACK_, ctr)                                                                          \

@@ -137,7 +137,8 @@ inline int side_index(int k, int lanes) { return lanes >= (1 << 19) ? k + 2 : k;
 // device (exec::Count); `dyn` / `dyn_inc`: the dimension counter that advances if this bounce had lanes to run.
 exec::Count run_bounce(const Scene &scene, const SceneD &sd, const SamplerD &rng, int dim, int rng_shift,
                        const int *active, exec::Count num_active, const VSlice &v, const VSlice &vn,
-                       const Queues &q, const Sink &sink, int *next_active, int *dyn = nullptr, int dyn_inc = 0) {
+                       const Queues &q, const Sink &sink, int *next_active, int *dyn = nullptr, int dyn_inc = 0,
+                       bool shadow_rays_coherent = false) {
     const int lean = scene_kind(scene, sink.ch);
     launch_v(lean, num_active, BounceSample{sd, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
     // the shadow-ray and the continuation-ray queue are traced side by side: both kernels wait on dependent loads
@@ -153,13 +154,13 @@ exec::Count run_bounce(const Scene &scene, const SceneD &sd, const SamplerD &rng
         {
             exec::StreamScope on(exec::side_stream(side_index(1, num_active.upper)));
             queued->gate(exec::ctx().stream);
-            exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true);
+            exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true, shadow_rays_coherent);
             shadow_done->after(exec::ctx().stream);
         }
         exec::trace(scene.bvh, q.bsdf, q.h_bsdf, num_active, false);
         shadow_done->gate(main_stream);
     } else {
-        exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true);
+        exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true, shadow_rays_coherent);
         exec::trace(scene.bvh, q.bsdf, q.h_bsdf, num_active, false);
     }
     launch_v(lean, num_active, BounceContrib{sd, rng, dim, rng_shift, active, v, vn, q.h_nee, q.h_bsdf, sink});
@@ -866,7 +867,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
 
             // ---- camera vertex ----
             launch_v(lean, lanes, GenPrimary{sd, rng, opt.sample_pixel_center, vs[0], q.bsdf});
-            exec::trace(scene.bvh, q.bsdf, q.h_bsdf, lanes, false);
+            exec::trace(scene.bvh, q.bsdf, q.h_bsdf, lanes, false, true);        // camera rays: a coherent queue
             launch_v(lean, lanes, ShadePrimary{sd, nullptr, vs[0], q.h_bsdf, sink_of(0)});
             std::fill(num_active.begin(), num_active.end(), exec::Count(0));
             num_active[0] = exec::compact_dev((const int *)nullptr, lanes, active, KeepHit{vs[0].shape});
@@ -879,7 +880,8 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
             const int dim_first = dim;
             for (int d = 0; d < B && num_active[d].upper > 0 && has_lights; ++d) {
                 num_active[d + 1] = run_bounce(scene, sd, rng, dim, 0, active + (size_t)d * PL, num_active[d],
-                                               vs[d], vs[d + 1], q, sink_of(d + 1), active + (size_t)(d + 1) * PL, w.main_dyn, 7);
+                                               vs[d], vs[d + 1], q, sink_of(d + 1), active + (size_t)(d + 1) * PL, w.main_dyn, 7,
+                                               d == 0);        // shadow rays of the camera vertices: neighbouring origins
                 if (num_active[d + 1].dev && d_image) segments(d + 1);
                 dim += 7;
             }

@@ -110,7 +110,7 @@ inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const 
 }
 struct TraceStats { double closest_ms = 0, any_ms = 0; uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes[2] = {0, 0}, tris[2] = {0, 0}, wide_nodes[2] = {0, 0}; bool timing = false, counting = false; };
 inline TraceStats &trace_stats() { static TraceStats s; return s; }
-inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count cnt_n, bool any) {
+inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count cnt_n, bool any, bool = false) {
     const int n = cnt_n.value();
     TraceStats &st = trace_stats();
     rt::Counters cnt{0, 0}, wcnt{0, 0};
