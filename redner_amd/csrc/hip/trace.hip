@@ -4,8 +4,13 @@
 // One ray per lane, 256-thread workgroups, per-lane traversal stack in an LDS column (16-bit entries when the
 // hierarchy allows); nodes and triangles are read through L1/L2 (the whole bunny_box hierarchy is ~1 MB and lives in
 // the 4 MiB per-XCD L2).  rt::traverse<> is the shared per-ray routine, so results are bit-identical to the
-// brute-force rule in raytri.h.  Measured numbers, what bounds the kernel and the loop shapes that were tried and
-// rejected are in DESIGN.md section "Traversal kernel" and profiles/r1_notes.md.
+// brute-force rule in raytri.h.  Three kernels, chosen per launch by exec::trace():
+//   trace_kernel          binary 32-byte records, one ray per lane                       (coherent queues; 2^19 < n < 2^22)
+//   trace_wide_kernel     4-wide 128-byte records, one ray per lane: half the steps      (queues of <= 2^19 rays)
+//   trace_refill_kernel   binary records, idle lanes take the next rays of the wave's    (incoherent queues sized for >= 2^22
+//                         own chunk                                                       lanes)
+// Measured numbers, what bounds a launch and the loop shapes that were tried and rejected are in DESIGN.md section 3
+// ("Traversal kernel", "Round 3") and profiles/r1_notes.md, r2_notes.md, r3_notes.md.
 #include "exec.h"
 #include <algorithm>
 #include <cstring>
