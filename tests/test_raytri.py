@@ -161,3 +161,25 @@ def test_reference_scene_intersect_kat_hostsim(hostsim_backend):
 @pytest.mark.gpu
 def test_reference_scene_intersect_kat_gpu(gpu_backend):
     _run_reference_kat(gpu_backend, torch.device('cuda:0'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('env', [{'RDR_TRACE_BINARY': '1'},
+                                 {'RDR_TRACE_BINARY': '1', 'RDR_TRACE_REFILL_ALL': '1', 'RDR_TRACE_REFILL': '2,4,2'},
+                                 {'RDR_TRACE_BINARY': '1', 'RDR_TRACE_REFILL_ALL': '1', 'RDR_TRACE_REFILL': '4,24,4'}],
+                         ids=['binary', 'refill_2_4_2', 'refill_4_24_4'])
+def test_gpu_traversal_kernel_forms(gpu_backend, env):
+    """exec::trace() picks one of three kernels by queue size (4-wide records for small queues, which is what the tests above
+    run; binary records; binary records with lanes that take the next ray of their wave's chunk for large incoherent queues).
+    The switches force the other two onto the small queues of the tests (read once per process: a subprocess): the
+    brute-force rule, the reference's known-answer vectors and a gradient fixture must hold for each."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, '-m', 'pytest', '-q', '-x', '-m', 'gpu', os.path.join(root, 'tests', 'test_raytri.py'),
+           os.path.join(root, 'tests', 'test_backward_parity.py'), '-k',
+           'test_gpu_traversal_equals_host_rule or test_reference_scene_intersect_kat_gpu or (test_backward_gpu and bunny_box_32x32x4)']
+    r = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
