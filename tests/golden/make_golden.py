@@ -311,6 +311,19 @@ def oracle_self_inconsistency(ref, case, K=4):
 
 SELFDIFF_CASES = set(CONFIG_CASES) | {'bunny_box_96x96x8'}
 
+# BASELINE config 4's own frame (1024 x 1024, max_bounces 4) at 1 spp: the 12.6 MB image is not committed -- its SHA-256 (the
+# forward image is bit-identical to the oracle's in every case), 16 x 16 block sums of it, and the bunny's vertex gradient are.
+FULL_FRAME_CASE = ('bunny_box_1024x1024x1', ('bunny_box', 1024, 1, 4))
+
+
+def full_frame_digest(out):
+    import hashlib
+    img = np.ascontiguousarray(out['image'], dtype=np.float32)
+    h, w, c = img.shape
+    blocks = img.astype(np.float64).reshape(h // 16, 16, w // 16, 16, c).sum(axis=(1, 3))
+    return {'image_sha256': np.frombuffer(hashlib.sha256(img.tobytes()).digest(), dtype=np.uint8).copy(), 'image_block_sums': blocks,
+            'grad_shape6_vertices': out['grad_shape6_vertices']}
+
 # ---- ref64: the oracle's estimator with the fp32 accumulation error taken out ------------------------------------------------
 # Few-element gradient tensors (light intensity, constant reflectances, camera, the 3 + 4 vertices of two_triangles) collect
 # millions of fp32 atomic adds per element in ONE backward pass of the reference (src/atomic.h:43-141), and the value it returns
@@ -364,6 +377,11 @@ def main():
         export_bunny_box()
     ref = oracle_util.load_oracle()
     only = [a for a in sys.argv[1:] if not a.startswith('--')]
+    if '--full-frame' in sys.argv:
+        name, case = FULL_FRAME_CASE
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), **full_frame_digest(render_case(ref, *case)))
+        print(name, 'written')
+        return
     if '--ref256' in sys.argv:
         for name in only:
             path = os.path.join(HERE, name + '.npz')
