@@ -51,8 +51,25 @@ __host__ inline void *lds_column_host_stub() { return nullptr; }
 // their values first (xor-butterfly when all 64 lanes are active, otherwise a scalar loop over
 // those lanes in lane order) and issue ONE atomic; that is repeated for up to kAccumRounds distinct
 // addresses (lanes on different materials / walls), whoever is left issues its own hardware fp64 atomic.
-static __device__ unsigned long long g_replica_stride = 0;   // doubles between replicas (0 = none)
-static __device__ unsigned g_replica_mask = 0;               // replicas - 1 (power of two)
+//
+// The accumulators are replicated (GradStore in render.cpp) and a wave adds to the replica its id selects, which spreads
+// the atomics on one logical address over many lines / channels.  Two tiers, because the replica count that the memory
+// budget allows depends on the size of what is replicated: SMALL tensors (camera, light intensities, constant albedos,
+// the vertices of low-poly shapes, the top mip levels) are the ones every wave adds to, and get 256 replicas whatever
+// else the scene holds; LARGE ones (image textures, big meshes) get as many as fit the budget.  Replica 0 of the small
+// tier lies below `hot_end`, everything of the large tier above it: the address tells the tier.
+struct ReplicaLayout {
+    const double *hot_end;           // accumulators (replica 0) below this address belong to the small tier
+    unsigned long long hot_stride;   // doubles between replicas of the small tier
+    unsigned long long stride;       // ... of the large tier (0 = no replicas)
+    unsigned hot_mask, mask;         // replicas - 1 (powers of two)
+};
+static __device__ ReplicaLayout g_rep = {nullptr, 0, 0, 0, 0};
+__device__ inline double *replica_of(double *p) {
+    const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const bool hot = p < g_rep.hot_end;
+    return p + (size_t)(wave & (hot ? g_rep.hot_mask : g_rep.mask)) * (hot ? g_rep.hot_stride : g_rep.stride);
+}
 constexpr int kAccumRounds = 3;                              // distinct addresses summed across the wave per call
 
 // Sum of x over the 64 lanes of a wave, returned in every lane; ALL lanes must be active.  Four data-parallel-primitive
@@ -87,7 +104,7 @@ __device__ inline void accum(double *p, double v) { accum_rounds(p, v, kAccumRou
 static __device__ int g_texel_rounds = 8;                    // (set_replicas uploads RDR_TEXEL_ROUNDS when it is set: experiments)
 __device__ inline void accum_texel(double *p, double v) { accum_rounds(p, v, g_texel_rounds); }
 __device__ inline void accum_rounds(double *p, double v, int ROUNDS) {
-    p += (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & g_replica_mask) * g_replica_stride;
+    p = replica_of(p);
     const unsigned long long act = __ballot(1);
     const unsigned long long addr = (unsigned long long)p;
     const int lane = threadIdx.x & 63;
@@ -125,7 +142,7 @@ __host__ inline void accum_texel(double *p, double v) { *p += v; }
 // of a wave almost never do, and the three search rounds cost ~25 scalar + vector instructions each, 18 times per lane in the
 // bounce adjoint (6 000 of its 13 500 instructions per wave, profiles/r2_pmc_sq2.csv).
 __device__ inline void accum_plain(double *p, double v) {
-    p += (size_t)((blockIdx.x * 4u + (threadIdx.x >> 6)) & g_replica_mask) * g_replica_stride;
+    p = replica_of(p);
     unsafeAtomicAdd(p, v);
 }
 __host__ inline void accum_plain(double *p, double v) { *p += v; }
@@ -260,18 +277,25 @@ struct Fence {
     void gate(hipStream_t consumer) { check(hipStreamWaitEvent(consumer, e, 0), "hipStreamWaitEvent"); }
 };
 
-// Replicated gradient accumulators (see GradStore in render.cpp): up to 256 replicas, as many as
-// fit in 256 MiB.  Must be called from the translation unit that instantiates the stage kernels.
-inline int choose_replicas(size_t replica_bytes) {
+// Replicated gradient accumulators (see GradStore in render.cpp): a power of two, at most 256 and as many as fit `budget`.
+// Must be called from the translation unit that instantiates the stage kernels.
+inline int choose_replicas(size_t replica_bytes, size_t budget) {
     int r = 256;
-    while (r > 1 && replica_bytes * (size_t)r > ((size_t)256 << 20)) r >>= 1;
+    while (r > 1 && replica_bytes * (size_t)r > budget) r >>= 1;
     return r;
 }
-inline void set_replicas(size_t stride_doubles, int replicas) {
-    unsigned long long st = stride_doubles;
-    unsigned mask = (unsigned)(replicas - 1);
-    check(hipMemcpyToSymbolAsync(HIP_SYMBOL(rdr::g_replica_stride), &st, sizeof(st), 0, hipMemcpyHostToDevice, ctx().stream), "set_replicas");
-    check(hipMemcpyToSymbolAsync(HIP_SYMBOL(rdr::g_replica_mask), &mask, sizeof(mask), 0, hipMemcpyHostToDevice, ctx().stream), "set_replicas");
+// Large tier: 256 MiB; a long job (pixels x samples of this call) may take 64 bytes per sample, up to 1 GiB -- the texel
+// gradients of a scene with several image textures per material are > 100 MB per replica, and one or two replicas leave
+// the adjoint stages waiting on the texels' lines (config-5 stand-in with environment map: 17.1 -> 18.5 Msamples/s at
+// 1 GiB).  Zeroing and summing 1 GiB costs ~0.5 ms.  RDR_REPLICA_MB: fixed budget, for experiments.
+inline size_t replica_budget(size_t job_samples) {
+    static const size_t mb = [] { const char *e = std::getenv("RDR_REPLICA_MB"); return e ? (size_t)std::atoi(e) : (size_t)0; }();
+    if (mb) return mb << 20;
+    const size_t lo = (size_t)256 << 20, hi = (size_t)1 << 30, want = job_samples * 64;
+    return want < lo ? lo : (want > hi ? hi : want);
+}
+inline void set_replicas(const rdr::ReplicaLayout &layout) {
+    check(hipMemcpyToSymbolAsync(HIP_SYMBOL(rdr::g_rep), &layout, sizeof(layout), 0, hipMemcpyHostToDevice, ctx().stream), "set_replicas");
     static const int texel_rounds = [] { const char *e = std::getenv("RDR_TEXEL_ROUNDS"); return e ? std::atoi(e) : 0; }();
     if (texel_rounds > 0) check(hipMemcpyToSymbolAsync(HIP_SYMBOL(rdr::g_texel_rounds), &texel_rounds, sizeof(int), 0, hipMemcpyHostToDevice, ctx().stream), "set_replicas");
     check(hipStreamSynchronize(ctx().stream), "set_replicas sync");

@@ -172,32 +172,37 @@ exec::Count run_bounce(const Scene &scene, const SceneD &sd, const SamplerD &rng
 struct GradStore {
     Arena arena;
     GScene g;
-    struct Pair { double *acc; float *out; size_t count; };
-    std::vector<Pair> pairs;
     std::vector<GShape> h_shapes;
     std::vector<GMaterial> h_materials;
 
-    // All accumulators live in ONE block of `stride` doubles that is replicated `replicas` times
-    // (replica r at base + r * stride); rdr::accum() picks the replica from the wave id, which
-    // spreads the atomics on hot addresses (camera, lights, constant albedos, wall corners) over
-    // many cache lines / memory channels.  flush() sums the replicas in fixed order.
-    double *block = nullptr;
-    size_t stride = 0, cursor = 0;
-    int replicas = 1;
+    // The accumulators live in ONE allocation in two tiers (exec.h: ReplicaLayout), each a block of `stride` doubles that
+    // is replicated `replicas` times (replica r at base + r * stride); rdr::accum() picks the replica from the wave id,
+    // which spreads the atomics on hot addresses (camera, lights, constant albedos, wall corners) over many cache lines /
+    // memory channels.  Tensors of at most kSmallTensor elements go to the small tier (256 replicas) while it has room;
+    // the rest -- image textures, big meshes -- to the large tier, which gets the replicas that fit exec::replica_budget():
+    // 256 MiB, up to 1 GiB for a job whose length pays for zeroing and summing that much.
+    // (One tier for everything gave the camera of a scene with 60 MB of texture gradients 4 replicas: every stage that adds
+    // to it or to the walls ran 2-3.5 x longer than with 256, profiles/r3_notes.md.)  flush() sums the replicas in fixed order.
+    static constexpr size_t kSmallTensor = 16384, kSmallTierMax = 65536;      // doubles (one replica of the small tier: <= 512 KiB)
+    struct Tier { double *base = nullptr; size_t stride = 0, cursor = 0; int replicas = 1; };
+    Tier tier[2];                  // 0 = small tensors, 1 = large
+    struct Pair { double *acc; float *out; size_t count; int tier; };
+    std::vector<Pair> pairs;
     bool counting = true;
 
+    double *place(size_t count, int &t) {
+        const size_t padded = (count + 3) & ~(size_t)3;
+        t = (count <= kSmallTensor && tier[0].cursor + padded <= kSmallTierMax) ? 0 : 1;
+        const size_t at = tier[t].cursor;
+        tier[t].cursor += padded;
+        return counting ? reinterpret_cast<double *>(8) : tier[t].base + at;       // placeholder in pass 1
+    }
     double *mirror(float *out, size_t count) {
         if (!out || count == 0) return nullptr;
-        size_t at = cursor;
-        cursor += (count + 3) & ~(size_t)3;
-        if (counting) return reinterpret_cast<double *>(8);       // placeholder, replaced in pass 2
-        pairs.push_back(Pair{block + at, out, count});
-        return block + at;
-    }
-    double *reserve(size_t count) {
-        size_t at = cursor;
-        cursor += (count + 3) & ~(size_t)3;
-        return counting ? reinterpret_cast<double *>(8) : block + at;
+        int t;
+        double *acc = place(count, t);
+        if (!counting) pairs.push_back(Pair{acc, out, count, t});
+        return acc;
     }
     GTex mirror_tex(const TexD &t, const rdr_dtexture_desc &d) {
         GTex g;
@@ -213,15 +218,20 @@ struct GradStore {
         return g;
     }
 
-    GradStore(const Scene &scene, const rdr_dscene_desc &ds) {
-        counting = true; cursor = 0;
-        layout(scene, ds);                                   // pass 1: size of one replica
-        stride = (cursor + 31) & ~(size_t)31;
-        replicas = exec::choose_replicas(stride * sizeof(double));
-        block = arena.get<double>(stride * replicas);
-        exec::zero(block, sizeof(double) * stride * replicas);
-        exec::set_replicas(stride, replicas);
-        counting = false; cursor = 0; pairs.clear();
+    GradStore(const Scene &scene, const rdr_dscene_desc &ds, size_t job_samples) {
+        counting = true;
+        layout(scene, ds);                                   // pass 1: size of one replica of each tier
+        for (Tier &t : tier) t.stride = (t.cursor + 31) & ~(size_t)31;
+        tier[0].replicas = tier[0].stride ? exec::choose_replicas(tier[0].stride * sizeof(double), 256 * kSmallTierMax * sizeof(double)) : 1;
+        tier[1].replicas = tier[1].stride ? exec::choose_replicas(tier[1].stride * sizeof(double), exec::replica_budget(job_samples)) : 1;
+        const size_t small_total = tier[0].stride * tier[0].replicas, total = small_total + tier[1].stride * tier[1].replicas;
+        double *block = arena.get<double>(total);
+        exec::zero(block, sizeof(double) * total);
+        tier[0].base = block; tier[1].base = block + small_total;
+        exec::set_replicas(ReplicaLayout{block + tier[0].stride, tier[0].stride, tier[1].stride,
+                                         (unsigned)(tier[0].replicas - 1), (unsigned)(tier[1].replicas - 1)});
+        counting = false; pairs.clear();
+        for (Tier &t : tier) t.cursor = 0;
         layout(scene, ds);                                   // pass 2: real pointers
     }
     void layout(const Scene &scene, const rdr_dscene_desc &ds) {
@@ -257,10 +267,11 @@ struct GradStore {
         // light intensities: one contiguous fp64 block, scattered back per light
         g.light_intensity = nullptr;
         if (!scene.lights.empty()) {
-            g.light_intensity = reserve(3 * scene.lights.size());
+            int light_tier = 0;
+            g.light_intensity = place(3 * scene.lights.size(), light_tier);
             if (!counting)
                 for (size_t l = 0; l < scene.lights.size(); ++l)
-                    if (ds.area_lights[l].intensity) pairs.push_back(Pair{g.light_intensity + 3 * l, ds.area_lights[l].intensity, 3});
+                    if (ds.area_lights[l].intensity) pairs.push_back(Pair{g.light_intensity + 3 * l, ds.area_lights[l].intensity, 3, light_tier});
         }
         const rdr_dcamera_desc &dc = ds.camera;
         g.cam.position = mirror(dc.position, 3); g.cam.look = mirror(dc.look, 3); g.cam.up = mirror(dc.up, 3);
@@ -279,24 +290,26 @@ struct GradStore {
         }
     }
     void flush() {
-        std::vector<FlushSegment> seg;
-        for (const Pair &p : pairs) seg.push_back(FlushSegment{(size_t)(p.acc - block), p.count, p.out});
-        std::sort(seg.begin(), seg.end(), [](const FlushSegment &a, const FlushSegment &b) { return a.begin < b.begin; });
-        if (!seg.empty()) {
-            if (stride > (size_t)0x7fffffff) throw std::runtime_error("render: gradient block too large");
+        // one launch per tier for all its tensors, unless two mirrors feed overlapping output ranges (a tensor shared by two
+        // DScene entries): those must add one after the other
+        std::vector<Pair> by_out(pairs);
+        std::sort(by_out.begin(), by_out.end(), [](const Pair &a, const Pair &b) { return a.out < b.out; });
+        bool aliased = false;
+        for (size_t i = 1; i < by_out.size(); ++i) aliased = aliased || by_out[i - 1].out + by_out[i - 1].count > by_out[i].out;
+        for (int t = 0; t < 2; ++t) {
+            const Tier &tr = tier[t];
+            std::vector<FlushSegment> seg;
+            for (const Pair &p : pairs) if (p.tier == t) seg.push_back(FlushSegment{(size_t)(p.acc - tr.base), p.count, p.out});
+            if (seg.empty()) continue;
+            std::sort(seg.begin(), seg.end(), [](const FlushSegment &a, const FlushSegment &b) { return a.begin < b.begin; });
+            if (tr.stride > (size_t)0x7fffffff) throw std::runtime_error("render: gradient block too large");
             FlushSegment *d_seg = arena.get<FlushSegment>(seg.size());
             exec::upload(d_seg, seg.data(), sizeof(FlushSegment) * seg.size());
-            // one launch for all tensors, unless two mirrors feed overlapping output ranges (a tensor shared by two
-            // DScene entries): those must add one after the other
-            std::vector<FlushSegment> by_out(seg);
-            std::sort(by_out.begin(), by_out.end(), [](const FlushSegment &a, const FlushSegment &b) { return a.out < b.out; });
-            bool aliased = false;
-            for (size_t i = 1; i < by_out.size(); ++i) aliased = aliased || by_out[i - 1].out + by_out[i - 1].count > by_out[i].out;
-            if (!aliased) exec::launch((int)stride, FlushGrad{block, stride, replicas, d_seg, (int)seg.size()});
+            if (!aliased) exec::launch((int)tr.stride, FlushGrad{tr.base, tr.stride, tr.replicas, d_seg, (int)seg.size()});
             else for (size_t i = 0; i < seg.size(); ++i)
-                exec::launch((int)(seg[i].begin + seg[i].count), FlushGrad{block, stride, replicas, d_seg + i, 1});
+                exec::launch((int)(seg[i].begin + seg[i].count), FlushGrad{tr.base, tr.stride, tr.replicas, d_seg + i, 1});
         }
-        exec::set_replicas(0, 1);
+        exec::set_replicas(ReplicaLayout{nullptr, 0, 0, 0, 0});
     }
 };
 
@@ -735,7 +748,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         lay.ch.id = ids;
     }
     std::unique_ptr<GradStore> grads;
-    if (d_image) grads.reset(new GradStore(scene, *d_scene));
+    if (d_image) grads.reset(new GradStore(scene, *d_scene, (size_t)P * (size_t)opt.num_samples));
 
     uint64_t *pcg_main = nullptr;
     if (opt.sampler_type == RDR_SAMPLER_INDEPENDENT) {

@@ -141,9 +141,11 @@ inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits,
 } // namespace exec
 namespace exec {
 inline void trace_stats_collect() {}
-inline int choose_replicas(size_t) { return 1; }
-inline void set_replicas(size_t, int) {}
+inline int choose_replicas(size_t, size_t) { return 1; }
+inline size_t replica_budget(size_t) { return 0; }
 }
+namespace rdr { struct ReplicaLayout { const double *hot_end; unsigned long long hot_stride, stride; unsigned hot_mask, mask; }; }
+namespace exec { inline void set_replicas(const rdr::ReplicaLayout &) {} }
 namespace rdr { inline void accum_f32(float *p, float v) { *p += v; } }
 
 namespace exec {

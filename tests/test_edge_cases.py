@@ -213,3 +213,43 @@ np.savez(sys.argv[1], img_a=img_a.detach().numpy(), img_b=img_b.detach().numpy()
         x, y = outs['beside'][k].astype(np.float64), outs['in_place'][k].astype(np.float64)
         assert np.abs(y).sum() > 0
         assert np.linalg.norm(x - y) <= 1e-6 * np.linalg.norm(y)
+
+
+def _shared_gradient_buffer(backend, device):
+    """Two materials whose DMaterial entries point at ONE gradient buffer (possible at the C boundary: the DScene holds plain
+    pointers): the buffer must receive the sum of what each material would have received alone."""
+    sc = scenes.two_triangles(device, resolution=(24, 24))
+    args = RenderFunction.serialize_scene(sc, 2, 2, sampler_type=backend.SamplerType.sobol, device=device, backend=backend)
+    meta, tensors = args[0], list(args[1:])
+    u = RenderFunction.unpack_args((3, 3), meta, tensors)
+    grad_img = torch.ones(24, 24, 3, device=device)
+
+    def backward(m):
+        d_scene, grads = RenderFunction.create_gradient_buffers(m, tensors)
+        backend.render(u.scene, u.options, backend.float_ptr(0), backend.float_ptr(grad_img.data_ptr()), d_scene,
+                       backend.float_ptr(0), backend.float_ptr(0))
+        return grads
+
+    i0 = meta['materials'][0]['diffuse_reflectance']['levels'][0]
+    i1 = meta['materials'][1]['diffuse_reflectance']['levels'][0]
+    apart = backward(meta)
+    import copy
+    shared_meta = copy.copy(meta)
+    shared_meta['materials'] = copy.deepcopy(meta['materials'])
+    shared_meta['materials'][1]['diffuse_reflectance']['levels'][0] = i0
+    shared = backward(shared_meta)
+    want = (apart[i0] + apart[i1]).cpu().numpy()
+    got = shared[i0].cpu().numpy()
+    assert np.linalg.norm(want) > 0
+    assert np.linalg.norm(got - want) <= 1e-5 * np.linalg.norm(want)
+    cam = meta['camera']['position']
+    assert np.linalg.norm((shared[cam] - apart[cam]).cpu().numpy()) <= 1e-5 * np.linalg.norm(apart[cam].cpu().numpy())
+
+
+def test_gradient_buffer_shared_by_two_entries_hostsim(hostsim_backend):
+    _shared_gradient_buffer(hostsim_backend, torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_gradient_buffer_shared_by_two_entries_gpu(gpu_backend):
+    _shared_gradient_buffer(gpu_backend, torch.device('cuda:0'))
