@@ -121,6 +121,10 @@ CASES = {
     # max_bounces 6, camera-pose gradients; and its environment-map + SVBRDF-texture variant
     'living_room_standin_40x40x2': ('living_room_standin', 40, 2, 6),
     'living_room_standin_envmap_32x32x2': ('living_room_standin_envmap', 32, 2, 6),
+    # a triangle that crosses the near plane, light behind the camera (tests/test_single_triangle_clipped.py)
+    'triangle_through_near_plane_64x64x4': ('triangle_through_near_plane', 64, 4, 1),
+    # near-mirror floor reflecting a light and a blocker (tests/test_shadow_glossy.py)
+    'glossy_floor_blocker_48x48x4': ('glossy_floor_blocker', 48, 4, 2),
     # render_albedo/render_g_buffer style: no radiance, no bounces (pyredner/render_utils.py)
     'textured_sphere_albedo_48x48x4': ('textured_sphere', 48, 4, 0,
                                        ['depth', 'shading_normal', 'diffuse_reflectance', 'uv']),

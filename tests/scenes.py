@@ -47,6 +47,41 @@ def two_triangles(device, resolution=(256, 256)):
     return Scene(cam, [t0, t1, light], mats, [AreaLight(2, _t([20.0, 20.0, 20.0], 'cpu'))])
 
 
+def triangle_through_near_plane(device, resolution=(64, 64)):
+    """tests/test_single_triangle_clipped.py:12-41: a triangle one corner of which lies BEHIND the camera, so the primary
+    edge sampler has to clip its edges against the near plane (src/edge.cpp: project / clip), with the light behind the
+    camera as there.  The triangle's vertices and the camera pose carry gradients."""
+    cam = Camera(position=_t([0.0, 0.0, -5.0], 'cpu', grad=True), look_at=_t([0.0, 0.0, 0.0], 'cpu', grad=True),
+                 up=_t([0.0, 1.0, 0.0], 'cpu', grad=True), fov=_t([45.0], 'cpu'), clip_near=1e-2, resolution=resolution)
+    mats = [Material(diffuse_reflectance=_t([0.55, 0.5, 0.45], device, grad=True))]
+    tri = Shape(_t([[-1.2, 0.9, 0.2], [1.1, 1.1, -0.2], [-0.4, -1.9, -6.6]], device, grad=True),
+                _t([[0, 1, 2]], device, torch.int32), 0)
+    light = Shape(_t([[-1.0, -1.0, -7.0], [1.0, -1.0, -7.0], [-1.0, 1.0, -7.0], [1.0, 1.0, -7.0]], device),
+                  _t([[0, 1, 2], [1, 3, 2]], device, torch.int32), 0)
+    return Scene(cam, [tri, light], mats, [AreaLight(1, _t([20.0, 20.0, 20.0], 'cpu', grad=True))])
+
+
+def glossy_floor_blocker(device, resolution=(48, 48)):
+    """tests/test_shadow_glossy.py:11-60 (and the other test_shadow_* scripts): a floor, a blocker between it and an area
+    light, the camera looking down at the floor.  The floor is a near-mirror (roughness 5e-4, no diffuse part), so what
+    the camera sees is the reflection of light and blocker: BSDF-sampled specular paths, the min_roughness rule of the
+    secondary edge sampler (src/edge.cpp:1396-1401) and nearly singular pdfs.  Gradients: blocker and floor vertices,
+    the floor's specular reflectance and roughness, the light, the camera position."""
+    cam = Camera(position=_t([0.0, 2.0, -4.0], 'cpu', grad=True), look_at=_t([0.0, -2.0, 0.0], 'cpu'),
+                 up=_t([0.0, 1.0, 0.0], 'cpu'), fov=_t([45.0], 'cpu'), clip_near=1e-2, resolution=resolution)
+    mats = [Material(diffuse_reflectance=_t([0.0, 0.0, 0.0], device), specular_reflectance=_t([0.9, 0.95, 1.0], device, grad=True),
+                     roughness=_t([0.0005], device, grad=True)),
+            Material(diffuse_reflectance=_t([0.5, 0.45, 0.55], device, grad=True)),
+            Material(diffuse_reflectance=_t([0.0, 0.0, 0.0], device))]
+    floor = Shape(_t([[-4.0, 0.0, -4.0], [-4.0, 0.0, 4.0], [4.0, 0.0, -4.0], [4.0, 0.0, 4.0]], device, grad=True),
+                  _t([[0, 1, 2], [1, 3, 2]], device, torch.int32), 0)
+    blocker = Shape(_t([[0.1, 5.0, 0.0], [-0.4, 7.1, 2.0], [1.4, 5.2, -0.1], [1.1, 7.0, 2.1]], device, grad=True),
+                    _t([[0, 1, 2], [1, 3, 2]], device, torch.int32), 1)
+    light = Shape(_t([[-2.0, 7.0, 4.0], [-2.0, 11.0, 4.0], [2.0, 7.0, 4.0], [2.0, 11.0, 4.0]], device),
+                  _t([[0, 1, 2], [1, 3, 2]], device, torch.int32), 2)
+    return Scene(cam, [floor, blocker, light], mats, [AreaLight(2, _t([0.6, 0.55, 0.5], 'cpu', grad=True))])
+
+
 def triangle_soup_large(device, resolution=(32, 32)):
     """The same at 40x the size (60 k triangles, 180 k edges): the edge-structure kernels beyond one workgroup's worth of anything."""
     return triangle_soup(device, resolution, scale=40)
