@@ -7,7 +7,7 @@ timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $OUT/pytest.log
 unset RDR_PARITY_REPORT
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
 timeout 900 python bench.py 2> $OUT/bench_default.err | tail -1 > $OUT/bench_default.json
-RDR_BATCH=1 timeout 600 python bench.py --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_one_sample_per_launch.json
+[ -n "$FINAL_WITH_ONE_SAMPLE" ] && RDR_BATCH=1 timeout 600 python bench.py --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_one_sample_per_launch.json
 timeout 600 python bench.py --workload living_room_standin --spp 32 --steps 2 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_living_room_standin.json
 timeout 600 python bench.py --workload living_room_standin_envmap --spp 32 --steps 2 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_living_room_standin_envmap.json
 { for cfg in "256 4" "256 4 move" "256 16" "128 8" "512 4" "64 4"; do echo "== $cfg"; python tools/small_loop_timing.py $cfg 2>&1 | tail -4; done; echo "== 256 4, one sample per launch (RDR_BATCH=1)"; RDR_BATCH=1 python tools/small_loop_timing.py 256 4 2>&1 | tail -4; } > $OUT/small_loop.txt
@@ -19,5 +19,5 @@ RDR_NO_OVERLAP=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format cs
 cp $OUT/stats_alone/*/*_kernel_stats.csv $OUT/kernel_stats_alone.csv
 rm -rf $OUT/stats $OUT/stats_alone
 cd $GRAFT_REPO_ROOT
-cat $OUT/pytest.log; cut -c1-260 $OUT/bench_default.json; echo; for f in one_sample_per_launch living_room_standin living_room_standin_envmap; do python -c "
+cat $OUT/pytest.log; cut -c1-260 $OUT/bench_default.json; echo; for f in living_room_standin living_room_standin_envmap; do python -c "
 import json; d=json.loads(open('$OUT/bench_$f.json').read()); print('$f', round(d['value'],2), 'roofline', round(d['roofline']['frac'],3))"; done; cat $OUT/small_loop.txt | grep -E "==|iteration"
