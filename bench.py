@@ -53,7 +53,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9     # CUs x SIMDs x lanes/clk x clock = 39.3 T lane-operations/s (79 TFLOP/s fp64 FMA)
 RAY_BYTES, HIT_BYTES, NODE_BYTES, WIDE_NODE_BYTES, TRI_BYTES = 32, 8, 32, 128, 36
-INNER_SPP = 8                  # samples of the job the rocprofv3 passes run (forms the same sample batches as the timed job at 1024 x 1024)
+INNER_SPP = 32                 # samples of the job the rocprofv3 passes run (forms the same sample batches as the timed job at 1024 x 1024)
 
 
 class Prepared:

@@ -203,7 +203,7 @@ int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, in
 
 /* Per-call device buffers (the reference's PathBuffer, src/pathtracer.cpp:36-152, allocated and freed by every render())
  * come from a caching allocator: blocks are parked for the next call of the same shape (bounded by RDR_POOL_CAP_MB per device,
- * default 16384).  rdr_trim_cache() returns every parked block to the driver -- for processes that share the device with
+ * default a quarter of the device's memory).  rdr_trim_cache() returns every parked block to the driver -- for processes that share the device with
  * another allocator (torch) and change resolution.  Returns the number of bytes released. */
 uint64_t rdr_trim_cache(void);
 

@@ -80,9 +80,15 @@ void pool_free(void *p) {
     std::lock_guard<std::mutex> lk(pl.lock);
     auto it = pl.live.find(p);
     if (it == pl.live.end()) { (void)hipFree(p); return; }
-    // The cache is bounded (RDR_POOL_CAP_MB, default 16 GiB per device of the 288 GB): a torch process shares the device with
-    // torch's own allocator, which cannot reclaim what is parked here; rdr_trim_cache() releases everything.
-    static const size_t cap = [] { const char *e = std::getenv("RDR_POOL_CAP_MB"); return (size_t)(e ? std::max(0, std::atoi(e)) : 16384) << 20; }();
+    // The cache is bounded (RDR_POOL_CAP_MB, default a quarter of the device's memory: 72 of the 288 GB, enough for the
+    // buffers of a 2^24-lane sample batch): a torch process shares the device with torch's own allocator, which cannot reclaim
+    // what is parked here; rdr_trim_cache() releases everything.
+    static const size_t cap = [] {
+        if (const char *e = std::getenv("RDR_POOL_CAP_MB")) return (size_t)std::max(0, std::atoi(e)) << 20;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (size_t)16384 << 20; }
+        return total_b / 4;
+    }();
     auto &fl = pl.free_blocks[it->second.second & 15];
     size_t parked = it->second.first;
     for (auto &kv : fl) parked += kv.first;

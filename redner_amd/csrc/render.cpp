@@ -781,15 +781,16 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         // up to ~131 k lanes and little more up to 524 k; two batches in flight on two host threads beat one of twice the size
         // from 262 k lanes on; and a launch keeps getting cheaper per lane up to several million lanes (every kernel of this
         // path ends with a tail of long lanes: the closest-hit launch takes ~80 us + 0.215 ns per ray) -- the 1024 x 1024
-        // benchmark runs 53.2 / 56.8 / 59.7 / 60.0 Msamples/s with 1 / 2 / 4 / 8 samples per launch.  So: everything in one
-        // batch while that is <= 2^17 lanes, otherwise batches of up to 2^22 lanes (RDR_BATCH_LANES; the buffers of such a batch
-        // take 4x a sample's: ~16 GB of the 288 GB at 1024 x 1024), at least two of them, driven by two workers while a batch
-        // is below 2^20 lanes.
+        // benchmark ran 53.2 / 56.8 / 59.7 / 60.0 Msamples/s with 1 / 2 / 4 / 8 samples per launch before the refilling traversal
+        // kernel, and runs 61.3 / 62.8 / 64.0 with 4 / 8 / 16 since (closest-hit launch at 0.62 / 0.69 / 0.73 of the roofline).
+        // So: everything in one batch while that is <= 2^17 lanes, otherwise batches of up to 2^24 lanes (RDR_BATCH_LANES; the
+        // buffers of such a batch are ~4 KB per lane: 64 GB of the 288 GB, which the buffer cache keeps between calls), at
+        // least two of them, driven by two workers while a batch is below 2^20 lanes.
         static const int batch_cap = [] { const char *e = std::getenv("RDR_BATCH"); return e ? std::max(1, std::min(kMaxBatch, std::atoi(e))) : kMaxBatch; }();
         const long long total = (long long)opt.num_samples * P;
         int want = opt.num_samples;
         if (total > (1 << 17) && samples_independent) want = (opt.num_samples + 1) / 2;
-        static const long long lane_cap = [] { const char *e = std::getenv("RDR_BATCH_LANES"); return e ? std::max(1LL, std::atoll(e)) : (1LL << 22); }();
+        static const long long lane_cap = [] { const char *e = std::getenv("RDR_BATCH_LANES"); return e ? std::max(1LL, std::atoll(e)) : (1LL << 24); }();
         batch.S = std::max(1, std::min(std::min(batch_cap, want), (int)std::max(1LL, lane_cap / P)));
         batch.on = batch.S > 1;
     }
