@@ -174,6 +174,7 @@ void *pool_alloc(size_t bytes);
 void pool_free(void *p);
 void pool_trim();                     // hipFree of every parked block (synchronises the device first)
 size_t pool_cached_bytes();           // bytes parked in the free lists right now
+size_t memory_available();            // what a call can still get: free device memory + what is parked in the cache
 size_t pool_device_mallocs();          // number of hipMalloc calls made by the pool so far (tests: steady state adds none)
 inline std::atomic<size_t> &host_count_reads_ref() { static std::atomic<size_t> n{0}; return n; }
 inline size_t host_count_reads() { return host_count_reads_ref().load(); }     // live-lane counts read back by the host so far

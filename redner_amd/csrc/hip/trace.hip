@@ -120,6 +120,12 @@ size_t pool_cached_bytes() {
     return total;
 }
 
+size_t memory_available() {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return ~(size_t)0; }
+    return free_b + pool_cached_bytes();
+}
+
 size_t pool_device_mallocs() { Pool &pl = pool(); std::lock_guard<std::mutex> lk(pl.lock); return pl.device_mallocs; }
 
 namespace {

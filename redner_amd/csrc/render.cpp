@@ -792,6 +792,12 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         if (total > (1 << 17) && samples_independent) want = (opt.num_samples + 1) / 2;
         static const long long lane_cap = [] { const char *e = std::getenv("RDR_BATCH_LANES"); return e ? std::max(1LL, std::atoll(e)) : (1LL << 24); }();
         batch.S = std::max(1, std::min(std::min(batch_cap, want), (int)std::max(1LL, lane_cap / P)));
+        // ... and what the device can still give: a batch's buffers are ~(400 (max_bounces + 1) + 1200) bytes per lane (2.9 KB
+        // measured at max_bounces 4 with both edge estimators); a process that shares the GPU with a large torch model
+        // gets smaller batches instead of an allocation failure
+        const double per_lane = 400.0 * (B + 1) + 1200.0;
+        const double room = 0.8 * (double)exec::memory_available();
+        while (batch.S > 1 && per_lane * batch.S * P > room) batch.S = (batch.S + 1) / 2;
         batch.on = batch.S > 1;
     }
     const int S = batch.S;

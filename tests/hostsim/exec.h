@@ -45,6 +45,7 @@ inline void sync() {}
 constexpr bool kDeviceEdgeTrees = false;      // the harness has no kernels: the host builder of edges.cpp builds the edge hierarchies
 inline void device_sync() {}
 inline size_t pool_cached_bytes() { return 0; }
+inline size_t memory_available() { return ~(size_t)0; }
 inline int current_device() { return 0; }
 inline void upload_async(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void upload_flush() {}
