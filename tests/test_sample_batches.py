@@ -4,7 +4,8 @@ compaction whose ranks number the secondary-edge sampler's slots, src/pathtracer
 advance only for samples whose lists are not empty, :432-436, 590-706; the order in which a pixel's fp32 image sums take the
 launches' contributions, :283,378) is kept per sample, so a batched render must equal the one-sample-at-a-time render:
 the image bit for bit, the gradients bit for bit on the sequential CPU harness and to the order of fp64 atomics on the GPU.
-RDR_BATCH=1 switches batching off (read once per process, hence the subprocesses)."""
+RDR_BATCH=1 switches batching off (read once per process, hence the subprocesses).  A third run pretends that the device has
+100 MB left (RDR_MEM_AVAILABLE_MB): the batches shrink to what fits (render.cpp) and nothing else changes."""
 import os
 import subprocess
 import sys
@@ -40,10 +41,13 @@ np.savez(sys.argv[1], **out)
 def _both(tmp_path, lib, dev):
     code = CODE % {'root': ROOT, 'lib': lib, 'dev': dev, 'cases': CASES}
     paths = []
-    for tag, env in (('one', {'RDR_BATCH': '1'}), ('batched', {})):
+    for tag, env in (('one', {'RDR_BATCH': '1'}), ('batched', {}), ('tight', {'RDR_MEM_AVAILABLE_MB': '100'})):
         p = str(tmp_path / (tag + '.npz'))
         e = dict(os.environ, **env)
-        e.pop('RDR_BATCH', None) if tag == 'batched' else None
+        if tag != 'one':
+            e.pop('RDR_BATCH', None)
+        if tag != 'tight':
+            e.pop('RDR_MEM_AVAILABLE_MB', None)
         subprocess.check_call([sys.executable, '-c', code, p], env=e, timeout=900)
         paths.append(np.load(p))
     return paths
@@ -51,19 +55,21 @@ def _both(tmp_path, lib, dev):
 
 def test_batches_equal_single_samples_hostsim(hostsim_backend, tmp_path):
     from conftest import HOSTSIM_LIB
-    one, batched = _both(tmp_path, HOSTSIM_LIB, 'cpu')
+    one, batched, tight = _both(tmp_path, HOSTSIM_LIB, 'cpu')
     for k in one.files:
         assert np.array_equal(one[k], batched[k]), k           # sequential harness: every tensor bit for bit
+        assert np.array_equal(one[k], tight[k]), k
 
 
 @pytest.mark.gpu
 def test_batches_equal_single_samples_gpu(gpu_backend, tmp_path):
     from redner_amd import _capi
-    one, batched = _both(tmp_path, _capi.library_path(), 'cuda:0')
-    for k in one.files:
-        if k.endswith('/image'):
-            assert np.array_equal(one[k], batched[k]), k       # the image: fp32 sums in the reference's order
-        else:
-            a, b = one[k].astype(np.float64), batched[k].astype(np.float64)
-            n = np.linalg.norm(a)
-            assert np.linalg.norm(a - b) <= 2e-6 * n + 1e-30, (k, np.linalg.norm(a - b) / max(n, 1e-300))
+    one, batched, tight = _both(tmp_path, _capi.library_path(), 'cuda:0')
+    for other in (batched, tight):
+        for k in one.files:
+            if k.endswith('/image'):
+                assert np.array_equal(one[k], other[k]), k     # the image: fp32 sums in the reference's order
+            else:
+                a, b = one[k].astype(np.float64), other[k].astype(np.float64)
+                n = np.linalg.norm(a)
+                assert np.linalg.norm(a - b) <= 2e-6 * n + 1e-30, (k, np.linalg.norm(a - b) / max(n, 1e-300))
