@@ -768,7 +768,10 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     // sample into the next there, DESIGN.md section 1 -- samples of a batch run side by side), the PCG sampler (stateful), a
     // screen-gradient image (plain read-modify-writes per pixel).
     const bool sobol_plain = screen_gradient_image == nullptr && opt.sampler_type == RDR_SAMPLER_SOBOL && !timer.on;
-    const bool batchable = sobol_plain && (lean == kLean || (!scene.has_mipmaps && scene.d.envmap == nullptr));
+    // Without either edge estimator (a loop that moves materials, textures or lights only: pyredner switches them off when
+    // neither the camera nor a vertex requires a gradient) there is no such scratch and every scene is batched.
+    const bool no_edge_passes = !scene.use_primary_edges && !scene.use_secondary_edges;
+    const bool batchable = sobol_plain && (lean == kLean || no_edge_passes || (!scene.has_mipmaps && scene.d.envmap == nullptr));
     const bool samples_independent = batchable && d_image != nullptr && image == nullptr;
     // A forward render is batched too -- of any scene: the stale scratch belongs to the edge passes -- : its launches deposit
     // per lane into staging planes and ResolveBatchImage adds them to the image in the reference's order (one stream, batches

@@ -125,6 +125,14 @@ CASES = {
     'triangle_through_near_plane_64x64x4': ('triangle_through_near_plane', 64, 4, 1),
     # near-mirror floor reflecting a light and a blocker (tests/test_shadow_glossy.py)
     'glossy_floor_blocker_48x48x4': ('glossy_floor_blocker', 48, 4, 2),
+    # material / texture / light optimisation: neither edge estimator (what pyredner selects when neither the camera nor a vertex
+    # requires a gradient) -- the gradient render of these mip-mapped / environment-lit scenes is then batched like a plain one
+    'living_room_standin_envmap_noedges_32x32x4': ('living_room_standin_envmap', 32, 4, 6, None,
+                                                   {'use_primary_edge_sampling': False, 'use_secondary_edge_sampling': False}),
+    'envmap_sphere_noedges_48x48x4': ('envmap_sphere', 48, 4, 2, None,
+                                      {'use_primary_edge_sampling': False, 'use_secondary_edge_sampling': False}),
+    'misc_features_noedges_40x56x4': ('misc_features', (40, 56), 4, 2, None,
+                                      {'use_primary_edge_sampling': False, 'use_secondary_edge_sampling': False}),
     # render_albedo/render_g_buffer style: no radiance, no bounces (pyredner/render_utils.py)
     'textured_sphere_albedo_48x48x4': ('textured_sphere', 48, 4, 0,
                                        ['depth', 'shading_normal', 'diffuse_reflectance', 'uv']),
