@@ -87,5 +87,6 @@ def record(name, rep, backend_tag):
     """Append the per-tensor numbers of one case to $RDR_PARITY_REPORT (a JSON-lines file), if set."""
     path = os.environ.get('RDR_PARITY_REPORT')
     if path:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)     # a report must never fail a test
         with open(path, 'a') as f:
             f.write(json.dumps({'case': name, 'backend': backend_tag, **summary(rep), 'tensors': rep}) + '\n')
