@@ -56,6 +56,7 @@ def test_stat_functionals_gpu(gpu_backend, name):
     path = os.environ.get('RDR_PARITY_REPORT')
     if path:
         import json
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         with open(path, 'a') as f:
             f.write(json.dumps({'case': name, 'backend': 'gpu', 'z_paired_max': float(z_paired.max()),
                                 'z_unpaired_max': float(z_unpaired.max()), 'share_identical': share_equal}) + '\n')
