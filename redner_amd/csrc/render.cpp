@@ -800,8 +800,10 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         // gets smaller batches instead of an allocation failure
         const double per_lane = 400.0 * (B + 1) + 1200.0;
         static const double room_override = [] { const char *e = std::getenv("RDR_MEM_AVAILABLE_MB"); return e ? std::atof(e) * 1048576.0 : -1.0; }();
-        const double room = 0.8 * (room_override >= 0 ? room_override : (double)exec::memory_available());      // (override: tests)
-        while (batch.S > 1 && per_lane * batch.S * P > room) batch.S = (batch.S + 1) / 2;
+        if (room_override >= 0 || per_lane * batch.S * P > 1073741824.0) {        // small frames: not worth asking the driver
+            const double room = 0.8 * (room_override >= 0 ? room_override : (double)exec::memory_available());      // (override: tests)
+            while (batch.S > 1 && per_lane * batch.S * P > room) batch.S = (batch.S + 1) / 2;
+        }
         batch.on = batch.S > 1;
     }
     const int S = batch.S;
