@@ -253,3 +253,47 @@ def test_gradient_buffer_shared_by_two_entries_hostsim(hostsim_backend):
 @pytest.mark.gpu
 def test_gradient_buffer_shared_by_two_entries_gpu(gpu_backend):
     _shared_gradient_buffer(gpu_backend, torch.device('cuda:0'))
+
+
+def _many_patches(device):
+    """Twelve 45 x 45-vertex patches: 72 900 doubles of vertex gradients in tensors of 6 075 each -- more than the small tier
+    of the gradient store holds (render.cpp: GradStore, 65 536 doubles), so the last patches' accumulators live in the
+    large tier and the flush has segments in both."""
+    n = 45
+    u = np.linspace(0.0, 1.0, n, dtype=np.float32)
+    gx, gy = np.meshgrid(u, u, indexing='xy')
+    idx = []
+    for j in range(n - 1):
+        for i in range(n - 1):
+            a = j * n + i
+            idx += [[a, a + n, a + 1], [a + 1, a + n, a + n + 1]]
+    idx = np.asarray(idx, np.int32)
+    shapes = []
+    for k in range(12):
+        ox, oy = -2.0 + (k % 4), -1.5 + (k // 4)
+        z = 0.15 * np.sin(3.0 * gx + k) * np.cos(2.0 * gy) + 0.05 * k
+        v = np.stack([ox + gx, oy + gy, z], axis=2).reshape(-1, 3).astype(np.float32)
+        shapes.append(scenes.Shape(torch.tensor(v, device=device, requires_grad=True), torch.tensor(idx, device=device), 0))
+    light = scenes.Shape(torch.tensor([[-1.0, -1.0, -7.0], [1.0, -1.0, -7.0], [-1.0, 1.0, -7.0], [1.0, 1.0, -7.0]], device=device),
+                         torch.tensor([[0, 1, 2], [1, 3, 2]], dtype=torch.int32, device=device), 1)
+    cam = Camera(position=torch.tensor([0.0, 0.0, -5.0]), look_at=torch.tensor([0.0, 0.0, 0.0]), up=torch.tensor([0.0, 1.0, 0.0]),
+                 fov=torch.tensor([45.0]), clip_near=1e-2, resolution=(32, 32))
+    mats = [scenes.Material(diffuse_reflectance=torch.tensor([0.5, 0.55, 0.45], device=device)),
+            scenes.Material(diffuse_reflectance=torch.tensor([0.0, 0.0, 0.0], device=device))]
+    return Scene(cam, shapes + [light], mats, [scenes.AreaLight(12, torch.tensor([20.0, 20.0, 20.0]))])
+
+
+def test_gradient_store_spills_into_the_large_tier_hostsim(hostsim_backend):
+    if not oracle_util.oracle_available():
+        pytest.skip('oracle not built')
+    img, grads = _run(hostsim_backend, torch.device('cpu'), _many_patches(torch.device('cpu')), spp=2, mb=1)
+    ref_img, ref_grads = _run(oracle_util.load_oracle(), torch.device('cpu'), _many_patches(torch.device('cpu')), spp=2, mb=1)
+    assert np.array_equal(img, ref_img)
+    seen = 0
+    for g, r in zip(grads, ref_grads):
+        if r is None:
+            continue
+        n = np.linalg.norm(r)
+        seen += n > 0
+        assert np.linalg.norm(g - r) <= 1e-4 * n + 1e-12
+    assert seen >= 10            # patches of both tiers received gradients
