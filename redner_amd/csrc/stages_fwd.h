@@ -167,7 +167,9 @@ struct GenPrimary {
 RDR_FN V3 direct_emission(const SceneD &sc, int shape, int tri, const Ray &ray, const RayDiff &rd) {
     V3 e = v3(0);
     if (shape < 0) {
-        if (sc.envmap != nullptr && sc.envmap->directly_visible) e = envmap_eval(*sc.envmap, ray.dir, rd);
+        // a ray without a direction (a fisheye pixel outside the image circle) is not an active pixel in the reference
+        // (src/active_pixels.cpp:8-28: init_active_pixels drops it before anything is accumulated): it sees nothing
+        if (sc.envmap != nullptr && sc.envmap->directly_visible && len_sq(ray.dir) > 0) e = envmap_eval(*sc.envmap, ray.dir, rd);
         return e;
     }
     const ShapeD &sh = sc.shapes[shape];
