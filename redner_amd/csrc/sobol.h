@@ -181,8 +181,14 @@ struct ResolveBatchImage {
         const int pixel = i / nd, c = i - pixel * nd;
         float acc = image[i];
         if (assign && assign[c]) {
-            for (int s = 0; s < samples; ++s)
-                if (first_shape[(size_t)s * pixels + pixel] >= 0) acc = stage[((size_t)s * pixels + pixel) * nd + c];
+            // ... and what later launches of the same sample ADD to such a component stays on top of it: with the radiance
+            // channel listed after them, the reference's bounce contributions land on the component whose index equals the
+            // radiance channel's position in the list (src/channels.cpp:27), which may be an id
+            for (int s = 0; s < samples; ++s) {
+                const size_t at = ((size_t)s * pixels + pixel) * nd + c;
+                if (first_shape[(size_t)s * pixels + pixel] >= 0) acc = stage[at];
+                for (int k = 1; k < planes; ++k) acc += stage[(size_t)k * plane_stride + at];
+            }
         } else {
             for (int s = 0; s < samples; ++s)
                 for (int k = 0; k < planes; ++k)

@@ -114,6 +114,10 @@ CASES = {
     'misc_features_viewport_40x56x4': ('misc_features_viewport', (40, 56), 4, 2, None, {'sample_pixel_center': True}),
     # radiance after a 3-wide channel: the reference adds path contributions at the channel INDEX (src/channels.cpp:27)
     'textured_sphere_radiance_last_48x48x2': ('textured_sphere', 48, 2, 2, ['position', 'radiance']),
+    # ... and after id channels: the bounce contributions land ON the ids (triangle / material id + what the last sample's paths
+    # carried), which a batched forward render has to reproduce on top of its assigned ids
+    'textured_sphere_ids_radiance_last_48x48x3': ('textured_sphere', 48, 3, 2,
+                                                  ['alpha', 'position', 'shape_id', 'triangle_id', 'material_id', 'radiance']),
     'textured_sphere_generic_48x48x4': ('textured_sphere', 48, 4, 1,
                                         ['radiance', 'barycentric_coordinates', 'generic_texture'],
                                         {'use_primary_edge_sampling': False, 'use_secondary_edge_sampling': False}),

@@ -219,6 +219,119 @@ def _render_rich(backend, seed, spp, mb, pixel_center, stripe=None):
     return out
 
 
+def _mesh(rng, kind, centre, size):
+    """Closed or open meshes with SHARED vertices (silhouette / dihedral logic of the edge list, src/edge.cpp:233-383)."""
+    if kind == 0:          # tetrahedron
+        v = np.array([[1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1]], np.float64)
+        f = [[0, 1, 2], [0, 3, 1], [0, 2, 3], [1, 3, 2]]
+    elif kind == 1:        # cube
+        v = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float64)
+        f = [[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1], [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]]
+    else:                  # 4 x 4 height field
+        n = 4
+        g = np.linspace(-1, 1, n)
+        v = np.array([[x, y, 0.3 * rng.uniform(-1, 1)] for y in g for x in g], np.float64)
+        f = []
+        for j in range(n - 1):
+            for i in range(n - 1):
+                a = j * n + i
+                f += [[a, a + n, a + 1], [a + 1, a + n, a + n + 1]]
+    # a random rotation
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return (centre + size * (v @ R.T)).astype(np.float32), np.asarray(f, np.int32)
+
+
+def _scene_mesh(seed, device):
+    rng = np.random.RandomState(5000 + seed)
+    mats, shapes = [], []
+    for k in range(3):
+        glossy = rng.rand() < 0.4
+        gen = None
+        if rng.rand() < 0.4:
+            gen = Texture([l.to(device).requires_grad_(True) for l in
+                           scenes._mip_chain(torch.tensor(rng.uniform(0, 1, (4, 4, 5)).astype(np.float32)))])
+        nmap = None
+        if rng.rand() < 0.3:
+            nm = rng.uniform(-0.3, 0.3, (4, 4, 3)); nm[:, :, 2] = 1.0
+            nm = 0.5 + 0.5 * nm / np.linalg.norm(nm, axis=2, keepdims=True)
+            nmap = Texture([l.to(device) for l in scenes._mip_chain(torch.tensor(nm.astype(np.float32)))])
+        mats.append(Material(
+            diffuse_reflectance=torch.tensor(rng.uniform(0.1, 0.8, 3).astype(np.float32), device=device, requires_grad=True),
+            specular_reflectance=torch.tensor((rng.uniform(0.05, 0.5, 3) if glossy else np.zeros(3)).astype(np.float32), device=device),
+            roughness=torch.tensor([float(rng.uniform(0.05, 0.6)) if glossy else 1.0], device=device),
+            generic_texture=gen, normal_map=nmap, two_sided=bool(rng.rand() < 0.3), use_vertex_color=bool(rng.rand() < 0.3)))
+    mats.append(Material(diffuse_reflectance=torch.zeros(3, device=device)))
+    for k in range(int(rng.randint(2, 5))):
+        v, f = _mesh(rng, int(rng.randint(0, 3)), rng.uniform([-1.6, -1.6, -0.3], [1.6, 1.6, 1.8]), float(rng.uniform(0.4, 0.9)))
+        uv = torch.tensor(rng.uniform(0, 1, (len(v), 2)).astype(np.float32), device=device, requires_grad=True)
+        col = torch.tensor(rng.uniform(0.1, 0.9, (len(v), 3)).astype(np.float32), device=device, requires_grad=True)
+        shapes.append(Shape(torch.tensor(v, device=device, requires_grad=True), torch.tensor(f, device=device), int(rng.randint(0, 3)),
+                            uvs=uv, colors=col))
+    c = rng.uniform([-2.0, -2.0, -7.0], [2.0, 2.0, -5.5])
+    lv = np.array([[c[0] - 0.8, c[1] - 0.8, c[2]], [c[0] + 0.8, c[1] - 0.8, c[2]], [c[0] - 0.8, c[1] + 0.8, c[2]], [c[0] + 0.8, c[1] + 0.8, c[2]]],
+                  np.float32)
+    shapes.append(Shape(torch.tensor(lv, device=device), torch.tensor([[0, 1, 2], [1, 3, 2]], dtype=torch.int32, device=device), 3))
+    lights = [AreaLight(len(shapes) - 1, torch.tensor(rng.uniform(5.0, 25.0, 3).astype(np.float32), requires_grad=True),
+                        two_sided=bool(rng.rand() < 0.3), directly_visible=bool(rng.rand() < 0.8))]
+    dist = None
+    if rng.rand() < 0.3:
+        dist = torch.tensor(rng.uniform(-0.05, 0.05, 8).astype(np.float32), requires_grad=True)
+    cam = Camera(position=torch.tensor((np.array([0.0, 0.0, -5.0]) + rng.uniform(-0.5, 0.5, 3)).astype(np.float32), requires_grad=True),
+                 look_at=torch.tensor(rng.uniform(-0.3, 0.3, 3).astype(np.float32), requires_grad=True),
+                 up=torch.tensor([0.0, 1.0, 0.0], requires_grad=True), fov=torch.tensor([float(rng.uniform(35.0, 60.0))]),
+                 clip_near=1e-2, resolution=(22, 20), distortion_params=dist)
+    return Scene(cam, shapes, mats, lights)
+
+
+MESH_CHANNELS = ['radiance', 'alpha', 'depth', 'position', 'geometry_normal', 'shading_normal', 'uv', 'diffuse_reflectance',
+                 'specular_reflectance', 'roughness', 'vertex_color', 'shape_id', 'triangle_id', 'material_id']
+
+
+def _render_mesh(backend, seed, spp, mb, stripe=None):
+    dev = torch.device('cpu')
+    sc = _scene_mesh(seed, dev)
+    rng = np.random.RandomState(9000 + seed)
+    names = ['radiance'] + [c for c in MESH_CHANNELS[1:] if rng.rand() < 0.35] if seed % 2 else ['radiance']
+    if rng.rand() < 0.3:
+        names = names[1:] + names[:1]                 # radiance last
+    ch = [getattr(backend.channels, c) for c in names]
+    args = RenderFunction.serialize_scene(sc, spp, mb, channels=ch, sampler_type=backend.SamplerType.sobol, device=dev, backend=backend)
+    img = RenderFunction.apply(seed, *args)
+    h, w, c = img.shape
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    base = [1.0 + 0.5 * torch.sin(0.4 * xx + 0.2 * yy), 1.0 + 0.5 * torch.cos(0.3 * yy), 1.0 - 0.3 * torch.sin(0.2 * (xx + yy))]
+    up = torch.stack([base[k % 3] * (1.0 + 0.1 * (k // 3)) for k in range(c)], 2)
+    if stripe is not None:
+        keep = torch.zeros(h * w)
+        keep[stripe[0]::stripe[1]] = 1
+        up = up * keep.reshape(h, w, 1)
+    (img * up).sum().backward()
+    out = {'image': img.detach().numpy()}
+    for i, s in enumerate(sc.shapes):
+        for n in ('vertices', 'uvs', 'colors'):
+            t = getattr(s, n)
+            if t is not None and t.grad is not None:
+                out['shape%d_%s' % (i, n)] = t.grad.numpy()
+    for i, m in enumerate(sc.materials):
+        for n, t in (('diffuse', m.diffuse_reflectance), ('generic', m.generic_texture)):
+            if t is None:
+                continue
+            for lv, l in enumerate(t.mipmap):
+                if l.grad is not None:
+                    out['mat%d_%s_L%d' % (i, n, lv)] = l.grad.numpy()
+    out['light0'] = sc.area_lights[0].intensity.grad.numpy()
+    for n in ('position', 'look_at', 'up', 'distortion_params'):
+        t = getattr(sc.camera, n)
+        if t is not None and t.grad is not None:
+            out['cam_' + n] = t.grad.numpy()
+    return out
+
+
+MESH_SEEDS = range(1, 121)
 PLAIN_SEEDS, RICH_SEEDS = range(1, 201), range(1, 161)
 
 
@@ -242,6 +355,12 @@ def _main(hostsim_lib):
         bad = _compare(mine, ref, lambda st: _render_rich(oracle, seed, spp, mb, pc, st))
         if bad:
             failures['rich %d' % seed] = bad
+    for seed in MESH_SEEDS:
+        spp, mb = 2 + seed % 3, seed % 4
+        ref, mine = _render_mesh(oracle, seed, spp, mb), _render_mesh(redner, seed, spp, mb)
+        bad = _compare(mine, ref, lambda st: _render_mesh(oracle, seed, spp, mb, st))
+        if bad:
+            failures['mesh %d' % seed] = bad
     print('FUZZ ' + json.dumps(failures))
 
 

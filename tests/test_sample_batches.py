@@ -20,6 +20,7 @@ CASES = ('bunny_box_32x32x4', 'two_triangles_64x64x16', 'bunny_box_96x96x8', 'tw
          'two_triangles_distorted_64x64x4', 'misc_features_40x56x4', 'misc_features_viewport_40x56x4',
          # mip-mapped textures / environment light: the forward render is batched, the gradient render is not
          'textured_sphere_gbuffer_48x48x4', 'envmap_sphere_48x48x4', 'living_room_standin_40x40x2',
+         'textured_sphere_ids_radiance_last_48x48x3',
          # ... unless both edge estimators are off: then it is
          'living_room_standin_envmap_noedges_32x32x4', 'envmap_sphere_noedges_48x48x4', 'misc_features_noedges_40x56x4')
 
