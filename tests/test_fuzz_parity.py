@@ -332,6 +332,69 @@ def _render_mesh(backend, seed, spp, mb, stripe=None):
 
 
 MESH_SEEDS = range(1, 121)
+def _scene_odd(seed, device):
+    """Corners of the interface: triangles that cross the camera's near plane or lie behind it, a viewport on a perspective
+    camera, lights that are not directly visible, a rotated environment map that may be invisible to the camera."""
+    rng = np.random.RandomState(7000 + seed)
+    sc = _scene(seed, device)
+    # a big triangle through the camera plane (z of the camera is about -5)
+    v = np.array([[rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(0.0, 1.0)],
+                  [rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(-1.0, 1.0)],
+                  [rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-6.5, -4.0)]], np.float32)
+    shapes = list(sc.shapes)
+    shapes.insert(3, Shape(torch.tensor(v, device=device, requires_grad=True), torch.tensor([[0, 1, 2]], dtype=torch.int32, device=device),
+                           int(rng.randint(0, 3))))
+    lights = []
+    for l in sc.area_lights:
+        lights.append(AreaLight(l.shape_id + 1, l.intensity, two_sided=l.two_sided, directly_visible=bool(rng.rand() < 0.5)))
+    env = None
+    if rng.rand() < 0.5:
+        img = torch.tensor(rng.uniform(0.05, 1.0, (4, 8, 3)).astype(np.float32))
+        ang = rng.uniform(0, 2 * np.pi)
+        e2w = torch.tensor([[np.cos(ang), 0, np.sin(ang), 0], [0, 1, 0, 0], [-np.sin(ang), 0, np.cos(ang), 0], [0, 0, 0, 1]], dtype=torch.float32)
+        env = EnvironmentMap(Texture([l.to(device).requires_grad_(True) for l in scenes._mip_chain(img)]), env_to_world=e2w,
+                             directly_visible=bool(rng.rand() < 0.6))
+    cam = sc.camera
+    vp = (3, 2, 19, 20) if rng.rand() < 0.5 else None
+    cam = Camera(position=cam.position, look_at=cam.look_at, up=cam.up, intrinsic_mat=cam.intrinsic_mat, clip_near=float(rng.choice([1e-2, 0.5, 2.0])),
+                 resolution=cam.resolution, viewport=vp)
+    return Scene(cam, shapes, sc.materials, lights, envmap=env)
+
+
+def _render_odd(backend, seed, spp, mb, stripe=None):
+    dev = torch.device('cpu')
+    sc = _scene_odd(seed, dev)
+    sampler = backend.SamplerType.independent if seed % 3 == 0 else backend.SamplerType.sobol
+    args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=sampler, device=dev, backend=backend)
+    img = RenderFunction.apply(seed, *args)
+    h, w, _ = img.shape
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    up = torch.stack([1.0 + 0.5 * torch.sin(0.4 * xx + 0.2 * yy), 1.0 + 0.5 * torch.cos(0.3 * yy), 1.0 - 0.3 * torch.sin(0.2 * (xx + yy))], 2)
+    if stripe is not None:
+        keep = torch.zeros(h * w)
+        keep[stripe[0]::stripe[1]] = 1
+        up = up * keep.reshape(h, w, 1)
+    (img * up).sum().backward()
+    out = {'image': img.detach().numpy()}
+    for i, s in enumerate(sc.shapes):
+        if s.vertices.grad is not None:
+            out['shape%d' % i] = s.vertices.grad.numpy()
+    for i, m in enumerate(sc.materials):
+        t = m.diffuse_reflectance.mipmap[0]
+        if t.grad is not None:
+            out['mat%d_diffuse' % i] = t.grad.numpy()
+    for i, l in enumerate(sc.area_lights):
+        out['light%d' % i] = l.intensity.grad.numpy()
+    if sc.envmap is not None:
+        for lv, l in enumerate(sc.envmap.values.mipmap):
+            if l.grad is not None:
+                out['envmap_L%d' % lv] = l.grad.numpy()
+    for n in ('position', 'look_at', 'up'):
+        out['cam_' + n] = getattr(sc.camera, n).grad.numpy()
+    return out
+
+
+ODD_SEEDS = range(1, 121)
 PLAIN_SEEDS, RICH_SEEDS = range(1, 201), range(1, 161)
 
 
@@ -361,6 +424,26 @@ def _main(hostsim_lib):
         bad = _compare(mine, ref, lambda st: _render_mesh(oracle, seed, spp, mb, st))
         if bad:
             failures['mesh %d' % seed] = bad
+    for seed in ODD_SEEDS:
+        spp, mb = 1 + seed % 6, seed % 7
+        ref, mine = _render_odd(oracle, seed, spp, mb), _render_odd(redner, seed, spp, mb)
+        bad = _compare(mine, ref, lambda st: _render_odd(oracle, seed, spp, mb, st))
+        if bad:
+            failures['odd %d' % seed] = bad
+    # screen-space gradient images (RenderFunction.visualize_screen_gradient, tests/test_screen_gradient.py)
+    for seed in range(1, 41):
+        kw = dict(num_samples=2 + seed % 3, max_bounces=seed % 3, device=torch.device('cpu'),
+                  sampler_type=(oracle.SamplerType.independent if seed % 2 else oracle.SamplerType.sobol))
+        imgs = []
+        for backend in (oracle, redner):
+            kw['sampler_type'] = backend.SamplerType.independent if seed % 2 else backend.SamplerType.sobol
+            sc = _scene_mesh(seed, torch.device('cpu')) if seed % 4 == 0 else _scene(seed, torch.device('cpu'))
+            ch = [backend.channels.radiance] if seed % 3 else [backend.channels.diffuse_reflectance]
+            imgs.append(RenderFunction.visualize_screen_gradient(None, seed, sc, channels=ch, backend=backend, **kw).numpy())
+        n = np.linalg.norm(imgs[0].astype(np.float64))
+        d = np.linalg.norm(imgs[1].astype(np.float64) - imgs[0].astype(np.float64))
+        if not d <= 1e-4 * n + 1e-9:
+            failures['screen gradient %d' % seed] = '%.3e' % (d / max(n, 1e-300))
     print('FUZZ ' + json.dumps(failures))
 
 
