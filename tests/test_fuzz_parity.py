@@ -430,6 +430,35 @@ def _main(hostsim_lib):
         bad = _compare(mine, ref, lambda st: _render_odd(oracle, seed, spp, mb, st))
         if bad:
             failures['odd %d' % seed] = bad
+    # an optimisation loop: the same connectivity with moved vertices (hierarchies refitted, edge structures rebuilt), then only
+    # materials / lights changed (edge structures shared with the previous Scene), then the camera moved -- every step against
+    # the oracle, which builds everything from scratch each time
+    for seed in range(1, 21):
+        for step in range(6):
+            outs = []
+            for backend in (oracle, redner):
+                sc = _scene_mesh(seed, torch.device('cpu'))
+                rng = np.random.RandomState(100 * seed + step)
+                with torch.no_grad():
+                    if step in (1, 2, 5):
+                        for sh in sc.shapes[:-1]:
+                            sh.vertices += torch.tensor(rng.normal(0, 0.03 * step, tuple(sh.vertices.shape)).astype(np.float32))
+                    if step in (3, 5):
+                        for m in sc.materials[:3]:
+                            m.diffuse_reflectance.mipmap[0].mul_(float(rng.uniform(0.5, 1.2)))
+                        sc.area_lights[0].intensity.mul_(float(rng.uniform(0.5, 1.5)))
+                    if step in (4, 5):
+                        sc.camera.position += torch.tensor(rng.normal(0, 0.1, 3).astype(np.float32))
+                args = RenderFunction.serialize_scene(sc, 2, 2, sampler_type=backend.SamplerType.sobol, device=torch.device('cpu'), backend=backend)
+                img = RenderFunction.apply(seed, *args)
+                img.sum().backward()
+                o = {'image': img.detach().numpy(), 'cam_position': sc.camera.position.grad.numpy(), 'light0': sc.area_lights[0].intensity.grad.numpy()}
+                for i, sh in enumerate(sc.shapes[:-1]):
+                    o['shape%d' % i] = sh.vertices.grad.numpy()
+                outs.append(o)
+            bad = _distance(outs[1], outs[0])
+            if bad:
+                failures['loop %d step %d' % (seed, step)] = bad
     # screen-space gradient images (RenderFunction.visualize_screen_gradient, tests/test_screen_gradient.py)
     for seed in range(1, 41):
         kw = dict(num_samples=2 + seed % 3, max_bounces=seed % 3, device=torch.device('cpu'),
