@@ -395,6 +395,67 @@ def _render_odd(backend, seed, spp, mb, stripe=None):
 
 
 ODD_SEEDS = range(1, 121)
+def _blob(rng, subdiv):
+    """A deformed icosphere with shared vertices (hundreds of silhouette / crease candidates for the edge hierarchies)."""
+    t = (1 + 5 ** 0.5) / 2
+    v = [[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t], [0, -1, -t], [0, 1, -t], [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]]
+    f = [[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9], [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8],
+         [3, 9, 4], [3, 4, 2], [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10], [8, 6, 7], [9, 8, 1]]
+    v = [np.array(x, np.float64) / np.linalg.norm(x) for x in v]
+    for _ in range(subdiv):
+        mid, nf = {}, []
+        def m(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in mid:
+                p = v[a] + v[b]
+                v.append(p / np.linalg.norm(p))
+                mid[k] = len(v) - 1
+            return mid[k]
+        for a, b, c in f:
+            ab, bc, ca = m(a, b), m(b, c), m(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        f = nf
+    v = np.asarray(v)
+    k = rng.uniform(1.0, 3.0, 3)
+    r = 1.0 + 0.25 * np.sin(k[0] * v[:, 0] * 3) * np.cos(k[1] * v[:, 1] * 3) + 0.1 * np.sin(k[2] * v[:, 2] * 5)
+    return (v * r[:, None]).astype(np.float32), np.asarray(f, np.int32)
+
+
+def _render_blob(backend, seed, stripe=None):
+    dev = torch.device('cpu')
+    rng = np.random.RandomState(3000 + seed)
+    v, f = _blob(rng, 1 + seed % 2)
+    v = v * float(rng.uniform(0.8, 1.2)) + rng.uniform(-0.3, 0.3, 3).astype(np.float32)
+    glossy = seed % 2 == 0
+    mats = [Material(diffuse_reflectance=torch.tensor(rng.uniform(0.2, 0.8, 3).astype(np.float32), requires_grad=True),
+                     specular_reflectance=torch.tensor((rng.uniform(0.1, 0.4, 3) if glossy else np.zeros(3)).astype(np.float32)),
+                     roughness=torch.tensor([float(rng.uniform(0.1, 0.5)) if glossy else 1.0])),
+            Material(diffuse_reflectance=torch.tensor([0.5, 0.5, 0.5], requires_grad=True)),
+            Material(diffuse_reflectance=torch.zeros(3))]
+    blob = Shape(torch.tensor(v, requires_grad=True), torch.tensor(f), 0)
+    floor = Shape(torch.tensor([[-3.0, -1.6, -3.0], [3.0, -1.6, -3.0], [-3.0, -1.6, 3.0], [3.0, -1.6, 3.0]], requires_grad=True),
+                  torch.tensor([[0, 2, 1], [1, 2, 3]], dtype=torch.int32), 1)
+    c = rng.uniform([-2.0, 2.5, -3.0], [2.0, 4.0, 0.0])
+    light = Shape(torch.tensor([[c[0] - 1, c[1], c[2] - 1], [c[0] + 1, c[1], c[2] - 1], [c[0] - 1, c[1], c[2] + 1], [c[0] + 1, c[1], c[2] + 1]],
+                               dtype=torch.float32), torch.tensor([[0, 1, 2], [1, 3, 2]], dtype=torch.int32), 2)
+    cam = Camera(position=torch.tensor([0.0, 0.8, -5.0], requires_grad=True), look_at=torch.tensor([0.0, 0.0, 0.0]),
+                 up=torch.tensor([0.0, 1.0, 0.0]), fov=torch.tensor([45.0]), clip_near=1e-2, resolution=(32, 32))
+    sc = Scene(cam, [blob, floor, light], mats, [AreaLight(2, torch.tensor([25.0, 25.0, 25.0], requires_grad=True), two_sided=True)])
+    args = RenderFunction.serialize_scene(sc, 2, 2 + seed % 2, sampler_type=backend.SamplerType.sobol, device=dev, backend=backend)
+    img = RenderFunction.apply(seed, *args)
+    h, w, _ = img.shape
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
+    up = torch.stack([1.0 + 0.5 * torch.sin(0.4 * xx + 0.2 * yy), 1.0 + 0.5 * torch.cos(0.3 * yy), 1.0 - 0.3 * torch.sin(0.2 * (xx + yy))], 2)
+    if stripe is not None:
+        keep = torch.zeros(h * w)
+        keep[stripe[0]::stripe[1]] = 1
+        up = up * keep.reshape(h, w, 1)
+    (img * up).sum().backward()
+    return {'image': img.detach().numpy(), 'blob': blob.vertices.grad.numpy(), 'floor': floor.vertices.grad.numpy(),
+            'mat0': mats[0].diffuse_reflectance.mipmap[0].grad.numpy(), 'mat1': mats[1].diffuse_reflectance.mipmap[0].grad.numpy(),
+            'light0': sc.area_lights[0].intensity.grad.numpy(), 'cam_position': cam.position.grad.numpy()}
+
+
 PLAIN_SEEDS, RICH_SEEDS = range(1, 201), range(1, 161)
 
 
@@ -430,6 +491,11 @@ def _main(hostsim_lib):
         bad = _compare(mine, ref, lambda st: _render_odd(oracle, seed, spp, mb, st))
         if bad:
             failures['odd %d' % seed] = bad
+    for seed in range(1, 25):                     # 80- and 320-triangle blobs above a floor
+        ref, mine = _render_blob(oracle, seed), _render_blob(redner, seed)
+        bad = _compare(mine, ref, lambda st: _render_blob(oracle, seed, st))
+        if bad:
+            failures['blob %d' % seed] = bad
     # an optimisation loop: the same connectivity with moved vertices (hierarchies refitted, edge structures rebuilt), then only
     # materials / lights changed (edge structures shared with the previous Scene), then the camera moved -- every step against
     # the oracle, which builds everything from scratch each time
