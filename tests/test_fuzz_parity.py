@@ -331,7 +331,7 @@ def _render_mesh(backend, seed, spp, mb, stripe=None):
     return out
 
 
-MESH_SEEDS = range(1, 121)
+MESH_SEEDS = range(1, 121, int(os.environ.get('FUZZ_STRIDE', '1')))
 def _scene_odd(seed, device):
     """Corners of the interface: triangles that cross the camera's near plane or lie behind it, a viewport on a perspective
     camera, lights that are not directly visible, a rotated environment map that may be invisible to the camera."""
@@ -394,7 +394,7 @@ def _render_odd(backend, seed, spp, mb, stripe=None):
     return out
 
 
-ODD_SEEDS = range(1, 121)
+ODD_SEEDS = range(1, 121, int(os.environ.get('FUZZ_STRIDE', '1')))
 def _blob(rng, subdiv):
     """A deformed icosphere with shared vertices (hundreds of silhouette / crease candidates for the edge hierarchies)."""
     t = (1 + 5 ** 0.5) / 2
@@ -456,7 +456,8 @@ def _render_blob(backend, seed, stripe=None):
             'light0': sc.area_lights[0].intensity.grad.numpy(), 'cam_position': cam.position.grad.numpy()}
 
 
-PLAIN_SEEDS, RICH_SEEDS = range(1, 201), range(1, 161)
+STRIDE = int(os.environ.get('FUZZ_STRIDE', '1'))       # the variant runs below take every third scene
+PLAIN_SEEDS, RICH_SEEDS = range(1, 201, STRIDE), range(1, 161, STRIDE)
 
 
 def _main(hostsim_lib):
@@ -491,7 +492,7 @@ def _main(hostsim_lib):
         bad = _compare(mine, ref, lambda st: _render_odd(oracle, seed, spp, mb, st))
         if bad:
             failures['odd %d' % seed] = bad
-    for seed in range(1, 25):                     # 80- and 320-triangle blobs above a floor
+    for seed in range(1, 25, STRIDE):             # 80- and 320-triangle blobs above a floor
         ref, mine = _render_blob(oracle, seed), _render_blob(redner, seed)
         bad = _compare(mine, ref, lambda st: _render_blob(oracle, seed, st))
         if bad:
@@ -499,7 +500,7 @@ def _main(hostsim_lib):
     # an optimisation loop: the same connectivity with moved vertices (hierarchies refitted, edge structures rebuilt), then only
     # materials / lights changed (edge structures shared with the previous Scene), then the camera moved -- every step against
     # the oracle, which builds everything from scratch each time
-    for seed in range(1, 21):
+    for seed in range(1, 21, STRIDE):
         for step in range(6):
             outs = []
             for backend in (oracle, redner):
@@ -526,7 +527,7 @@ def _main(hostsim_lib):
             if bad:
                 failures['loop %d step %d' % (seed, step)] = bad
     # screen-space gradient images (RenderFunction.visualize_screen_gradient, tests/test_screen_gradient.py)
-    for seed in range(1, 41):
+    for seed in range(1, 41, STRIDE):
         kw = dict(num_samples=2 + seed % 3, max_bounces=seed % 3, device=torch.device('cpu'),
                   sampler_type=(oracle.SamplerType.independent if seed % 2 else oracle.SamplerType.sobol))
         imgs = []
@@ -542,12 +543,17 @@ def _main(hostsim_lib):
     print('FUZZ ' + json.dumps(failures))
 
 
-def test_random_scenes_hostsim_vs_oracle(hostsim_backend):
+# the default schedule (sample batches, specialised stage kernels), one sample per launch, no stage specialisation
+@pytest.mark.parametrize('variant', ['', 'RDR_BATCH=1 FUZZ_STRIDE=3', 'RDR_FORCE_GENERAL=1 FUZZ_STRIDE=3'])
+def test_random_scenes_hostsim_vs_oracle(hostsim_backend, variant):
     from conftest import HOSTSIM_LIB
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MALLOC_MMAP_THRESHOLD_='1024',
                PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get('PYTHONPATH', '')]))
-    out = subprocess.check_output([sys.executable, os.path.abspath(__file__), HOSTSIM_LIB], env=env, timeout=900).decode()
+    for k in ('RDR_BATCH', 'RDR_FORCE_GENERAL', 'FUZZ_STRIDE'):
+        env.pop(k, None)
+    env.update(dict(kv.split('=') for kv in variant.split()))
+    out = subprocess.check_output([sys.executable, os.path.abspath(__file__), HOSTSIM_LIB], env=env, timeout=1500).decode()
     line = [l for l in out.splitlines() if l.startswith('FUZZ ')][-1]
     assert json.loads(line[5:]) == {}
 
