@@ -513,9 +513,11 @@ struct Backward {
         // see trace_edge_paths)
         int edim = 0;
         if (edge_dyn) exec::zero(edge_dyn, sizeof(int) * kMaxBatch);
-        exec::zero(adj.thr, sizeof(double) * 3 * P);
-        exec::zero(adj.ray_dir, sizeof(double) * 3 * P);
-        exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * P);
+        // (the whole buffers: they are component-major with the buffers' lane count as the stride, so the first 3 x n_lanes
+        //  doubles of a batch that is smaller than the buffers -- the last one of a call -- are not its lanes' records)
+        exec::zero(adj.thr, sizeof(double) * 3 * stride);
+        exec::zero(adj.ray_dir, sizeof(double) * 3 * stride);
+        exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * stride);
         const int dim0 = opt.sample_pixel_center ? 0 : 2;
         static const bool pickh_fused = std::getenv("RDR_PICKH_FUSED") != nullptr;     // A/B: the one-loop form
         static const bool pickh_lazy = std::getenv("RDR_PICKH_LAZY") != nullptr;       // A/B: per-field node loads

@@ -5,7 +5,8 @@ advance only for samples whose lists are not empty, :432-436, 590-706; the order
 launches' contributions, :283,378) is kept per sample, so a batched render must equal the one-sample-at-a-time render:
 the image bit for bit, the gradients bit for bit on the sequential CPU harness and to the order of fp64 atomics on the GPU.
 RDR_BATCH=1 switches batching off (read once per process, hence the subprocesses).  A third run pretends that the device has
-100 MB left (RDR_MEM_AVAILABLE_MB): the batches shrink to what fits (render.cpp) and nothing else changes."""
+100 MB left (RDR_MEM_AVAILABLE_MB): the batches shrink to what fits (render.cpp) and nothing else changes; a fourth caps the
+batches at three samples, so that a call is several batches and its last one is smaller than the buffers were made for."""
 import os
 import subprocess
 import sys
@@ -44,10 +45,11 @@ np.savez(sys.argv[1], **out)
 def _both(tmp_path, lib, dev):
     code = CODE % {'root': ROOT, 'lib': lib, 'dev': dev, 'cases': CASES}
     paths = []
-    for tag, env in (('one', {'RDR_BATCH': '1'}), ('batched', {}), ('tight', {'RDR_MEM_AVAILABLE_MB': '100'})):
+    for tag, env in (('one', {'RDR_BATCH': '1'}), ('batched', {}), ('tight', {'RDR_MEM_AVAILABLE_MB': '100'}),
+                     ('ragged', {'RDR_BATCH': '3'})):
         p = str(tmp_path / (tag + '.npz'))
         e = dict(os.environ, **env)
-        if tag != 'one':
+        if tag not in ('one', 'ragged'):
             e.pop('RDR_BATCH', None)
         if tag != 'tight':
             e.pop('RDR_MEM_AVAILABLE_MB', None)
@@ -58,17 +60,18 @@ def _both(tmp_path, lib, dev):
 
 def test_batches_equal_single_samples_hostsim(hostsim_backend, tmp_path):
     from conftest import HOSTSIM_LIB
-    one, batched, tight = _both(tmp_path, HOSTSIM_LIB, 'cpu')
+    one, batched, tight, ragged = _both(tmp_path, HOSTSIM_LIB, 'cpu')
     for k in one.files:
         assert np.array_equal(one[k], batched[k]), k           # sequential harness: every tensor bit for bit
         assert np.array_equal(one[k], tight[k]), k
+        assert np.array_equal(one[k], ragged[k]), k
 
 
 @pytest.mark.gpu
 def test_batches_equal_single_samples_gpu(gpu_backend, tmp_path):
     from redner_amd import _capi
-    one, batched, tight = _both(tmp_path, _capi.library_path(), 'cuda:0')
-    for other in (batched, tight):
+    one, batched, tight, ragged = _both(tmp_path, _capi.library_path(), 'cuda:0')
+    for other in (batched, tight, ragged):
         for k in one.files:
             if k.endswith('/image'):
                 assert np.array_equal(one[k], other[k]), k     # the image: fp32 sums in the reference's order
