@@ -546,13 +546,17 @@ def _main(hostsim_lib):
 # the default schedule (sample batches, specialised stage kernels), one sample per launch, no stage specialisation, ragged
 # batches (3 samples, then what is left), several batches per call (2 samples each under the lane cap)
 @pytest.mark.parametrize('variant', ['', 'RDR_BATCH=1 FUZZ_STRIDE=3', 'RDR_FORCE_GENERAL=1 FUZZ_STRIDE=3', 'RDR_BATCH=3 FUZZ_STRIDE=3',
-                                     'RDR_BATCH_LANES=1000 FUZZ_STRIDE=3'])
+                                     'RDR_BATCH_LANES=1000 FUZZ_STRIDE=3',
+                                     # the gather's hand-over paths (tiny budgets / list capacities); caches and refits off
+                                     'RDR_GATHER_BUDGET=2 RDR_GATHER_CAPS=3,5 FUZZ_STRIDE=4', 'RDR_GATHER_BUDGET=1 RDR_GATHER_CAPS=0,0 FUZZ_STRIDE=4',
+                                     'RDR_NO_REFIT=1 RDR_NO_EDGE_CACHE=1 FUZZ_STRIDE=4'])
 def test_random_scenes_hostsim_vs_oracle(hostsim_backend, variant):
     from conftest import HOSTSIM_LIB
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MALLOC_MMAP_THRESHOLD_='1024',
                PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get('PYTHONPATH', '')]))
-    for k in ('RDR_BATCH', 'RDR_FORCE_GENERAL', 'FUZZ_STRIDE', 'RDR_BATCH_LANES'):
+    for k in ('RDR_BATCH', 'RDR_FORCE_GENERAL', 'FUZZ_STRIDE', 'RDR_BATCH_LANES', 'RDR_GATHER_BUDGET', 'RDR_GATHER_CAPS', 'RDR_NO_REFIT',
+              'RDR_NO_EDGE_CACHE'):
         env.pop(k, None)
     env.update(dict(kv.split('=') for kv in variant.split()))
     out = subprocess.check_output([sys.executable, os.path.abspath(__file__), HOSTSIM_LIB], env=env, timeout=1500).decode()
