@@ -6,6 +6,9 @@ oracle is "sum of the shards == single-device result".  Why sample blocks and no
 a sample's random numbers depend only on (sample index, dimension, per-pixel scramble), live-lane
 compaction and the Sobol' dimension bookkeeping are whole-frame properties, so every rank
 reproduces exactly the samples a single device would have drawn.
+Two exceptions: the PCG sampler, whose state depends on the earlier samples, and scenes with mip-mapped
+textures rendered with primary edge sampling, where the reference's scratch carries ray differentials from sample to sample
+-- a block that starts at sample k > 0 draws a few of its edge samples' texture levels differently (same estimator).
 
 Communication: one all_gather of the partial image after forward and one all_gather per gradient
 tensor after backward (image 12.6 MB at 1024^2, bunny_box gradients < 0.1 MB), followed by a

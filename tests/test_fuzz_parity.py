@@ -526,6 +526,37 @@ def _main(hostsim_lib):
             bad = _distance(outs[1], outs[0])
             if bad:
                 failures['loop %d step %d' % (seed, step)] = bad
+    # sample blocks (what the ranks of a multi-GPU job render, redner_amd/distributed.py): 2 or 3 blocks of 2 samples each,
+    # summed in block order, against the oracle's single call over all samples.  Without mip-mapped textures: with them the
+    # reference's primary-edge pass reads ray differentials that EARLIER SAMPLES left in its scratch (DESIGN.md section 1,
+    # "stale scratch"), a chain that a block starting at sample k > 0 cannot continue -- its first samples pick other texture
+    # levels for a few edge samples than the single call does (another draw of the same estimator; measured here: vertex
+    # gradients 0.5-2 % apart on 20 x 22 frames with a normal map and 4-6 samples, nothing without mip levels).
+    from redner_amd.distributed import render_blocked
+    for seed in range(1, 41, STRIDE):
+        blocks = 2 + seed % 2
+        outs = []
+        for backend, R in ((oracle, None), (redner, blocks)):
+            sc = _scene_mesh(seed, torch.device('cpu')) if seed % 2 else _scene(seed, torch.device('cpu'))
+            for m in sc.materials:
+                m.normal_map = m.generic_texture = None
+            args = RenderFunction.serialize_scene(sc, 2 * blocks, 1 + seed % 2, sampler_type=backend.SamplerType.sobol,
+                                                  device=torch.device('cpu'), backend=backend)
+            img = render_blocked(seed, args, R) if R else RenderFunction.apply(seed, *args)
+            img.sum().backward()
+            o = {'image': img.detach().numpy(), 'cam_position': sc.camera.position.grad.numpy()}
+            for i, sh in enumerate(sc.shapes):
+                if sh.vertices.grad is not None:
+                    o['shape%d' % i] = sh.vertices.grad.numpy()
+            outs.append(o)
+        ref, mine = outs
+        n = np.linalg.norm(ref['image'].astype(np.float64))
+        if np.linalg.norm(mine['image'].astype(np.float64) - ref['image']) > 1e-6 * n:       # fp32 sums in another order
+            failures['blocks %d' % seed] = 'image'
+        mine['image'] = ref['image']
+        bad = _distance(mine, ref)
+        if bad:
+            failures['blocks %d' % seed] = bad
     # screen-space gradient images (RenderFunction.visualize_screen_gradient, tests/test_screen_gradient.py)
     for seed in range(1, 41, STRIDE):
         kw = dict(num_samples=2 + seed % 3, max_bounces=seed % 3, device=torch.device('cpu'),
