@@ -526,6 +526,37 @@ def _main(hostsim_lib):
             bad = _distance(outs[1], outs[0])
             if bad:
                 failures['loop %d step %d' % (seed, step)] = bad
+    # degenerate geometry: a triangle with two coinciding corners, with collinear corners, and two identical triangles
+    # (coplanar, overlapping: the closest-hit tie rule and the edge list's merging of duplicate edges)
+    for seed in range(1, 61, STRIDE):
+        outs = []
+        for backend in (oracle, redner):
+            rng = np.random.RandomState(400 + seed)
+            sc = _scene(seed, torch.device('cpu'))
+            with torch.no_grad():
+                v = sc.shapes[0].vertices
+                kind = int(rng.randint(0, 3))
+                if kind == 0:
+                    v[1] = v[0]
+                elif kind == 1:
+                    v[2] = 0.5 * (v[0] + v[1])
+                elif v.shape[0] >= 6:
+                    v[3:6] = v[0:3]
+            args = RenderFunction.serialize_scene(sc, 3, 2, sampler_type=backend.SamplerType.sobol, device=torch.device('cpu'), backend=backend)
+            img = RenderFunction.apply(seed, *args)
+            img.sum().backward()
+            o = {'image': img.detach().numpy(), 'cam_position': sc.camera.position.grad.numpy()}
+            for i, sh in enumerate(sc.shapes[:3]):
+                o['shape%d' % i] = sh.vertices.grad.numpy()
+            outs.append(o)
+        ref, mine = outs
+        if any(not np.isfinite(x).all() for x in ref.values()):
+            if any(not np.array_equal(np.isfinite(ref[k]), np.isfinite(mine[k])) for k in ref):
+                failures['degenerate %d' % seed] = 'non-finite values in other places than the oracle'
+            continue
+        bad = _distance(mine, ref)
+        if bad:
+            failures['degenerate %d' % seed] = bad
     # sample blocks (what the ranks of a multi-GPU job render, redner_amd/distributed.py): 2 or 3 blocks of 2 samples each,
     # summed in block order, against the oracle's single call over all samples.  Without mip-mapped textures: with them the
     # reference's primary-edge pass reads ray differentials that EARLIER SAMPLES left in its scratch (DESIGN.md section 1,
