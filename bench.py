@@ -132,9 +132,11 @@ def cpu_baseline(a, gpu_rd=None, gpu_dev=None):
     ref = oracle_util.load_oracle()
     cpu = torch.device('cpu')
     lines, best, check = [], None, None
-    for res, spp, budget in ((256, 4, 6.0), (a.res, 1, 9.0)):
+    for res, spp, min_reps, budget in ((256, 4, 3, 30.0), (a.res, 1, 3, 70.0)):
         p = Prepared(ref, build_scene(a, cpu, res), spp, spp, 0, a.max_bounces, cpu)
-        p.step(0)                                   # warm-up (thread pool, page faults); also the step the GPU is compared with
+        t0 = time.time()
+        p.step(0)                                   # first pass (starts the thread pool, faults the pages in); also the step the GPU is compared with
+        times = [time.time() - t0]
         if gpu_rd is not None and res == a.res:
             g = Prepared(gpu_rd, build_scene(a, gpu_dev, res), spp, spp, 0, a.max_bounces, gpu_dev)
             g.step(0)
@@ -148,20 +150,30 @@ def cpu_baseline(a, gpu_rd=None, gpu_dev=None):
                      'note': 'single reference pass: its few-element tensors (light, reflectances, camera) carry the fp32-atomics '
                              'error the ref64 fixtures take out (tests/golden/make_golden.py)'}
             del g
-        t0 = time.time()
-        reps = 0
-        while time.time() - t0 < budget:
-            p.step(reps + 1)
-            reps += 1
-        dt = time.time() - t0
-        rate = res * res * spp * reps / dt / 1e6
-        lines.append({'sample': '%dx%d, %d spp' % (res, res, spp), 'value': rate, 'repetitions': reps, 'seconds': dt})
+        # at least `min_reps` passes, each timed on its own, while the sample stays within its budget of CPU seconds
+        while len(times) < min_reps and sum(times) + min(times) < budget:
+            t1 = time.time()
+            p.step(len(times))
+            times.append(time.time() - t1)
+        best_t = min(times)
+        rate = res * res * spp / best_t / 1e6
+        lines.append({'sample': '%dx%d, %d spp' % (res, res, spp), 'value': rate, 'repetitions': len(times),
+                      'seconds_per_pass': times, 'value_mean': res * res * spp * len(times) / sum(times) / 1e6})
         if best is None or rate > best[0]:
-            best = (rate, res, spp, reps, dt)
+            best = (rate, res, spp, len(times), best_t)
         del p
+    # ... and the launch shape the timed region actually runs -- one 16-sample batch of the full frame: 16.8 M lanes, 15.3 M-ray
+    # queues, the refilling traversal kernel, per-sample segment tables -- against the oracle's committed fixture
+    # (tests/golden/bunny_box_1024x1024x16.npz: ~10 min of oracle time, not repeated here): image bit for bit, vertex gradient
+    if check is not None and gpu_rd is not None and (a.workload, a.res, a.max_bounces) == ('bunny_box', 1024, 4):
+        from golden.make_golden import full_frame_check
+        same, blocks_err, e = full_frame_check(gpu_rd, 'bunny_box_1024x1024x16', gpu_dev)
+        check['batched_16spp_vs_oracle_fixture'] = {'job': 'bunny_box 1024x1024, 16 spp fwd+bwd = one 16-sample batch', 'image_bit_identical': same,
+                                                    'largest_block_sum_difference': blocks_err, 'vertex_gradient_rel_l2': e,
+                                                    'ok': bool(same and e < 1e-4)}
     rate, res, spp, reps, dt = best
     return {'value': rate, 'unit': 'Msamples/s', 'cores': os.cpu_count(), 'kind': 'reference',
-            'sample': '%s %dx%d, %d spp fwd+bwd, max_bounces %d, Sobol, %d repetitions in %.1f s; reference C++ core '
+            'sample': '%s %dx%d, %d spp fwd+bwd, max_bounces %d, Sobol, best of %d passes (%.1f s); reference C++ core '
                       '(oracle/_ref) with the BVH Embree stand-in, all host threads; the better of the two samples in `samples`'
                       % (a.workload, res, res, spp, a.max_bounces, reps, dt),
             'samples': lines, 'gpu_vs_reference': check}
@@ -376,12 +388,13 @@ def main():
     from redner_amd import redner
     prep = Prepared(redner, build_scene(a, dev, a.res), spp_rank, a.spp, rank * spp_rank, a.max_bounces, dev)
     def reduce_all():
-        # the image, and every gradient tensor in one bucket: all_gather + fixed-order sum (bit-reproducible), see distributed.py
+        # the image and every gradient tensor in ONE bucket, ONE collective per step: all_gather + fixed-order sum
+        # (bit-reproducible), see distributed.py
         if world == 1:
             return
-        from redner_amd.distributed import _all_gather_sum, _all_gather_sum_many
-        prep.img.copy_(_all_gather_sum(prep.img, dist.group.WORLD))
-        for t, r in zip(prep.grads, _all_gather_sum_many(prep.grads, dist.group.WORLD)):
+        from redner_amd.distributed import _all_gather_sum_many
+        both = [prep.img] + list(prep.grads)
+        for t, r in zip(both, _all_gather_sum_many(both, dist.group.WORLD)):
             t.copy_(r)
 
     from redner_amd import _capi
@@ -395,18 +408,27 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.time()
+    render_s = [0.0]                  # this rank's time inside its two render() calls (they return synchronised)
     for i in range(a.steps):
+        t1 = time.time()
         prep.step(a.warmup + i)
+        render_s[0] += time.time() - t1
         reduce_all()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     dt = time.time() - t0
     st = trace_stats()
+    per_rank_ms = [dt / a.steps * 1e3]
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        # every rank's own clock around the same K steps (they end at the same barrier: what differs is where a rank waited --
+        # inside its renders or in the collective); the reported time is the maximum
+        mine = torch.tensor([dt, render_s[0]], dtype=torch.float64, device=torch.device('cpu') if share else dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(t[0]) / a.steps * 1e3 for t in every]
+        per_rank_render_ms = [float(t[1]) / a.steps * 1e3 for t in every]
+        dt = max(float(t[0]) for t in every)
     samples = a.res * a.res * a.spp * a.steps
     value = samples / dt / 1e6
 
@@ -427,14 +449,13 @@ def main():
     # shadow-ray launch of the same bounce runs beside every closest-hit launch)
     alone = None
     if not a.no_alone_leg:
-        os.environ['RDR_NO_OVERLAP'] = '1'
+        short.u.options.tuning.flags |= _capi.TUNE_NO_OVERLAP          # rdr_tuning: every stage on the calling stream
         lib.rdr_trace_stats_enable(1, 0)
         trace_stats(reset=True)
         short.step(a.warmup)
         torch.cuda.synchronize(dev)
         alone = trace_stats()
         lib.rdr_trace_stats_enable(0, 0)
-        del os.environ['RDR_NO_OVERLAP']
     del short
 
     out = None
@@ -467,6 +488,10 @@ def main():
                                       'camera-pose' if a.workload.startswith('living_room_standin') else 'vertex', world, spp_rank),
                        'resolution': [a.res, a.res], 'spp': a.spp, 'spp_per_gpu': spp_rank, 'max_bounces': a.max_bounces,
                        'parallelism': 'sample-sharded x%d' % world, 'world_size': world},
+            # per rank: wall time per step, and the part of it spent inside render() (the rest: the one collective + waiting
+            # for the slowest rank) -- so that a scaling curve explains itself
+            'per_rank_ms_per_step': per_rank_ms,
+            'per_rank_render_ms_per_step': per_rank_render_ms if world > 1 else [render_s[0] / max(a.steps, 1) * 1e3],
             # Scene incl. its edge structures, synchronised (the library builds those beside the caller: a render loop does not
             # wait here); first Scene of the process / a later one with the same connectivity
             'scene_build_ms': prep.scene_build_s * 1e3, 'scene_build_warm_ms': scene_build_warm_ms,

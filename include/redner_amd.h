@@ -127,6 +127,7 @@ typedef struct rdr_denvmap_desc { rdr_dtexture_desc values; float *world_to_env;
  * Extension for multi-GPU sample sharding (no reference counterpart): this
  * call renders Sobol' samples [sample_offset, sample_offset + num_samples) of a total_samples-spp
  * estimate, i.e. with weight 1/total_samples.  total_samples == 0 means "num_samples". */
+typedef struct rdr_tuning rdr_tuning;
 typedef struct rdr_render_options {
     uint64_t seed;
     int num_samples, max_bounces;
@@ -134,7 +135,59 @@ typedef struct rdr_render_options {
     int sampler_type;                        /* rdr_sampler_type */
     int sample_pixel_center;
     int sample_offset, total_samples;
+    const rdr_tuning *tuning;                /* or NULL = every default (below) */
 } rdr_render_options;
+
+/* How a render() call is scheduled on the GPU -- which kernels, how many samples per launch, how many host threads.  No
+ * reference counterpart (its RenderOptions stop at sample_pixel_center, src/pathtracer.h:16-23); results do not depend on any
+ * of this beyond the order of floating-point atomics.  EVERY field: 0 = the library's default, so a zeroed struct (or a NULL
+ * pointer) is the shipped configuration.  These fields replace the RDR_* environment switches of earlier rounds for
+ * everything that selects a kernel or a schedule; a variable that is still set supplies the default of a field that is 0
+ * (A/B scripts), the field wins. */
+enum rdr_tune_flags {
+    RDR_TUNE_NO_OVERLAP       = 1 << 0,   /* every stage on the calling stream (no side streams)              RDR_NO_OVERLAP */
+    RDR_TUNE_FORCE_GENERAL    = 1 << 1,   /* no stage specialisation (lean / mid kernels)                     RDR_FORCE_GENERAL */
+    RDR_TUNE_PICKN_WALK       = 1 << 2,   /* NEE-mode edge pick: reference-order walk for every slot          RDR_PICKN_WALK */
+    RDR_TUNE_PICKH_FUSED      = 1 << 3,   /* hierarchical edge pick: the one-loop form                        RDR_PICKH_FUSED */
+    RDR_TUNE_PICKH_LAZY       = 1 << 4,   /* ... per-field node loads                                         RDR_PICKH_LAZY */
+    RDR_TUNE_NO_HOIST         = 1 << 5,   /* first-vertex edge picks inside the backward sweep                RDR_NO_HOIST */
+    RDR_TUNE_REFILL_OFF       = 1 << 6,   /* never the refilling traversal kernel                             RDR_TRACE_REFILL=0 */
+    RDR_TUNE_REFILL_ALL       = 1 << 7,   /* the refilling traversal kernel on every queue                    RDR_TRACE_REFILL_ALL */
+    RDR_TUNE_TRACE_BINARY     = 1 << 8,   /* never the 4-wide node records                                    RDR_TRACE_BINARY */
+    RDR_TUNE_TRACE_NO_LDS_TOP = 1 << 9,   /* hierarchy top not staged in LDS                                  RDR_TRACE_NO_LDS_TOP */
+    RDR_TUNE_NO_FUSED_BOUNCE  = 1 << 10   /* BounceContrib(d) and BounceSample(d+1) as two launches          RDR_NO_FUSED_BOUNCE */
+};
+struct rdr_tuning {
+    unsigned flags;                 /* rdr_tune_flags */
+    int batch_samples;              /* most samples rendered as one set of lanes; 1 = one sample per launch (default 16)   RDR_BATCH */
+    int64_t batch_lanes;            /* most lanes of such a set (default 2^24; 2^22 when another allocator holds > 10 % of
+                                     * the device's memory)                                                                  RDR_BATCH_LANES */
+    int workers;                    /* host threads that drive the batches of a gradient render (default: by size)         RDR_WORKERS */
+    int refill_rays_per_lane, refill_idle_lanes, refill_steps;   /* trace_refill_kernel (4, 24, 4)                          RDR_TRACE_REFILL=k,idle,steps */
+    int wide_max_rays;              /* queues of up to this many rays walk the 4-wide records (2^19)                       RDR_WIDE_MAX */
+    int gather_budget;              /* pops per lane of SecEdgeGatherN before it hands over (256)                          RDR_GATHER_BUDGET */
+    int gather_heavy_cap_plus1, gather_work_cap_plus1;   /* list capacities of the gather's hand-over paths, + 1 (tests: 1 = capacity 0)   RDR_GATHER_CAPS */
+    int mem_available_mb;           /* size the batches as if this much device memory were free (tests)                    RDR_MEM_AVAILABLE_MB */
+};
+
+/* Library-wide settings (no reference counterpart).
+ * rdr_set_stream: launches of later rdr_scene_create / rdr_render / rdr_scene_trace calls made by THIS host thread are
+ *   ordered on `hip_stream` (a hipStream_t; NULL = the null stream, the default) -- a caller whose tensors are produced on
+ *   a non-default stream (torch.cuda.stream(...)) passes that stream and needs no device-wide synchronisation of its own.
+ *   The calls still return synchronised (like the reference, src/pathtracer.cpp:947-949).
+ * rdr_set_pool_cap_mb: bound of the buffer cache per device (see rdr_trim_cache), default min(a quarter of the device, 16 GiB)
+ *   or RDR_POOL_CAP_MB; a dedicated render process may raise it so that the ~48 GB of a 2^24-lane sample batch stay parked
+ *   between calls.  Negative = back to the default.
+ * rdr_set_build_flags: rdr_build_flags for later rdr_scene_create calls (debugging / tests). */
+void rdr_set_stream(void *hip_stream);
+void rdr_set_pool_cap_mb(int64_t megabytes);
+enum rdr_build_flags {
+    RDR_BUILD_NO_REFIT        = 1 << 0,   /* no topology caches: hierarchies built from scratch every Scene   RDR_NO_REFIT */
+    RDR_BUILD_NO_EDGE_CACHE   = 1 << 1,   /* edge structures never shared between Scenes                      RDR_NO_EDGE_CACHE */
+    RDR_BUILD_SYNC_EDGES      = 1 << 2,   /* edge structures built inside rdr_scene_create                    RDR_SYNC_EDGES */
+    RDR_BUILD_EDGE_HOST_BUILD = 1 << 3    /* edge hierarchies by the host builder                             RDR_EDGE_HOST_BUILD */
+};
+void rdr_set_build_flags(unsigned flags);
 
 /* redner.DScene(...)  src/redner.cpp:75-82 */
 typedef struct rdr_dscene_desc {

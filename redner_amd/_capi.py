@@ -83,11 +83,26 @@ class DEnvmapDesc(C.Structure):
     _fields_ = [('values', DTextureDesc), ('world_to_env', C.c_void_p)]
 
 
+class Tuning(C.Structure):
+    """rdr_tuning: every field 0 = the library's default (include/redner_amd.h)."""
+    _fields_ = [('flags', C.c_uint), ('batch_samples', C.c_int), ('batch_lanes', C.c_int64), ('workers', C.c_int),
+                ('refill_rays_per_lane', C.c_int), ('refill_idle_lanes', C.c_int), ('refill_steps', C.c_int),
+                ('wide_max_rays', C.c_int), ('gather_budget', C.c_int),
+                ('gather_heavy_cap_plus1', C.c_int), ('gather_work_cap_plus1', C.c_int), ('mem_available_mb', C.c_int)]
+
+
+# rdr_tune_flags / rdr_build_flags
+TUNE_NO_OVERLAP, TUNE_FORCE_GENERAL, TUNE_PICKN_WALK, TUNE_PICKH_FUSED, TUNE_PICKH_LAZY, TUNE_NO_HOIST, TUNE_REFILL_OFF, \
+    TUNE_REFILL_ALL, TUNE_TRACE_BINARY, TUNE_TRACE_NO_LDS_TOP, TUNE_NO_FUSED_BOUNCE = [1 << k for k in range(11)]
+BUILD_NO_REFIT, BUILD_NO_EDGE_CACHE, BUILD_SYNC_EDGES, BUILD_EDGE_HOST_BUILD = [1 << k for k in range(4)]
+
+
 class RenderOptionsDesc(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('num_samples', C.c_int), ('max_bounces', C.c_int),
                 ('channels', C.POINTER(C.c_int)), ('num_channels', C.c_int),
                 ('sampler_type', C.c_int), ('sample_pixel_center', C.c_int),
-                ('sample_offset', C.c_int), ('total_samples', C.c_int)]
+                ('sample_offset', C.c_int), ('total_samples', C.c_int),
+                ('tuning', C.POINTER(Tuning))]
 
 
 class DSceneDesc(C.Structure):
@@ -114,7 +129,8 @@ class DebugCounters(C.Structure):
 EXPORTS = ('rdr_scene_create', 'rdr_scene_destroy', 'rdr_scene_max_generic_texture_dimension',
            'rdr_render', 'rdr_compute_num_channels', 'rdr_last_error',
            'rdr_trace_stats_enable', 'rdr_trace_stats_reset', 'rdr_trace_stats_get', 'rdr_scene_trace',
-           'rdr_debug_counters_get', 'rdr_trim_cache')
+           'rdr_debug_counters_get', 'rdr_trim_cache', 'rdr_debug_dump_edges',
+           'rdr_set_stream', 'rdr_set_pool_cap_mb', 'rdr_set_build_flags')
 
 _lib = None
 _lib_path = None
@@ -156,6 +172,12 @@ def load(path=None):
     lib.rdr_debug_counters_get.argtypes = [C.POINTER(DebugCounters)]
     lib.rdr_trim_cache.restype = C.c_uint64
     lib.rdr_trim_cache.argtypes = []
+    lib.rdr_set_stream.restype = None
+    lib.rdr_set_stream.argtypes = [C.c_void_p]
+    lib.rdr_set_pool_cap_mb.restype = None
+    lib.rdr_set_pool_cap_mb.argtypes = [C.c_int64]
+    lib.rdr_set_build_flags.restype = None
+    lib.rdr_set_build_flags.argtypes = [C.c_uint]
     lib.rdr_trace_stats_get.restype = None
     lib.rdr_trace_stats_get.argtypes = [C.POINTER(TraceStats)]
     lib.rdr_scene_trace.restype = C.c_int

@@ -1,6 +1,7 @@
 // capi.cpp -- extern "C" entry points declared in include/redner_amd.h.
 #include "../../include/redner_amd.h"
 #include "render.h"
+#include "tuning.h"
 #include "edges.h"
 #include <cstdio>
 #include "scene.h"
@@ -16,6 +17,9 @@ thread_local std::string g_last_error;
 // concurrent calls would share the replicated-accumulator symbols, the helper threads and the per-thread scratch.
 std::recursive_mutex g_api_lock;
 void set_error(const char *what) { g_last_error = what ? what : "unknown error"; }
+// rdr_set_stream: the stream the calling thread's launches are ordered on (null = the null stream)
+thread_local void *g_user_stream = nullptr;
+void use_caller_stream() { exec::ctx().stream = (hipStream_t)g_user_stream; }
 }
 
 extern "C" {
@@ -30,6 +34,7 @@ rdr_scene *rdr_scene_create(const rdr_camera_desc *camera, const rdr_shape_desc 
     try {
         g_last_error.clear();
         std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+        use_caller_stream();
         return reinterpret_cast<rdr_scene *>(rdr::create_scene(camera, shapes, num_shapes, materials, num_materials,
                                                                area_lights, num_area_lights, envmap, use_gpu, gpu_index,
                                                                use_primary_edge_sampling, use_secondary_edge_sampling));
@@ -54,6 +59,7 @@ int rdr_render(const rdr_scene *scene, const rdr_render_options *options, float 
         const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
         std::lock_guard<std::recursive_mutex> lk(g_api_lock);
         exec::select_device(1, s.gpu_index);
+        use_caller_stream();
         rdr::render(s, *options, rendered_image, d_rendered_image, d_scene, screen_gradient_image, debug_image);
         return 0;
     } catch (const std::exception &e) {
@@ -90,10 +96,15 @@ void rdr_trace_stats_get(rdr_trace_stats *out) {
 
 uint64_t rdr_trim_cache(void) {
     std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+    rdr::drop_edge_cache();            // the last Scene's edge structures, kept for the next one (scene.cpp: EdgeCache)
     const uint64_t bytes = exec::pool_cached_bytes();
     exec::pool_trim();
     return bytes;
 }
+
+void rdr_set_stream(void *hip_stream) { g_user_stream = hip_stream; }
+void rdr_set_pool_cap_mb(int64_t megabytes) { exec::pool_set_cap(megabytes < 0 ? -1 : (long long)megabytes << 20); }
+void rdr_set_build_flags(unsigned flags) { rdr::build_flags_ref().store(flags); }
 
 void rdr_debug_counters_get(rdr_debug_counters *out) {
     out->device_mallocs = exec::pool_device_mallocs();
@@ -143,6 +154,7 @@ int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, in
         const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
         std::lock_guard<std::recursive_mutex> lk(g_api_lock);
         exec::select_device(1, s.gpu_index);
+        use_caller_stream();
         exec::trace(s.bvh, reinterpret_cast<const rt::RayRec *>(rays), reinterpret_cast<rt::HitRec *>(hits), num_rays, any_hit != 0);
         exec::sync();
         return 0;

@@ -478,7 +478,7 @@ EdgeData *compute_edge_data(const Scene &scene) {
     // vertices, not connectivity).  Everything after it depends on positions and is redone.
     struct MergedCache { std::vector<std::vector<int>> indices; std::vector<std::vector<EdgeD>> merged; };
     static MergedCache *merged_cache = new MergedCache();            // one build at a time (build_lock above; scene.cpp: EdgeBuilder)
-    static const bool cache_allowed = std::getenv("RDR_NO_REFIT") == nullptr;
+    const bool cache_allowed = !(scene.build_flags & RDR_BUILD_NO_REFIT);
     if ((int)merged_cache->indices.size() != ns) { merged_cache->indices.assign(ns, {}); merged_cache->merged.assign(ns, {}); }
     std::vector<EdgeD> &edges = ed->edges;
     // The CANONICAL edges: every shape's merged edges in id order -- a function of the index buffers alone.  The final list is a
@@ -592,7 +592,7 @@ EdgeData *compute_edge_data(const Scene &scene) {
 
     // ---- secondary edges: the two hierarchies (src/edge_tree.cpp:724-882) ----
     if (scene.use_secondary_edges && ne > 0) {
-        static const bool host_trees = std::getenv("RDR_EDGE_HOST_BUILD") != nullptr;      // A/B, and the check of one against the other
+        const bool host_trees = (scene.build_flags & RDR_BUILD_EDGE_HOST_BUILD) != 0;      // A/B, and the check of one against the other
         ed->device_trees = exec::kDeviceEdgeTrees && !host_trees;
         const bool spatial_only = ed->device_trees;      // the kernels compute the Hough-space bounds themselves (edges_gpu.cpp)
         std::vector<int> cs_ids, ncs_ids;
@@ -634,7 +634,7 @@ EdgeData *compute_edge_data(const Scene &scene) {
         static GatherCache *gather_cache = new GatherCache();            // one build at a time (build_lock above; scene.cpp: EdgeBuilder)
         rt::BvhHost gather_built;
         double &expand_out = ed->edge_bounds_expand;
-        auto gather_job = hostpool::run([&gather_built, &edges, &canon, &can_of, &cs_ids, &ncs_ids, shapes, ne, &expand_out] {
+        auto gather_job = hostpool::run([&gather_built, &edges, &canon, &can_of, &cs_ids, &ncs_ids, shapes, ne, &expand_out, cache_allowed] {
             // mean absolute deviation of the endpoints -> billboard half-width
             std::vector<int> all_ids(cs_ids);
             all_ids.insert(all_ids.end(), ncs_ids.begin(), ncs_ids.end());

@@ -175,6 +175,8 @@ void pool_free(void *p);
 void pool_trim();                     // hipFree of every parked block (synchronises the device first)
 size_t pool_cached_bytes();           // bytes parked in the free lists right now
 size_t memory_available();            // what a call can still get: free device memory + what is parked in the cache
+double memory_held_by_others();       // fraction of the device's memory that neither is free nor came from this pool (torch's allocator, other processes)
+void pool_set_cap(long long bytes);   // bound of the cache per device; negative = the default (rdr_set_pool_cap_mb)
 size_t pool_device_mallocs();          // number of hipMalloc calls made by the pool so far (tests: steady state adds none)
 inline std::atomic<size_t> &host_count_reads_ref() { static std::atomic<size_t> n{0}; return n; }
 inline size_t host_count_reads() { return host_count_reads_ref().load(); }     // live-lane counts read back by the host so far
@@ -558,10 +560,9 @@ TraceStats &trace_stats();
 void trace_stats_collect();     // folds pending hipEvent pairs / device counters into trace_stats()
 // `coherent`: neighbouring queue slots hold neighbouring rays that finish together (camera rays): the plain kernel, whatever the size
 void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count n, bool any, bool coherent = false);
-// Host threads render() may drive samples from (RDR_WORKERS=1 turns the second one off).
+// Host threads render() may drive samples from (rdr_tuning::workers = 1 turns the second one off).
 inline int sample_workers(int lanes, int samples, bool batches = false) {
-    static const int forced = [] { const char *e = std::getenv("RDR_WORKERS"); return e ? std::min(1 + kMaxHelpers, std::max(1, std::atoi(e))) : 0; }();
-    if (forced) return forced;
+    // (rdr_tuning::workers overrides all of this, render.cpp)
     // sample batches (render.cpp): two chains of launches in flight, more do not help (tools/gpu_batch_grid.sh)
     if (batches) return samples >= 2 && lanes < (1 << 20) ? 2 : 1;
     // measured (bunny_box backward, round 2): 256x256x4 spp 13.8 / 14.6 / 15.2 ms with 2 / 3 / 4 workers, 256x256x16 spp

@@ -12,6 +12,7 @@
 // Measured numbers, what bounds a launch and the loop shapes that were tried and rejected are in DESIGN.md section 3
 // ("Traversal kernel", "Round 3") and profiles/r1_notes.md, r2_notes.md, r3_notes.md.
 #include "exec.h"
+#include "../tuning.h"
 #include <algorithm>
 #include <cstring>
 #include <map>
@@ -40,9 +41,34 @@ struct Pool {
     std::mutex lock;
     std::multimap<size_t, void *> free_blocks[16];              // per device, by capacity
     std::unordered_map<void *, std::pair<size_t, int>> live;    // block -> (capacity, device)
+    size_t parked[16] = {};                                     // bytes in free_blocks[d] (kept in step: no walk per free)
+    size_t from_driver[16] = {};                                // bytes this pool currently holds from hipMalloc (live + parked)
     size_t device_mallocs = 0;
+    long long cap_override = -1;                                // rdr_set_pool_cap_mb
 };
 Pool &pool() { static Pool *p = new Pool(); return *p; }       // never destroyed: blocks may be returned during exit
+
+// The cache is bounded: a torch process shares the device with torch's own allocator, which cannot reclaim what is parked
+// here.  Default: a quarter of the device's memory but no more than 16 GiB (round 3 parked up to 72 GB -- the 48 GB of a
+// 2^24-lane sample batch -- for +4 % at 1024 x 1024: now a decision of the caller, rdr_set_pool_cap_mb / RDR_POOL_CAP_MB);
+// rdr_trim_cache() releases everything.
+size_t pool_cap(const Pool &pl) {
+    if (pl.cap_override >= 0) return (size_t)pl.cap_override;
+    static const size_t dflt = [] {
+        if (const char *e = std::getenv("RDR_POOL_CAP_MB")) return (size_t)std::max(0, std::atoi(e)) << 20;
+        const size_t sixteen = (size_t)16384 << 20;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return sixteen; }
+        return std::min(total_b / 4, sixteen);
+    }();
+    return dflt;
+}
+}
+
+void pool_set_cap(long long bytes) {
+    Pool &pl = pool();
+    std::lock_guard<std::mutex> lk(pl.lock);
+    pl.cap_override = bytes;
 }
 
 void *pool_alloc(size_t bytes) {
@@ -57,6 +83,7 @@ void *pool_alloc(size_t bytes) {
         if (it != fl.end() && it->first <= want + want / 4 + 4096) {          // close fit: reuse
             void *p = it->second;
             pl.live[p] = {it->first, dev};
+            pl.parked[dev & 15] -= it->first;
             fl.erase(it);
             return p;
         }
@@ -70,6 +97,7 @@ void *pool_alloc(size_t bytes) {
     }
     std::lock_guard<std::mutex> lk(pl.lock);
     pl.device_mallocs++;
+    pl.from_driver[dev & 15] += want;
     pl.live[p] = {want, dev};
     return p;
 }
@@ -77,27 +105,23 @@ void *pool_alloc(size_t bytes) {
 void pool_free(void *p) {
     if (!p) return;
     Pool &pl = pool();
-    std::lock_guard<std::mutex> lk(pl.lock);
+    std::unique_lock<std::mutex> lk(pl.lock);
     auto it = pl.live.find(p);
-    if (it == pl.live.end()) { (void)hipFree(p); return; }
-    // The cache is bounded (RDR_POOL_CAP_MB, default a quarter of the device's memory: 72 of the 288 GB, enough for the
-    // buffers of a 2^24-lane sample batch): a torch process shares the device with torch's own allocator, which cannot reclaim
-    // what is parked here; rdr_trim_cache() releases everything.
-    static const size_t cap = [] {
-        if (const char *e = std::getenv("RDR_POOL_CAP_MB")) return (size_t)std::max(0, std::atoi(e)) << 20;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (size_t)16384 << 20; }
-        return total_b / 4;
-    }();
-    auto &fl = pl.free_blocks[it->second.second & 15];
-    size_t parked = it->second.first;
-    for (auto &kv : fl) parked += kv.first;
-    if (parked > cap) { (void)hipFree(p); pl.live.erase(it); return; }       // hipFree waits for the device: safe whatever is in flight
-    fl.emplace(it->second.first, p);
+    if (it == pl.live.end()) { lk.unlock(); (void)hipFree(p); return; }
+    const size_t bytes = it->second.first;
+    const int d = it->second.second & 15;
     pl.live.erase(it);
+    if (pl.parked[d] + bytes > pool_cap(pl)) {
+        pl.from_driver[d] -= bytes;
+        lk.unlock();
+        (void)hipFree(p);              // waits for the device: safe whatever is in flight; outside the lock: the other workers go on
+        return;
+    }
+    pl.free_blocks[d].emplace(bytes, p);
+    pl.parked[d] += bytes;
 }
 
-void pool_trim() {
+void pool_trim() {                     // hipFree waits for the device before it releases a block
     Pool &pl = pool();
     std::lock_guard<std::mutex> lk(pl.lock);
     int dev = 0;
@@ -108,6 +132,8 @@ void pool_trim() {
         (void)hipSetDevice(d);
         for (auto &kv : fl) (void)hipFree(kv.second);
         fl.clear();
+        pl.from_driver[d] -= pl.parked[d];
+        pl.parked[d] = 0;
     }
     (void)hipSetDevice(dev);
 }
@@ -116,14 +142,29 @@ size_t pool_cached_bytes() {
     Pool &pl = pool();
     std::lock_guard<std::mutex> lk(pl.lock);
     size_t total = 0;
-    for (auto &fl : pl.free_blocks) for (auto &kv : fl) total += kv.first;
+    for (size_t b : pl.parked) total += b;
     return total;
 }
 
 size_t memory_available() {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return ~(size_t)0; }
-    return free_b + pool_cached_bytes();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Pool &pl = pool();
+    std::lock_guard<std::mutex> lk(pl.lock);
+    return free_b + pl.parked[dev & 15];
+}
+
+double memory_held_by_others() {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) { (void)hipGetLastError(); return 0.0; }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    Pool &pl = pool();
+    std::lock_guard<std::mutex> lk(pl.lock);
+    const double used = (double)(total_b - free_b), mine = (double)pl.from_driver[dev & 15];
+    return used > mine ? (used - mine) / (double)total_b : 0.0;
 }
 
 size_t pool_device_mallocs() { Pool &pl = pool(); std::lock_guard<std::mutex> lk(pl.lock); return pl.device_mallocs; }
@@ -231,6 +272,23 @@ struct FetchStaged {
         return n;
     }
 };
+// Tallies of the counting variants (untimed roofline pass of bench.py): summed across the wave first -- one atomic per wave and
+// counter instead of one per lane (15 M lanes x 3 counters on one line cost 13-15 ms per launch, profiles/r3_notes.md).
+__device__ inline void wave_tally(unsigned long long *p, unsigned long long v) {
+    const unsigned long long act = __ballot(1);
+    double s;
+    if (act == ~0ull) s = rdr::wave_sum((double)v);          // exact: the tallies stay far below 2^53
+    else {
+        s = 0;
+        const int lo = (int)(unsigned)v, hi = (int)(unsigned)(v >> 32);
+        for (unsigned long long m = act; m; m &= m - 1) {
+            const int k = __ffsll((long long)m) - 1;
+            s += (double)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(hi, k) << 32) | (unsigned)__builtin_amdgcn_readlane(lo, k));
+        }
+    }
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(p, (unsigned long long)s);
+}
+
 template <bool ANY, bool COUNT, int STACK, class IDX, bool TOP>
 __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays,
                                                     rt::HitRec *__restrict__ hits, int n, const int *count,
@@ -250,19 +308,21 @@ __global__ void __launch_bounds__(256) trace_kernel(rt::BvhD bvh, const rt::RayR
     if (i >= n) return;
     rt::RayRec r = rays[i];
     rt::Hit h{0.f, -1, -1};
-    if (COUNT) atomicAdd(&counters[ANY ? 3 : 4], 1ull);        // queue slots (base is g_counters, +2 for any-hit): [4] / [5]
+    rt::Counters c{0, 0};
     if (!(r.tmax < 0.f)) {
         float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
         if (COUNT) {
-            rt::Counters c{0, 0};
             h = TOP ? rt::traverse_with<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, &c, FetchStaged{bvh.nodes, (LdsFloats)(const float *)top, ntop})
                     : rt::traverse<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, &c);
-            atomicAdd(&counters[0], c.nodes);
-            atomicAdd(&counters[1], c.tris);
         } else {
             h = TOP ? rt::traverse_with<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, (rt::Counters *)nullptr, FetchStaged{bvh.nodes, (LdsFloats)(const float *)top, ntop})
                     : rt::traverse<ANY, IDX>(bvh, o, d, r.tmin, r.tmax, stack, 256, nullptr);
         }
+    }
+    if (COUNT) {                                                // (the lanes of the wave that hold a queue slot are all here)
+        wave_tally(&counters[ANY ? 3 : 4], 1ull);               // queue slots (base is g_counters, +2 for any-hit): [4] / [5]
+        wave_tally(&counters[0], c.nodes);
+        wave_tally(&counters[1], c.tris);
     }
     hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};
 }
@@ -284,14 +344,13 @@ __global__ void __launch_bounds__(256) trace_wide_kernel(rt::BvhD bvh, const rt:
     if (i >= n) return;
     const rt::RayRec r = rays[i];
     rt::Hit h{0.f, -1, -1};
-    if (COUNT) atomicAdd(&counters[ANY ? 3 : 4], 1ull);
+    rt::Counters c{0, 0};
     if (!(r.tmax < 0.f)) {
         const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
-        rt::Counters c{0, 0};
         h = rt::traverse_wide<ANY>(bvh, o, d, r.tmin, r.tmax, stack, 256, COUNT ? &c : nullptr);
-        // counters = base of this query kind ({nodes, tris} at [0, 1]); the 4-wide records are tallied at g_counters[6] / [7]
-        if (COUNT) { atomicAdd(&counters[ANY ? 5 : 6], c.nodes); atomicAdd(&counters[1], c.tris); }
     }
+    // counters = base of this query kind ({nodes, tris} at [0, 1]); the 4-wide records are tallied at g_counters[6] / [7]
+    if (COUNT) { wave_tally(&counters[ANY ? 3 : 4], 1ull); wave_tally(&counters[ANY ? 5 : 6], c.nodes); wave_tally(&counters[1], c.tris); }
     hits[i] = rt::HitRec{h.shape, h.shape >= 0 ? h.prim : -1};
 }
 
@@ -507,16 +566,16 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count 
         check(hipEventRecord(p.a, s), "hipEventRecord");
     }
     // Staging pays on big queues (closest-hit 0.330 -> 0.321 ms per 956 k rays); on a 256 x 256 frame the 8 KiB copy + barrier per
-    // 256 rays costs more than the L1-hot top levels save (optimisation-loop iteration +2 ms).  RDR_TRACE_NO_LDS_TOP=1: never.
-    static const bool stage_allowed = std::getenv("RDR_TRACE_NO_LDS_TOP") == nullptr;
-    const bool stage_top = stage_allowed && n >= (1 << 18);
+    // 256 rays costs more than the L1-hot top levels save (optimisation-loop iteration +2 ms).  RDR_TUNE_TRACE_NO_LDS_TOP: never.
+    const rdr::Tuning &tune = rdr::tuning();
+    const bool stage_top = !tune.has(RDR_TUNE_TRACE_NO_LDS_TOP) && n >= (1 << 18);
     // Which form of the hierarchy: queues of up to RDR_WIDE_MAX rays (default 2^19) walk the 4-wide records (measured,
     // tools/trace_ab.py, profiles/r3_notes.md: half the dependent steps per ray pays where a launch is one or two waves per
     // SIMD -- closest-hit 0.119 -> 0.102 ms, any-hit 0.078 -> 0.066 ms per 65 k / 50 k rays; on queues of a million rays and
     // more both forms issue the same number of vector instructions per wave and the binary records, at 8 instead of 5 waves
-    // per SIMD, are 0-10 % ahead).  RDR_TRACE_BINARY=1: never the wide records.
-    static const bool wide_allowed = std::getenv("RDR_TRACE_BINARY") == nullptr;
-    static const int wide_max = [] { const char *e = std::getenv("RDR_WIDE_MAX"); return e ? std::atoi(e) : (1 << 19); }();
+    // per SIMD, are 0-10 % ahead).  RDR_TUNE_TRACE_BINARY: never the wide records.
+    const bool wide_allowed = !tune.has(RDR_TUNE_TRACE_BINARY);
+    const int wide_max = tune.wide_max;
     if (wide_allowed && bvh.wide != nullptr && bvh.wide_stack_need <= 48 && n <= wide_max) {
         unsigned long long *ctr = nullptr;
         if (st.counting) {
@@ -555,24 +614,11 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count 
     // caller does not mark coherent.  (The queue's host-side bound decides: a launch sized for 2^22 lanes -- four samples of a
     // 1024 x 1024 frame, the edge sub-paths' two lanes per slot -- still holds 1.5-3.3 M rays after the compactions; choosing the
     // rays per lane in the kernel from the actual count was measured too and is slower, 61.8 vs 62.5 Msamples/s.)
-    // RDR_TRACE_REFILL=0: never; ="k,idle,steps": those parameters; RDR_TRACE_REFILL_ALL=1: every queue (tools/trace_ab.py).
-    struct RefillSetup { int k = 4, idle = 24, steps = 4; bool off = false, all = false; };
-    static const RefillSetup rf = [] {
-        RefillSetup r;
-        if (const char *e = std::getenv("RDR_TRACE_REFILL")) {
-            int k = 0, idle = 0, steps = 0;
-            const int got = std::sscanf(e, "%d,%d,%d", &k, &idle, &steps);
-            if (got >= 1 && k <= 0) r.off = true;
-            if (got >= 1 && k > 0) r.k = k;
-            if (got >= 2 && idle > 0) r.idle = idle;
-            if (got >= 3 && steps > 0) r.steps = steps;
-        }
-        r.all = std::getenv("RDR_TRACE_REFILL_ALL") != nullptr;
-        return r;
-    }();
-    const int refill_k = rf.off ? 0 : ((rf.all || (!coherent && n >= (1 << 22))) ? rf.k : 0);
+    // rdr_tuning: RDR_TUNE_REFILL_OFF never; refill_* those parameters; RDR_TUNE_REFILL_ALL every queue (tools/trace_ab.py).
+    const bool refill_off = tune.has(RDR_TUNE_REFILL_OFF), refill_all = tune.has(RDR_TUNE_REFILL_ALL);
+    const int refill_k = refill_off ? 0 : ((refill_all || (!coherent && n >= (1 << 22))) ? tune.refill_k : 0);
     if (refill_k >= 1 && !st.counting && bvh.stack_need <= rt::kTraverseStack) {
-        const int idle_min = rf.idle, steps = rf.steps;
+        const int idle_min = tune.refill_idle, steps = tune.refill_steps;
         const int wg_rays = 4 * 64 * refill_k;
         const int rblocks = (int)(((long long)n + wg_rays - 1) / wg_rays);
         const int k_arg = refill_k;

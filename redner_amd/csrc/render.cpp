@@ -7,6 +7,7 @@
 // the reference's, because sample-exact parity depends on it; how a bounce is cut into kernels
 // and what is kept in HBM is ours (stages_fwd.h / stages_bwd.h / stages_edge.h).
 #include "render.h"
+#include "tuning.h"
 #include <atomic>
 #include <exception>
 #include <cstdio>
@@ -24,9 +25,9 @@ namespace rdr {
 
 namespace {
 
-// Independent stages on side streams (DESIGN.md section 3 "Streams")?  Re-read from the environment by every render() call so
-// that bench.py can time the traversal kernel on its own in an extra, untimed pass (RDR_NO_OVERLAP=1).
-std::atomic<bool> g_overlap{true};
+// Independent stages on side streams (DESIGN.md section 3 "Streams")?  Part of the call's tuning (RDR_TUNE_NO_OVERLAP): bench.py
+// times the traversal kernel on its own in an extra, untimed pass.
+inline bool overlap_on() { return !tuning().has(RDR_TUNE_NO_OVERLAP); }
 
 // Device arena: typed arrays from the caching allocator (exec::pool_alloc); they go back to its free lists when the
 // call ends, so the next render() of the same shape performs no hipMalloc / hipFree at all.
@@ -116,8 +117,7 @@ bool scene_is_lean(const Scene &scene, const ChannelsD &ch) {
 // Which specialisation of the stages a scene can use (stages_fwd.h): kLean / kMid / kGeneral.
 constexpr int kGeneral = 0, kLean = 1, kMid = 2;
 int scene_kind(const Scene &scene, const ChannelsD &ch) {
-    static const bool force_general = std::getenv("RDR_FORCE_GENERAL") != nullptr;       // A/B: what the specialisations buy
-    if (force_general) return kGeneral;
+    if (tuning().has(RDR_TUNE_FORCE_GENERAL)) return kGeneral;       // A/B: what the specialisations buy
     if (scene_is_lean(scene, ch)) return kLean;
     const CameraD &c = scene.d.cam;
     if (scene.d.envmap == nullptr && c.kind == kCamPerspective && !c.distortion.defined && ch.radiance_only) return kMid;
@@ -143,7 +143,7 @@ exec::Count run_bounce(const Scene &scene, const SceneD &sd, const SamplerD &rng
     launch_v(lean, num_active, BounceSample{sd, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
     // the shadow-ray and the continuation-ray queue are traced side by side: both kernels wait on dependent loads
     // with a fraction of their lanes active (profiles/r1_notes.md), so they fill each other's gaps
-    const bool side = g_overlap.load(std::memory_order_relaxed);
+    const bool side = overlap_on();
     if (side) {
         static thread_local exec::Fence *fences[16][2] = {};                   // per host thread and device
         const int dev = exec::current_device();
@@ -372,13 +372,9 @@ struct Backward {
             gshared.work = arena.get<GatherWork>(kGatherWorkCap);
             gshared.cands_big = arena.get<GatherCand>((size_t)kGatherCandsBig * kGatherHeavyCap);
             gshared.heavy_cap = kGatherHeavyCap; gshared.work_cap = kGatherWorkCap;
-            if (const char *e = std::getenv("RDR_GATHER_CAPS")) {          // tests: small lists, so that the overflow paths run
-                int h = 0, w = 0;
-                if (std::sscanf(e, "%d,%d", &h, &w) == 2) {
-                    gshared.heavy_cap = std::max(0, std::min(h, kGatherHeavyCap));
-                    gshared.work_cap = std::max(0, std::min(w, kGatherWorkCap));
-                }
-            }
+            // tests: small lists, so that the overflow paths run (rdr_tuning::gather_*_cap_plus1)
+            if (tuning().gather_heavy_cap >= 0) gshared.heavy_cap = std::min(tuning().gather_heavy_cap, kGatherHeavyCap);
+            if (tuning().gather_work_cap >= 0) gshared.work_cap = std::min(tuning().gather_work_cap, kGatherWorkCap);
             h_leaves = arena.get<HLeaf>((size_t)kHSamples * P);
             h_spill = arena.get<HLeaf>((size_t)(kHSamples - kHStackLds) * P);
             edge_contrib = arena.get<double>(L);
@@ -406,7 +402,7 @@ struct Backward {
     GatherCand *gather_cands = nullptr;        // positive leaves found by the NEE-mode gather, kGatherCands per list position
     int *nee_slots = nullptr;                  // slots of the NEE-mode edge pick (its walk runs beside the hierarchical pick)
     exec::Fence depth_begin, adjoint_done, setup_done, walk_done, picks_begin, pickh_done;
-    const bool overlap = g_overlap.load(std::memory_order_relaxed);
+    const bool overlap = overlap_on();
     double *edge_contrib = nullptr, *edge_tmin = nullptr, *hit_pos = nullptr;
     PrimaryEdgeRec *prim_recs = nullptr;
     SecondaryEdgeRec *sec_recs = nullptr;
@@ -442,14 +438,14 @@ struct Backward {
     template <int LEAN> void launch_pick_n(int need, exec::Count nN, const SecEdgeArgs &sa) {
         // order-free gather over the billboard hierarchy (SecEdgeGatherN), then the reference-order walk for the slots it
         // marked kPickOverflow (none in practice); RDR_PICKN_WALK=1 walks every slot instead (A/B measurements)
-        static const bool walk_all = std::getenv("RDR_PICKN_WALK") != nullptr;
+        const bool walk_all = tuning().has(RDR_TUNE_PICKN_WALK);
         const bool gather = !walk_all && sa.es.gather.num_nodes > 0;
         if (gather) {
             const int gneed = sa.es.gather.stack_need;
             exec::zero(gshared.book, sizeof(GatherBook));
             auto passes = [&](auto tag) {
                 constexpr int NS = decltype(tag)::value;
-                static const int budget = [] { const char *e = std::getenv("RDR_GATHER_BUDGET"); return e ? std::max(1, std::atoi(e)) : kGatherBudget; }();
+                const int budget = tuning().gather_budget;
                 launch_v(LEAN, nN, SecEdgeGatherN<NS>{sa, nee_slots, sec_picks, gather_cands, gshared, budget});
                 launch_v(LEAN, kGatherWorkCap, SecEdgeGatherSub<NS>{sa, nee_slots, gshared});
                 launch_v(LEAN, kGatherHeavyCap, SecEdgeGatherReplay{sa, nee_slots, sec_picks, gshared});
@@ -519,8 +515,8 @@ struct Backward {
         exec::zero(adj.ray_dir, sizeof(double) * 3 * stride);
         exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * stride);
         const int dim0 = opt.sample_pixel_center ? 0 : 2;
-        static const bool pickh_fused = std::getenv("RDR_PICKH_FUSED") != nullptr;     // A/B: the one-loop form
-        static const bool pickh_lazy = std::getenv("RDR_PICKH_LAZY") != nullptr;       // A/B: per-field node loads
+        const bool pickh_fused = tuning().has(RDR_TUNE_PICKH_FUSED);     // A/B: the one-loop form
+        const bool pickh_lazy = tuning().has(RDR_TUNE_PICKH_LAZY);       // A/B: per-field node loads
         // The two edge picks of a secondary pass: slot setup, the per-mode slot lists, the NEE-mode gather and the hierarchical
         // pick.  `early`: everything off the calling stream (setup + lists + gather on side stream 1, hierarchical pick on side
         // stream 0), so that the caller's stream is free for the bounce adjoints; otherwise setup, lists and the hierarchical pick
@@ -593,7 +589,7 @@ struct Backward {
         const bool secondary_on = edges_on && scene.use_secondary_edges;
         SecEdgeArgs early_sa{};
         bool hoisted = false;
-        static const bool hoist_allowed = std::getenv("RDR_NO_HOIST") == nullptr;          // A/B
+        const bool hoist_allowed = !tuning().has(RDR_TUNE_NO_HOIST);          // A/B
         if (hoist_allowed && secondary_on && overlap && scene.diffuse_only && pcg_edge == nullptr && has_lights && B >= 2 && num_active[0].upper > 0) {
             // the dimension the sweep will have reached at the first vertex: 4 per deeper depth that has lanes (device counts)
             if (batch.on) {
@@ -741,7 +737,8 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     const bool has_lights = scene.d.num_lights > 0;
     if (2 + 7 * B > kSamplerDims) throw std::runtime_error("render: max_bounces exceeds the Sobol' table");
 
-    g_overlap.store(std::getenv("RDR_NO_OVERLAP") == nullptr && std::getenv("RDR_DEBUG_DUMP") == nullptr);
+    const Tuning tune = resolve_tuning(opt.tuning);
+    TuningScope tuning_scope(tune);
     PhaseTimer timer(d_image ? "render (backward)" : "render (forward)");
     Arena arena;
     {
@@ -791,20 +788,35 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         // So: everything in one batch while that is <= 2^17 lanes, otherwise batches of up to 2^24 lanes (RDR_BATCH_LANES; the
         // buffers of such a batch are ~4 KB per lane: 64 GB of the 288 GB, which the buffer cache keeps between calls), at
         // least two of them, driven by two workers while a batch is below 2^20 lanes.
-        static const int batch_cap = [] { const char *e = std::getenv("RDR_BATCH"); return e ? std::max(1, std::min(kMaxBatch, std::atoi(e))) : kMaxBatch; }();
+        const int batch_cap = std::min(kMaxBatch, tune.batch_samples);
         const long long total = (long long)opt.num_samples * P;
         int want = opt.num_samples;
         if (total > (1 << 17) && samples_independent) want = (opt.num_samples + 1) / 2;
-        static const long long lane_cap = [] { const char *e = std::getenv("RDR_BATCH_LANES"); return e ? std::max(1LL, std::atoll(e)) : (1LL << 24); }();
+        // Lanes per batch (rdr_tuning::batch_lanes): 2^24 in a process that has the device to itself; 2^22 when another allocator
+        // (torch holding a network next to the renderer) has taken more than a tenth of the device's memory -- the buffers of a
+        // 2^24-lane batch are ~48 GB, of a 2^22-lane batch 12 GB, for 4 % of throughput at 1024 x 1024 (profiles/r3_notes.md).
+        long long lane_cap = tune.batch_lanes;
+        if (lane_cap == 0) {
+            lane_cap = 1LL << 24;
+            if (total > (1LL << 22) && exec::memory_held_by_others() > 0.10) lane_cap = 1LL << 22;
+        }
         batch.S = std::max(1, std::min(std::min(batch_cap, want), (int)std::max(1LL, lane_cap / P)));
-        // ... and what the device can still give: a batch's buffers are ~(400 (max_bounces + 1) + 1200) bytes per lane (2.9 KB
-        // measured at max_bounces 4 with both edge estimators); a process that shares the GPU with a large torch model
-        // gets smaller batches instead of an allocation failure
-        const double per_lane = 400.0 * (B + 1) + 1200.0;
-        static const double room_override = [] { const char *e = std::getenv("RDR_MEM_AVAILABLE_MB"); return e ? std::atof(e) * 1048576.0 : -1.0; }();
-        if (room_override >= 0 || per_lane * batch.S * P > 1073741824.0) {        // small frames: not worth asking the driver
-            const double room = 0.8 * (room_override >= 0 ? room_override : (double)exec::memory_available());      // (override: tests)
-            while (batch.S > 1 && per_lane * batch.S * P > room) batch.S = (batch.S + 1) / 2;
+        // ... and what the device can still give: a worker's buffers are ~(400 (max_bounces + 1) + 1200) bytes per lane (2.9 KB
+        // measured at max_bounces 4 with both edge estimators), a forward batch adds its staging planes, a gradient batch the
+        // per-lane copy of the upstream gradient; gradient batches below 2^20 lanes are driven by two workers (more when the
+        // tuning asks).  A process that shares the GPU with a large torch model gets smaller batches instead of an
+        // allocation failure.
+        auto bytes_needed = [&](int S_try) {
+            const double lanes = (double)S_try * P;
+            const int wk = !samples_independent ? 1 : (tune.workers > 0 ? tune.workers : (lanes < (double)(1 << 20) ? 2 : 1));
+            double per_lane = (400.0 * (B + 1) + 1200.0) * wk;
+            if (forward_batches) per_lane += 4.0 * lay.nd * (B + 1);
+            if (d_image) per_lane += 4.0 * lay.nd;
+            return per_lane * lanes;
+        };
+        if (tune.mem_available_mb >= 0 || bytes_needed(batch.S) > 1073741824.0) {        // small frames: not worth asking the driver
+            const double room = 0.8 * (tune.mem_available_mb >= 0 ? tune.mem_available_mb * 1048576.0 : (double)exec::memory_available());      // (override: tests)
+            while (batch.S > 1 && bytes_needed(batch.S) > room) batch.S = (batch.S + 1) / 2;
         }
         batch.on = batch.S > 1;
     }
@@ -839,7 +851,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         }
     }
     int workers = 1;
-    if (samples_independent) workers = std::max(1, std::min(exec::sample_workers(PL, num_batches, batch.on), num_batches));
+    if (samples_independent) workers = std::max(1, std::min(tune.workers > 0 ? tune.workers : exec::sample_workers(PL, num_batches, batch.on), num_batches));
 
     // Everything one sample (or sample batch) needs between its camera rays and its last gradient add.
     struct Worker {
@@ -932,6 +944,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
         exec::sync();                          // accumulators zeroed, tables uploaded: visible to the other streams
         for (int k = 1; k < workers; ++k)
             exec::SecondThread::get(k - 1).start([&, k] {
+                TuningScope helper_scope(tune);        // (thread-local: the helper renders under the call's tuning)
                 Worker w;
                 make_worker(w);
                 run_samples(w, k, workers);

@@ -1,5 +1,6 @@
 // scene.cpp -- Scene construction (see scene.h).
 #include "scene.h"
+#include "tuning.h"
 #include "hostpool.h"
 #include "surface.h"
 #include "sobol.h"
@@ -145,6 +146,22 @@ int compute_num_channels(const int *channels, int n, int max_generic) {
     return total;
 }
 
+// The inputs and the result of the last edge build (see create_scene): host mirrors of every shape + a reference to the
+// device structures.  It outlives the Scene it was made for on purpose (the next Scene of an optimisation loop takes it), and
+// rdr_trim_cache() -- "give back what the library keeps for later" -- drops it along with the parked buffers.
+struct EdgeCache {
+    int gpu_index = -1; bool primary = false, secondary = false;
+    CameraD cam;
+    std::vector<std::vector<float>> vertices, normals;
+    std::vector<std::vector<int>> indices;
+    std::shared_future<std::shared_ptr<EdgeData>> result;
+};
+static EdgeCache *edge_cache() { static EdgeCache *c = new EdgeCache(); return c; }
+void drop_edge_cache() {
+    EdgeCache *c = edge_cache();
+    *c = EdgeCache();                // the device structures go when the last Scene that shares them does
+}
+
 Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, int num_shapes,
                     const rdr_material_desc *materials, int num_materials,
                     const rdr_area_light_desc *area_lights, int num_area_lights,
@@ -158,6 +175,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     Scene &s = *sp;
     PhaseTimer timer("scene build");
     s.gpu_index = gpu_index;
+    s.build_flags = build_flags();
     s.use_primary_edges = primary_edges != 0;
     s.use_secondary_edges = secondary_edges != 0;
 
@@ -341,12 +359,12 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         meshes[i] = rt::MeshView{s.h_vertices[i].data(), s.h_indices[i].data(), s.shapes[i].num_triangles};
     // A Scene with the index buffers of the previous one (an optimisation loop moves vertices, pyredner builds a Scene per
     // forward call, render_pytorch.py:609) keeps that hierarchy's topology and refits its boxes; hits do not depend on the
-    // hierarchy (raytri.h), and it is rebuilt once its inner surface area has grown by more than 30 %.  RDR_NO_REFIT=1: always build.
+    // hierarchy (raytri.h), and it is rebuilt once its inner surface area has grown by more than 30 %.  RDR_BUILD_NO_REFIT: always build.
     struct TopologyCache { std::vector<std::vector<int>> indices; rt::BvhHost bvh; };
     static TopologyCache *topo_cache = new TopologyCache();          // guarded by the API lock (capi.cpp)
-    static const bool refit_allowed = std::getenv("RDR_NO_REFIT") == nullptr;
+    const bool refit_allowed = !(s.build_flags & RDR_BUILD_NO_REFIT);
     rt::BvhHost bvh_built;
-    auto bvh_job = hostpool::run([&meshes, &bvh_built, &s] {      // (joins in its destructor on an early exit)
+    auto bvh_job = hostpool::run([&meshes, &bvh_built, &s, refit_allowed] {      // (joins in its destructor on an early exit)
         bool same = refit_allowed && topo_cache->indices.size() == s.h_indices.size() && !topo_cache->bvh.nodes.empty();
         for (size_t i = 0; same && i < s.h_indices.size(); ++i) same = topo_cache->indices[i] == s.h_indices[i];
         if (same) {
@@ -432,18 +450,11 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     timer.lap("device copies");
     // ---- edge sampling structures ----
     if (s.use_primary_edges || s.use_secondary_edges) {
-        static const bool sync_edges = std::getenv("RDR_SYNC_EDGES") != nullptr;
+        const bool sync_edges = (s.build_flags & RDR_BUILD_SYNC_EDGES) != 0;
         // Everything the edge structures are computed from (edges.cpp: compute_edge_data): if it equals what the previous
         // Scene's were computed from, that result -- finished or still in the builder's hands -- is this Scene's too.
-        struct EdgeCache {
-            int gpu_index = -1; bool primary = false, secondary = false;
-            CameraD cam;
-            std::vector<std::vector<float>> vertices, normals;
-            std::vector<std::vector<int>> indices;
-            std::shared_future<std::shared_ptr<EdgeData>> result;
-        };
-        static EdgeCache *cache = new EdgeCache();            // guarded by the API lock (capi.cpp)
-        static const bool cache_allowed = std::getenv("RDR_NO_EDGE_CACHE") == nullptr && std::getenv("RDR_NO_REFIT") == nullptr;
+        EdgeCache *cache = edge_cache();                      // guarded by the API lock (capi.cpp)
+        const bool cache_allowed = !(s.build_flags & (RDR_BUILD_NO_EDGE_CACHE | RDR_BUILD_NO_REFIT));
         const bool hit = cache_allowed && cache->result.valid() && cache->gpu_index == s.gpu_index &&
                          cache->primary == s.use_primary_edges && cache->secondary == s.use_secondary_edges &&
                          std::memcmp(&cache->cam, &s.d.cam, sizeof(CameraD)) == 0 && cache->indices == s.h_indices &&
@@ -468,7 +479,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
             }).share();
             if (cache_allowed) {
                 cache->gpu_index = s.gpu_index; cache->primary = s.use_primary_edges; cache->secondary = s.use_secondary_edges;
-                cache->cam = s.d.cam;
+                std::memcpy(&cache->cam, &s.d.cam, sizeof(CameraD));      // (padding too: the comparison above is a memcmp)
                 cache->vertices = s.h_vertices; cache->normals = s.h_normals; cache->indices = s.h_indices;
                 cache->result = s.edge_build;
             }

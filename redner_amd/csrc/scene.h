@@ -42,6 +42,7 @@ struct EdgeData;   // edges.h
 
 struct Scene {
     int gpu_index = 0;
+    unsigned build_flags = 0;      // rdr_build_flags in force when the Scene was created (tuning.h)
     bool use_primary_edges = false, use_secondary_edges = false;
     int max_generic_texture_dimension = 0;
     bool has_textures = false;     // some reflectance / roughness is an image, or a normal map is present
@@ -86,6 +87,7 @@ struct Scene {
     ~Scene();
 };
 
+void drop_edge_cache();          // releases the edge structures kept for the next Scene (rdr_trim_cache)
 Scene *create_scene(const rdr_camera_desc *camera,
                     const rdr_shape_desc *shapes, int num_shapes,
                     const rdr_material_desc *materials, int num_materials,

@@ -10,9 +10,11 @@ Two exceptions: the PCG sampler, whose state depends on th
 textures rendered with primary edge sampling, where the reference's scratch carries ray differentials from sample to sample
 -- a block that starts at sample k > 0 draws a few of its edge samples' texture levels differently (same estimator).
 
-Communication: one all_gather of the partial image after forward and one all_gather per gradient
-tensor after backward (image 12.6 MB at 1024^2, bunny_box gradients < 0.1 MB), followed by a
-sum in FIXED rank order, so the result is bit-identical on every rank and from run to run.
+Communication: ONE all_gather of the partial image after forward and ONE after backward for all gradient
+tensors together (a flat bucket; image 12.6 MB at 1024^2, bunny_box gradients < 0.1 MB), each followed by a
+sum in FIXED rank order, so the result is bit-identical on every rank and from run to run.  A caller that
+has both in hand (bench.py: forward + backward per step) folds them into a single collective
+(`_all_gather_sum_many([image] + gradients)`).
 `render_blocked` renders the same blocks sequentially on one device with the same summation
 order, which is the bit-exact single-GPU counterpart of an R-rank run.
 """
@@ -33,6 +35,12 @@ def _all_gather_sum(t, group):
     world = dist.get_world_size(group)
     if world == 1:
         return t
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        # rehearsals of the multi-rank path on fewer GPUs than ranks (tests, RDR_BENCH_SHARE_GPU): gloo gathers host tensors
+        host = t.detach().cpu().contiguous()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        return _ordered_sum([p.to(t.device) for p in parts])
     parts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(parts, t.contiguous(), group=group)
     return _ordered_sum(parts)

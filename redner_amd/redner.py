@@ -15,6 +15,7 @@ Errors raise RuntimeError instead of aborting the process (the reference: assert
 """
 import ctypes as C
 import enum
+import sys
 import struct
 import zlib
 
@@ -328,6 +329,7 @@ class Scene:                           # src/redner.cpp:62-73
                  use_primary_edge_sampling, use_secondary_edge_sampling):
         lib = _capi.lib()
         self._lib = lib
+        _use_torch_stream(lib, use_gpu)
         self.camera = camera
         sh = (_capi.ShapeDesc * max(len(shapes), 1))(*[s._desc for s in shapes])
         mt = (_capi.MaterialDesc * max(len(materials), 1))(*[m._to_desc() for m in materials])
@@ -374,6 +376,8 @@ class RenderOptions:                   # src/redner.cpp:207-216 (+ sample_offset
         self.sample_pixel_center = bool(sample_pixel_center)
         self.sample_offset = 0
         self.total_samples = 0
+        # rdr_tuning (redner_amd extension; every field 0 = the library's default): e.g. options.tuning.batch_samples = 1
+        self.tuning = _capi.Tuning()
 
     def _to_desc(self):
         d = _capi.RenderOptionsDesc()
@@ -382,6 +386,7 @@ class RenderOptions:                   # src/redner.cpp:207-216 (+ sample_offset
         d.channels, d.num_channels = self._ch, len(self.channels)
         d.sampler_type, d.sample_pixel_center = self.sampler_type, int(self.sample_pixel_center)
         d.sample_offset, d.total_samples = int(self.sample_offset), int(self.total_samples)
+        d.tuning = C.pointer(self.tuning)
         return d
 
 
@@ -397,11 +402,37 @@ def render(scene, options, rendered_image, d_rendered_image, d_scene, screen_gra
     """redner.render(...)  src/redner.cpp:257 -- forward iff rendered_image != 0, backward iff
     d_rendered_image != 0."""
     od = options._to_desc()
+    _use_torch_stream(scene._lib, scene.use_gpu)
     ds = C.byref(d_scene._desc) if d_scene is not None else None
     rc = scene._lib.rdr_render(scene._handle, C.byref(od), _addr(rendered_image), _addr(d_rendered_image), ds,
                                _addr(screen_gradient_image), _addr(debug_image))
     if rc != 0:
         raise RuntimeError('redner.render: ' + _capi.last_error())
+
+
+def _use_torch_stream(lib, use_gpu):
+    """The library orders its launches on the calling thread's CURRENT torch stream (rdr_set_stream): tensors produced
+    under `with torch.cuda.stream(s):` are read after their producers without a device-wide synchronisation.  (The
+    reference's kernels run on the null stream, which torch's default stream is.)"""
+    if not use_gpu:
+        return
+    torch = sys.modules.get('torch')
+    stream = 0
+    if torch is not None and torch.cuda.is_available():
+        stream = int(torch.cuda.current_stream().cuda_stream)
+    lib.rdr_set_stream(stream or None)
+
+
+def set_pool_cap_mb(megabytes):
+    """Not in the reference: bound of the library's buffer cache per device (default min(a quarter of the device, 16 GiB)).
+    A dedicated render process may raise it (e.g. 65536) so that the buffers of a 2^24-lane sample batch stay parked
+    between calls; negative = back to the default."""
+    _capi.lib().rdr_set_pool_cap_mb(int(megabytes))
+
+
+def set_build_flags(flags):
+    """Not in the reference: rdr_build_flags (_capi.BUILD_*) for the Scenes created from now on (debugging / tests)."""
+    _capi.lib().rdr_set_build_flags(int(flags))
 
 
 def trim_cache():

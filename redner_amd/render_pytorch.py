@@ -18,6 +18,7 @@ unmodified pyredner package can be used instead: `redner_amd.install()` (see INT
 tests pass the oracle build of the reference here to render the same scene with both.
 """
 import math
+import os
 import weakref
 from typing import List, Optional
 
@@ -135,13 +136,21 @@ class _Unpacked:
 
 
 # serialize_scene() asserts that every floating-point scene tensor is finite, like pyredner (render_pytorch.py:194-270: one
-# torch.isfinite(...).all() -- two kernels and a synchronisation -- per tensor and call).  An optimisation loop passes the same
-# tensor OBJECTS every iteration and changes a few of them in place; a tensor that was finite at its current version is not
-# looked at again (weak references: a new tensor object is always checked, whatever storage it reuses).
+# torch.isfinite(...).all() -- two kernels and a synchronisation -- per tensor and call).  Here the device tensors of a call
+# are checked by ONE multi-tensor kernel and one read-back, every call.  The only tensors that are not looked at again are
+# LARGE device tensors that do not require a gradient (a static mesh, a fixed image texture: not what a loop writes to) and
+# were finite at their current `_version`.  `_version` does not see writes through `.data`, through a numpy alias
+# (torch.from_numpy) or by a foreign kernel through data_ptr() -- `p.data.clamp_()` on a PARAMETER is common in pyredner
+# scripts -- which is why parameters (requires_grad) and small tensors are never skipped; REDNER_AMD_FINITE_CACHE=0 makes
+# every call check everything.
 _finite_seen = {}            # id(tensor) -> (weak reference to it, version at which it was found finite)
+_FINITE_CACHE_MIN_ELEMS = 1 << 16
+_finite_cache_on = os.environ.get('REDNER_AMD_FINITE_CACHE', '1') != '0'
 
 
 def _known_finite(t):
+    if not _finite_cache_on or t.requires_grad or t.numel() < _FINITE_CACHE_MIN_ELEMS or t.device.type == 'cpu':
+        return False
     e = _finite_seen.get(id(t))
     return e is not None and e[0]() is t and e[1] == t._version
 
@@ -160,8 +169,9 @@ class RenderFunction(torch.autograd.Function):
     @staticmethod
     def serialize_scene(scene: Scene, num_samples, max_bounces, channels: Optional[List] = None,
                         sampler_type=None, use_primary_edge_sampling=True, use_secondary_edge_sampling=True,
-                        sample_pixel_center=False, device: Optional[torch.device] = None, backend=None):
-        """Flatten a scene into [meta, tensor, tensor, ...] for RenderFunction.apply."""
+                        sample_pixel_center=False, device: Optional[torch.device] = None, backend=None, tuning=None):
+        """Flatten a scene into [meta, tensor, tensor, ...] for RenderFunction.apply.
+        `tuning` (redner_amd extension): dict of rdr_tuning fields (include/redner_amd.h), e.g. {'batch_samples': 1}."""
         backend = backend or _default_backend
         if device is None:
             device = torch.device('cuda:%d' % torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
@@ -185,7 +195,6 @@ class RenderFunction(torch.autograd.Function):
             if t.is_floating_point() and not _known_finite(t):
                 if t.device.type == 'cpu':
                     assert torch.isfinite(t).all()
-                    _remember_finite(t)
                 else:
                     to_check.append(t)
             tensors.append(t.to(dev).contiguous())
@@ -197,6 +206,8 @@ class RenderFunction(torch.autograd.Function):
         meta = {'backend': backend, 'device': device, 'num_samples': num_samples, 'max_bounces': max_bounces,
                 'channels': list(channels), 'sampler_type': sampler_type,
                 'sample_pixel_center': sample_pixel_center}
+        if tuning:
+            meta['tuning'] = dict(tuning)
         cm = {}
         for name in ('position', 'look_at', 'up', 'cam_to_world', 'world_to_cam', 'intrinsic_mat_inv', 'intrinsic_mat',
                      'distortion_params'):
@@ -251,7 +262,8 @@ class RenderFunction(torch.autograd.Function):
                 peaks = torch.stack(torch._foreach_norm(live, float('inf')))
                 assert bool(torch.isfinite(peaks).all()), 'serialize_scene: a scene tensor holds non-finite values'
             for t in to_check:
-                _remember_finite(t)
+                if not t.requires_grad and t.numel() >= _FINITE_CACHE_MIN_ELEMS:
+                    _remember_finite(t)
         return [meta] + tensors
 
     @staticmethod
@@ -326,6 +338,9 @@ class RenderFunction(torch.autograd.Function):
                            meta['use_primary_edge_sampling'], meta['use_secondary_edge_sampling'])
         u.options = rd.RenderOptions(seed[0], meta['num_samples'][0], meta['max_bounces'], meta['channels'],
                                      meta['sampler_type'], meta['sample_pixel_center'])
+        for k, v in meta.get('tuning', {}).items():      # rdr_tuning (redner_amd extension; the reference's options have none)
+            if hasattr(u.options, 'tuning'):
+                setattr(u.options.tuning, k, v)
         if 'sample_offset' in meta:             # multi-GPU sample sharding (redner_amd extension)
             u.options.sample_offset = meta['sample_offset'][0]
             u.options.total_samples = meta['total_samples'][0]

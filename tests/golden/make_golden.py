@@ -330,6 +330,10 @@ SELFDIFF_CASES = set(CONFIG_CASES) | {'bunny_box_96x96x8'}
 # BASELINE config 4's own frame (1024 x 1024, max_bounces 4) at 1 spp: the 12.6 MB image is not committed -- its SHA-256 (the
 # forward image is bit-identical to the oracle's in every case), 16 x 16 block sums of it, and the bunny's vertex gradient are.
 FULL_FRAME_CASE = ('bunny_box_1024x1024x1', ('bunny_box', 1024, 1, 4))
+# ... and at 16 spp: 16.8 M lanes = ONE 16-sample batch of the GPU build (2^24 lanes) -- the launch shape bench.py times
+# (15.3 M-ray queues, the refilling traversal kernel, per-sample segment tables of the secondary-edge sampler).  ~10 min of
+# oracle time on 8 cores.
+FULL_FRAME_CASES = dict([FULL_FRAME_CASE, ('bunny_box_1024x1024x16', ('bunny_box', 1024, 16, 4))])
 
 
 def full_frame_digest(out):
@@ -339,6 +343,15 @@ def full_frame_digest(out):
     blocks = img.astype(np.float64).reshape(h // 16, 16, w // 16, 16, c).sum(axis=(1, 3))
     return {'image_sha256': np.frombuffer(hashlib.sha256(img.tobytes()).digest(), dtype=np.uint8).copy(), 'image_block_sums': blocks,
             'grad_shape6_vertices': out['grad_shape6_vertices']}
+
+def full_frame_check(backend, name, device):
+    """-> (image equal bit for bit?, largest block-sum difference, rel-L2 of the bunny's vertex gradient); also used by bench.py"""
+    gold = np.load(os.path.join(HERE, name + '.npz'))
+    mine = full_frame_digest(render_case(backend, *FULL_FRAME_CASES[name], device=device))
+    blocks_err = float(np.abs(mine['image_block_sums'] - gold['image_block_sums']).max())
+    g, m = gold['grad_shape6_vertices'].astype(np.float64), mine['grad_shape6_vertices'].astype(np.float64)
+    return bool(np.array_equal(mine['image_sha256'], gold['image_sha256'])), blocks_err, float(np.linalg.norm(m - g) / np.linalg.norm(g))
+
 
 # ---- ref64: the oracle's estimator with the fp32 accumulation error taken out ------------------------------------------------
 # Few-element gradient tensors (light intensity, constant reflectances, camera, the 3 + 4 vertices of two_triangles) collect
@@ -393,10 +406,12 @@ def main():
         export_bunny_box()
     ref = oracle_util.load_oracle()
     only = [a for a in sys.argv[1:] if not a.startswith('--')]
-    if '--full-frame' in sys.argv:
-        name, case = FULL_FRAME_CASE
-        np.savez_compressed(os.path.join(HERE, name + '.npz'), **full_frame_digest(render_case(ref, *case)))
-        print(name, 'written')
+    if '--full-frame' in sys.argv:                     # python make_golden.py --full-frame [case ...]
+        for name, case in FULL_FRAME_CASES.items():
+            if only and name not in only:
+                continue
+            np.savez_compressed(os.path.join(HERE, name + '.npz'), **full_frame_digest(render_case(ref, *case)))
+            print(name, 'written', flush=True)
         return
     if '--ref256' in sys.argv:
         for name in only:

@@ -46,6 +46,8 @@ constexpr bool kDeviceEdgeTrees = false;      // the harness has no kernels: the
 inline void device_sync() {}
 inline size_t pool_cached_bytes() { return 0; }
 inline size_t memory_available() { return ~(size_t)0; }
+inline double memory_held_by_others() { return 0.0; }
+inline void pool_set_cap(long long) {}
 inline int current_device() { return 0; }
 inline void upload_async(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void upload_flush() {}
@@ -91,6 +93,7 @@ inline void launch_persistent(Count c, const W &w) {          // see hip/exec.h:
 
 // ---- host stand-ins for the hand-written kernels (compact.hip / trace.hip) ----------------------
 #include "bvh.h"
+#include "tuning.h"
 #include "trace_sim.h"
 namespace exec {
 inline void select_device(int /*use_gpu*/, int /*gpu_index*/) {}
@@ -123,7 +126,7 @@ inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits,
         if (!(r.tmax < 0.f)) {
             float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
             int stack[rt::kTraverseStack];
-            static const bool binary = std::getenv("RDR_TRACE_BINARY") != nullptr;
+            const bool binary = rdr::tuning().has(RDR_TUNE_TRACE_BINARY);
             if (bvh.wide && !binary) {            // like the GPU build: the 4-wide records when the hierarchy has them
                 int wstack[64];
                 if (bvh.wide_stack_need > 64) throw std::runtime_error("wide hierarchy deeper than the harness stack");

@@ -3,7 +3,9 @@
   config 2   two_triangles 256 x 256 x 64 spp, max_bounces 1          (tests/test_two_triangles.py:11-55,72-79)
   config 3   bunny_box 512 x 512, max_bounces 4 (tests/test_bunny_box.py:25-32), in the reduced form section 8d
              prescribes: the full frame at 8 spp, and a full-resolution 128 x 128 viewport tile at the full 128 spp
-  config 4   the same scene at 1024 x 1024: the full frame at 1 spp (image by hash, vertex gradient)
+  config 4   the same scene at 1024 x 1024: the full frame at 1 spp and at 16 spp (image by hash, vertex gradient); 16 spp =
+             16.8 M lanes = one 16-sample batch: the launch shape bench.py times (15.3 M-ray queues, refilling traversal kernel,
+             per-sample segment tables), against the oracle rather than against the library's own one-sample-at-a-time render
 
 Forward image and every gradient tensor (bunny vertices incl. both edge estimators, light, materials, camera)."""
 import os
@@ -12,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden.make_golden import CONFIG_CASES, FULL_FRAME_CASE, full_frame_digest, render_case
+from golden.make_golden import CONFIG_CASES, FULL_FRAME_CASES, full_frame_check, render_case
 from parity_util import GOLD, assert_parity, compare, record
 
 
@@ -32,15 +34,19 @@ def test_config_fixtures_present():
 
 
 @pytest.mark.gpu
-def test_config4_frame_gpu(gpu_backend):
-    """BASELINE config 4's own frame -- bunny_box 1024 x 1024, max_bounces 4 -- at 1 spp against the oracle: the image bit for bit
-    (SHA-256 of its bytes; 16 x 16 block sums for the diagnosis), the bunny's vertex gradient (both edge estimators) to 1e-4."""
-    name, case = FULL_FRAME_CASE
-    gold = np.load(os.path.join(GOLD, name + '.npz'))
-    mine = full_frame_digest(render_case(gpu_backend, *case, device=torch.device('cuda:0')))
-    blocks_err = np.abs(mine['image_block_sums'] - gold['image_block_sums']).max()
-    assert np.array_equal(mine['image_sha256'], gold['image_sha256']), 'image differs from the oracle (largest block-sum difference %.3e)' % blocks_err
-    g, m = gold['grad_shape6_vertices'].astype(np.float64), mine['grad_shape6_vertices'].astype(np.float64)
-    e = np.linalg.norm(m - g) / np.linalg.norm(g)
-    record(name, {'grad_shape6_vertices': {'rel_l2': float(e), 'tol': 1e-4, 'flipped_rows': 0}, 'image': {'rel_l2': 0.0, 'tol': 0.0, 'flipped_rows': 0}}, 'gpu')
+@pytest.mark.parametrize('name', list(FULL_FRAME_CASES))
+def test_config4_frame_gpu(gpu_backend, name):
+    """BASELINE config 4's own frame -- bunny_box 1024 x 1024, max_bounces 4 -- at 1 spp and at 16 spp (one 16-sample batch)
+    against the oracle: the image bit for bit (SHA-256 of its bytes; 16 x 16 block sums for the diagnosis), the bunny's vertex
+    gradient (both edge estimators) to 1e-4."""
+    same, blocks_err, e = full_frame_check(gpu_backend, name, torch.device('cuda:0'))
+    assert same, 'image differs from the oracle (largest block-sum difference %.3e)' % blocks_err
+    record(name, {'grad_shape6_vertices': {'rel_l2': e, 'tol': 1e-4, 'flipped_rows': 0}, 'image': {'rel_l2': 0.0, 'tol': 0.0, 'flipped_rows': 0}}, 'gpu')
     assert e < 1e-4, e
+
+
+def test_full_frame_fixtures_present():
+    for name in FULL_FRAME_CASES:
+        z = np.load(os.path.join(GOLD, name + '.npz'))
+        assert z['image_sha256'].shape == (32,) and z['grad_shape6_vertices'].shape[1] == 3
+

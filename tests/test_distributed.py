@@ -62,3 +62,62 @@ def test_two_rank_gloo_equals_single_process(hostsim_backend, tmp_path):
     f_img, f_g0, f_g1 = single(lambda a: RenderFunction.apply(3, *a))
     assert np.allclose(z['image'], f_img, rtol=2e-6, atol=1e-7)   # un-sharded: only the fp32 sum order differs
     assert np.allclose(z['g0'], f_g0, rtol=1e-5, atol=1e-6) and np.allclose(z['g1'], f_g1, rtol=1e-5, atol=1e-6)
+
+
+GPU_WORKER = r'''
+import os, sys
+sys.path[:0] = [%(root)r, %(root)r + '/tests']
+import numpy as np, torch, torch.distributed as dist
+from redner_amd import _capi
+_capi.load()                                     # the product library
+assert _capi.library_path().endswith('libredner_amd.so')
+from redner_amd import redner
+from redner_amd.render_pytorch import RenderFunction
+from redner_amd.distributed import render_sharded
+import scenes
+torch.cuda.set_device(0)                         # both ranks share the one GPU of the box
+dist.init_process_group('gloo')
+dev = torch.device('cuda:0')
+sc = scenes.bunny_box(dev, resolution=(96, 96))
+args = RenderFunction.serialize_scene(sc, 8, 4, sampler_type=redner.SamplerType.sobol, device=dev)
+img = render_sharded(3, args)
+img.sum().backward()
+torch.cuda.synchronize()
+if dist.get_rank() == 0:
+    g = {'g%%d' %% i: s.vertices.grad.cpu().numpy() for i, s in enumerate(sc.shapes) if s.vertices.grad is not None}
+    np.savez(%(out)r, image=img.detach().cpu().numpy(), **g)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_equal_blocked_render(gpu_backend, tmp_path):
+    """Two ranks under torch.distributed.run through render_sharded -- each renders its sample block with the product library,
+    image and gradients meet in the fixed-order all_gather sums -- on the ONE GPU of the test box (gloo; with a GPU per rank the
+    backend is nccl = RCCL and nothing else changes): the image equals render_blocked(..., 2) bit for bit, gradients to 1e-6."""
+    from redner_amd.render_pytorch import RenderFunction
+    from redner_amd.distributed import render_blocked
+    import scenes
+    out = str(tmp_path / 'dist_gpu.npz')
+    script = tmp_path / 'worker_gpu.py'
+    script.write_text(GPU_WORKER % {'root': ROOT, 'out': out})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    subprocess.check_call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                           '--master-addr', '127.0.0.1', '--master-port', '29519', str(script)], env=env, timeout=600)
+    z = np.load(out)
+    rd = gpu_backend
+    dev = torch.device('cuda:0')
+    sc = scenes.bunny_box(dev, resolution=(96, 96))
+    args = RenderFunction.serialize_scene(sc, 8, 4, sampler_type=rd.SamplerType.sobol, device=dev)
+    img = render_blocked(3, args, 2)
+    img.sum().backward()
+    assert np.array_equal(z['image'], img.detach().cpu().numpy())
+    for i, s in enumerate(sc.shapes):
+        if s.vertices.grad is None:
+            continue
+        g, m = s.vertices.grad.double().cpu().numpy(), z['g%d' % i].astype(np.float64)
+        assert np.linalg.norm(m - g) <= 1e-6 * max(np.linalg.norm(g), 1e-30), i

@@ -297,3 +297,35 @@ def test_gradient_store_spills_into_the_large_tier_hostsim(hostsim_backend):
         seen += n > 0
         assert np.linalg.norm(g - r) <= 1e-4 * n + 1e-12
     assert seen >= 10            # patches of both tiers received gradients
+
+
+def _nonfinite_through_data(backend, device):
+    """pyredner asserts isfinite on every serialize_scene (render_pytorch.py:194-270); a value written through `.data` or a
+    numpy alias does not bump `_version`, so no version-keyed cache may hide it (advisor finding, round 3)."""
+    sc = scenes.two_triangles(device, resolution=(16, 16))
+    kw = dict(sampler_type=backend.SamplerType.sobol, device=device, backend=backend)
+    RenderFunction.serialize_scene(sc, 1, 1, **kw)
+    RenderFunction.serialize_scene(sc, 1, 1, **kw)
+    v = sc.shapes[0].vertices
+    v.data[0, 0] = float('nan')                      # what `p.data.clamp_()`-style loops do: no version bump
+    with pytest.raises(AssertionError):
+        RenderFunction.serialize_scene(sc, 1, 1, **kw)
+    v.data[0, 0] = 0.0
+    # a big static tensor (no gradient): cached by version, and an in-place write through the tensor itself is seen
+    big = torch.zeros(300, 300, 3, device=device)
+    from redner_amd.render_pytorch import Texture
+    sc.materials[0].diffuse_reflectance = Texture([big])
+    RenderFunction.serialize_scene(sc, 1, 1, **kw)
+    RenderFunction.serialize_scene(sc, 1, 1, **kw)
+    big[5, 5, 0] = float('inf')
+    with pytest.raises(AssertionError):
+        RenderFunction.serialize_scene(sc, 1, 1, **kw)
+
+
+def test_nonfinite_written_through_data_is_caught_hostsim(hostsim_backend):
+    _nonfinite_through_data(hostsim_backend, torch.device('cpu'))
+
+
+@pytest.mark.gpu
+def test_nonfinite_written_through_data_is_caught_gpu(gpu_backend):
+    _nonfinite_through_data(gpu_backend, torch.device('cuda:0'))

@@ -24,6 +24,20 @@ from redner_amd.render_pytorch import Camera, Shape, Material, AreaLight, Scene,
 
 pytestmark = pytest.mark.skipif(not oracle_util.oracle_available(), reason='oracle not built')
 
+# Where `redner_amd` renders: the CPU harness (build container) or cuda:0 (the GPU leg, `_main(..., gpu=True)`).  Scenes are
+# always BUILT on the CPU -- leaf tensors and their gradients live there -- and serialize_scene() moves the data to the device
+# of the backend that renders it; the oracle always renders on the CPU.
+MINE_DEVICE = torch.device('cpu')
+ON_GPU = False
+
+
+def _sdev(backend):
+    return MINE_DEVICE if getattr(backend, '__name__', '').startswith('redner_amd') else torch.device('cpu')
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
 
 def _scene(seed, device):
     rng = np.random.RandomState(seed)
@@ -63,7 +77,7 @@ def _scene(seed, device):
 def _render(backend, seed, spp, mb, stripe=None):
     dev = torch.device('cpu')
     sc = _scene(seed, dev)
-    args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=backend.SamplerType.sobol, device=dev, backend=backend)
+    args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=backend.SamplerType.sobol, device=_sdev(backend), backend=backend)
     img = RenderFunction.apply(seed, *args)
     h, w, _ = img.shape
     yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
@@ -72,8 +86,8 @@ def _render(backend, seed, spp, mb, stripe=None):
         keep = torch.zeros(h * w)
         keep[stripe[0]::stripe[1]] = 1
         up = up * keep.reshape(h, w, 1)
-    (img * up).sum().backward()
-    out = {'image': img.detach().numpy()}
+    (img * up.to(img.device)).sum().backward()
+    out = {'image': _np(img)}
     for i, s in enumerate(sc.shapes):
         if s.vertices.grad is not None:
             out['shape%d' % i] = s.vertices.grad.numpy()
@@ -184,8 +198,12 @@ def _render_rich(backend, seed, spp, mb, pixel_center, stripe=None):
     dev = torch.device('cpu')
     sc = _scene_rich(seed, dev)
     sampler = backend.SamplerType.independent if seed % 4 == 3 else backend.SamplerType.sobol      # PCG32 every fourth scene
-    args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=sampler, device=dev, backend=backend,
-                                          sample_pixel_center=pixel_center)
+    # Fisheye / panorama primary rays go through sin / cos, whose last bit differs between the device's libm and glibc, and the
+    # hierarchical edge pick is chaotic in the shading position: on the GPU those cameras are compared
+    # without the secondary-edge estimator (both backends), like the *_nosec fixtures.
+    sec = not (ON_GPU and sc.camera.camera_type in (2, 3))
+    args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=sampler, device=_sdev(backend), backend=backend,
+                                          sample_pixel_center=pixel_center, use_secondary_edge_sampling=sec)
     img = RenderFunction.apply(seed, *args)
     h, w, _ = img.shape
     yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
@@ -194,8 +212,8 @@ def _render_rich(backend, seed, spp, mb, pixel_center, stripe=None):
         keep = torch.zeros(h * w)
         keep[stripe[0]::stripe[1]] = 1
         up = up * keep.reshape(h, w, 1)
-    (img * up).sum().backward()
-    out = {'image': img.detach().numpy()}
+    (img * up.to(img.device)).sum().backward()
+    out = {'image': _np(img)}
     for i, s in enumerate(sc.shapes):
         for n in ('vertices', 'normals', 'uvs'):
             t = getattr(s, n)
@@ -299,7 +317,7 @@ def _render_mesh(backend, seed, spp, mb, stripe=None):
     if rng.rand() < 0.3:
         names = names[1:] + names[:1]                 # radiance last
     ch = [getattr(backend.channels, c) for c in names]
-    args = RenderFunction.serialize_scene(sc, spp, mb, channels=ch, sampler_type=backend.SamplerType.sobol, device=dev, backend=backend)
+    args = RenderFunction.serialize_scene(sc, spp, mb, channels=ch, sampler_type=backend.SamplerType.sobol, device=_sdev(backend), backend=backend)
     img = RenderFunction.apply(seed, *args)
     h, w, c = img.shape
     yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
@@ -309,8 +327,8 @@ def _render_mesh(backend, seed, spp, mb, stripe=None):
         keep = torch.zeros(h * w)
         keep[stripe[0]::stripe[1]] = 1
         up = up * keep.reshape(h, w, 1)
-    (img * up).sum().backward()
-    out = {'image': img.detach().numpy()}
+    (img * up.to(img.device)).sum().backward()
+    out = {'image': _np(img)}
     for i, s in enumerate(sc.shapes):
         for n in ('vertices', 'uvs', 'colors'):
             t = getattr(s, n)
@@ -331,7 +349,7 @@ def _render_mesh(backend, seed, spp, mb, stripe=None):
     return out
 
 
-MESH_SEEDS = range(1, 121, int(os.environ.get('FUZZ_STRIDE', '1')))
+MESH_SEEDS = range(1 + int(os.environ.get('FUZZ_OFFSET', '0')), 121, int(os.environ.get('FUZZ_STRIDE', '1')))
 def _scene_odd(seed, device):
     """Corners of the interface: triangles that cross the camera's near plane or lie behind it, a viewport on a perspective
     camera, lights that are not directly visible, a rotated environment map that may be invisible to the camera."""
@@ -365,7 +383,7 @@ def _render_odd(backend, seed, spp, mb, stripe=None):
     dev = torch.device('cpu')
     sc = _scene_odd(seed, dev)
     sampler = backend.SamplerType.independent if seed % 3 == 0 else backend.SamplerType.sobol
-    args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=sampler, device=dev, backend=backend)
+    args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=sampler, device=_sdev(backend), backend=backend)
     img = RenderFunction.apply(seed, *args)
     h, w, _ = img.shape
     yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
@@ -374,8 +392,8 @@ def _render_odd(backend, seed, spp, mb, stripe=None):
         keep = torch.zeros(h * w)
         keep[stripe[0]::stripe[1]] = 1
         up = up * keep.reshape(h, w, 1)
-    (img * up).sum().backward()
-    out = {'image': img.detach().numpy()}
+    (img * up.to(img.device)).sum().backward()
+    out = {'image': _np(img)}
     for i, s in enumerate(sc.shapes):
         if s.vertices.grad is not None:
             out['shape%d' % i] = s.vertices.grad.numpy()
@@ -394,7 +412,7 @@ def _render_odd(backend, seed, spp, mb, stripe=None):
     return out
 
 
-ODD_SEEDS = range(1, 121, int(os.environ.get('FUZZ_STRIDE', '1')))
+ODD_SEEDS = range(1 + int(os.environ.get('FUZZ_OFFSET', '0')), 121, int(os.environ.get('FUZZ_STRIDE', '1')))
 def _blob(rng, subdiv):
     """A deformed icosphere with shared vertices (hundreds of silhouette / crease candidates for the edge hierarchies)."""
     t = (1 + 5 ** 0.5) / 2
@@ -441,7 +459,7 @@ def _render_blob(backend, seed, stripe=None):
     cam = Camera(position=torch.tensor([0.0, 0.8, -5.0], requires_grad=True), look_at=torch.tensor([0.0, 0.0, 0.0]),
                  up=torch.tensor([0.0, 1.0, 0.0]), fov=torch.tensor([45.0]), clip_near=1e-2, resolution=(32, 32))
     sc = Scene(cam, [blob, floor, light], mats, [AreaLight(2, torch.tensor([25.0, 25.0, 25.0], requires_grad=True), two_sided=True)])
-    args = RenderFunction.serialize_scene(sc, 2, 2 + seed % 2, sampler_type=backend.SamplerType.sobol, device=dev, backend=backend)
+    args = RenderFunction.serialize_scene(sc, 2, 2 + seed % 2, sampler_type=backend.SamplerType.sobol, device=_sdev(backend), backend=backend)
     img = RenderFunction.apply(seed, *args)
     h, w, _ = img.shape
     yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing='ij')
@@ -450,19 +468,28 @@ def _render_blob(backend, seed, stripe=None):
         keep = torch.zeros(h * w)
         keep[stripe[0]::stripe[1]] = 1
         up = up * keep.reshape(h, w, 1)
-    (img * up).sum().backward()
-    return {'image': img.detach().numpy(), 'blob': blob.vertices.grad.numpy(), 'floor': floor.vertices.grad.numpy(),
+    (img * up.to(img.device)).sum().backward()
+    return {'image': _np(img), 'blob': blob.vertices.grad.numpy(), 'floor': floor.vertices.grad.numpy(),
             'mat0': mats[0].diffuse_reflectance.mipmap[0].grad.numpy(), 'mat1': mats[1].diffuse_reflectance.mipmap[0].grad.numpy(),
             'light0': sc.area_lights[0].intensity.grad.numpy(), 'cam_position': cam.position.grad.numpy()}
 
 
 STRIDE = int(os.environ.get('FUZZ_STRIDE', '1'))       # the variant runs below take every third scene
-PLAIN_SEEDS, RICH_SEEDS = range(1, 201, STRIDE), range(1, 161, STRIDE)
+FIRST = 1 + int(os.environ.get('FUZZ_OFFSET', '0'))     # ... the GPU legs every eighth, each from another first seed
+PLAIN_SEEDS, RICH_SEEDS = range(FIRST, 201, STRIDE), range(FIRST, 161, STRIDE)
 
 
-def _main(hostsim_lib):
+def _main(lib):
+    """lib = path of the CPU harness build, or 'gpu': the product library on cuda:0 (the GPU leg)."""
+    global MINE_DEVICE, ON_GPU
     from redner_amd import _capi
-    _capi.load(hostsim_lib)
+    if lib == 'gpu':
+        assert torch.cuda.is_available(), 'the GPU leg needs a GPU'
+        _capi.load()
+        assert _capi.library_path().endswith('libredner_amd.so')
+        MINE_DEVICE, ON_GPU = torch.device('cuda:0'), True
+    else:
+        _capi.load(lib)
     from redner_amd import redner
     oracle = oracle_util.load_oracle()
     failures = {}
@@ -492,7 +519,7 @@ def _main(hostsim_lib):
         bad = _compare(mine, ref, lambda st: _render_odd(oracle, seed, spp, mb, st))
         if bad:
             failures['odd %d' % seed] = bad
-    for seed in range(1, 25, STRIDE):             # 80- and 320-triangle blobs above a floor
+    for seed in range(FIRST, 25, STRIDE):             # 80- and 320-triangle blobs above a floor
         ref, mine = _render_blob(oracle, seed), _render_blob(redner, seed)
         bad = _compare(mine, ref, lambda st: _render_blob(oracle, seed, st))
         if bad:
@@ -500,7 +527,7 @@ def _main(hostsim_lib):
     # an optimisation loop: the same connectivity with moved vertices (hierarchies refitted, edge structures rebuilt), then only
     # materials / lights changed (edge structures shared with the previous Scene), then the camera moved -- every step against
     # the oracle, which builds everything from scratch each time
-    for seed in range(1, 21, STRIDE):
+    for seed in range(FIRST, 21, STRIDE):
         for step in range(6):
             outs = []
             for backend in (oracle, redner):
@@ -516,10 +543,10 @@ def _main(hostsim_lib):
                         sc.area_lights[0].intensity.mul_(float(rng.uniform(0.5, 1.5)))
                     if step in (4, 5):
                         sc.camera.position += torch.tensor(rng.normal(0, 0.1, 3).astype(np.float32))
-                args = RenderFunction.serialize_scene(sc, 2, 2, sampler_type=backend.SamplerType.sobol, device=torch.device('cpu'), backend=backend)
+                args = RenderFunction.serialize_scene(sc, 2, 2, sampler_type=backend.SamplerType.sobol, device=_sdev(backend), backend=backend)
                 img = RenderFunction.apply(seed, *args)
                 img.sum().backward()
-                o = {'image': img.detach().numpy(), 'cam_position': sc.camera.position.grad.numpy(), 'light0': sc.area_lights[0].intensity.grad.numpy()}
+                o = {'image': _np(img), 'cam_position': sc.camera.position.grad.numpy(), 'light0': sc.area_lights[0].intensity.grad.numpy()}
                 for i, sh in enumerate(sc.shapes[:-1]):
                     o['shape%d' % i] = sh.vertices.grad.numpy()
                 outs.append(o)
@@ -528,7 +555,7 @@ def _main(hostsim_lib):
                 failures['loop %d step %d' % (seed, step)] = bad
     # degenerate geometry: a triangle with two coinciding corners, with collinear corners, and two identical triangles
     # (coplanar, overlapping: the closest-hit tie rule and the edge list's merging of duplicate edges)
-    for seed in range(1, 61, STRIDE):
+    for seed in range(FIRST, 61, STRIDE):
         outs = []
         for backend in (oracle, redner):
             rng = np.random.RandomState(400 + seed)
@@ -542,10 +569,10 @@ def _main(hostsim_lib):
                     v[2] = 0.5 * (v[0] + v[1])
                 elif v.shape[0] >= 6:
                     v[3:6] = v[0:3]
-            args = RenderFunction.serialize_scene(sc, 3, 2, sampler_type=backend.SamplerType.sobol, device=torch.device('cpu'), backend=backend)
+            args = RenderFunction.serialize_scene(sc, 3, 2, sampler_type=backend.SamplerType.sobol, device=_sdev(backend), backend=backend)
             img = RenderFunction.apply(seed, *args)
             img.sum().backward()
-            o = {'image': img.detach().numpy(), 'cam_position': sc.camera.position.grad.numpy()}
+            o = {'image': _np(img), 'cam_position': sc.camera.position.grad.numpy()}
             for i, sh in enumerate(sc.shapes[:3]):
                 o['shape%d' % i] = sh.vertices.grad.numpy()
             outs.append(o)
@@ -564,7 +591,7 @@ def _main(hostsim_lib):
     # levels for a few edge samples than the single call does (another draw of the same estimator; measured here: vertex
     # gradients 0.5-2 % apart on 20 x 22 frames with a normal map and 4-6 samples, nothing without mip levels).
     from redner_amd.distributed import render_blocked
-    for seed in range(1, 41, STRIDE):
+    for seed in range(FIRST, 41, STRIDE):
         blocks = 2 + seed % 2
         outs = []
         for backend, R in ((oracle, None), (redner, blocks)):
@@ -572,10 +599,10 @@ def _main(hostsim_lib):
             for m in sc.materials:
                 m.normal_map = m.generic_texture = None
             args = RenderFunction.serialize_scene(sc, 2 * blocks, 1 + seed % 2, sampler_type=backend.SamplerType.sobol,
-                                                  device=torch.device('cpu'), backend=backend)
+                                                  device=_sdev(backend), backend=backend)
             img = render_blocked(seed, args, R) if R else RenderFunction.apply(seed, *args)
             img.sum().backward()
-            o = {'image': img.detach().numpy(), 'cam_position': sc.camera.position.grad.numpy()}
+            o = {'image': _np(img), 'cam_position': sc.camera.position.grad.numpy()}
             for i, sh in enumerate(sc.shapes):
                 if sh.vertices.grad is not None:
                     o['shape%d' % i] = sh.vertices.grad.numpy()
@@ -589,15 +616,16 @@ def _main(hostsim_lib):
         if bad:
             failures['blocks %d' % seed] = bad
     # screen-space gradient images (RenderFunction.visualize_screen_gradient, tests/test_screen_gradient.py)
-    for seed in range(1, 41, STRIDE):
-        kw = dict(num_samples=2 + seed % 3, max_bounces=seed % 3, device=torch.device('cpu'),
+    for seed in range(FIRST, 41, STRIDE):
+        kw = dict(num_samples=2 + seed % 3, max_bounces=seed % 3,
                   sampler_type=(oracle.SamplerType.independent if seed % 2 else oracle.SamplerType.sobol))
         imgs = []
         for backend in (oracle, redner):
             kw['sampler_type'] = backend.SamplerType.independent if seed % 2 else backend.SamplerType.sobol
             sc = _scene_mesh(seed, torch.device('cpu')) if seed % 4 == 0 else _scene(seed, torch.device('cpu'))
             ch = [backend.channels.radiance] if seed % 3 else [backend.channels.diffuse_reflectance]
-            imgs.append(RenderFunction.visualize_screen_gradient(None, seed, sc, channels=ch, backend=backend, **kw).numpy())
+            imgs.append(RenderFunction.visualize_screen_gradient(None, seed, sc, channels=ch, backend=backend, device=_sdev(backend),
+                                                                 **kw).cpu().numpy())
         n = np.linalg.norm(imgs[0].astype(np.float64))
         d = np.linalg.norm(imgs[1].astype(np.float64) - imgs[0].astype(np.float64))
         if not d <= 1e-4 * n + 1e-9:
@@ -622,6 +650,28 @@ def test_random_scenes_hostsim_vs_oracle(hostsim_backend, variant):
         env.pop(k, None)
     env.update(dict(kv.split('=') for kv in variant.split()))
     out = subprocess.check_output([sys.executable, os.path.abspath(__file__), HOSTSIM_LIB], env=env, timeout=1500).decode()
+    line = [l for l in out.splitlines() if l.startswith('FUZZ ')][-1]
+    assert json.loads(line[5:]) == {}
+
+
+# The GPU leg: the product library on cuda:0 against the live oracle (oracle/_ref travels to the GPU box), every eighth scene of
+# every family above, under the default schedule (sample batches, specialised kernels, side streams), with ragged batches, and
+# with the refilling traversal kernel forced onto every queue (it normally serves queues of >= 2^22 lanes only: bench.py's).
+GPU_KEYS = ('RDR_BATCH', 'RDR_FORCE_GENERAL', 'FUZZ_STRIDE', 'FUZZ_OFFSET', 'RDR_BATCH_LANES', 'RDR_TRACE_REFILL_ALL', 'RDR_NO_OVERLAP',
+            'RDR_TRACE_REFILL', 'RDR_WORKERS')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('variant', ['FUZZ_STRIDE=8', 'RDR_BATCH=3 FUZZ_STRIDE=8 FUZZ_OFFSET=3',
+                                     'RDR_TRACE_REFILL_ALL=1 FUZZ_STRIDE=8 FUZZ_OFFSET=5'])
+def test_random_scenes_gpu_vs_oracle(gpu_backend, variant):
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MALLOC_MMAP_THRESHOLD_='1024',
+               PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get('PYTHONPATH', '')]))
+    for k in GPU_KEYS:
+        env.pop(k, None)
+    env.update(dict(kv.split('=') for kv in variant.split()))
+    out = subprocess.check_output([sys.executable, os.path.abspath(__file__), 'gpu'], env=env, timeout=900).decode()
     line = [l for l in out.splitlines() if l.startswith('FUZZ ')][-1]
     assert json.loads(line[5:]) == {}
 
