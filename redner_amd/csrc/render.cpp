@@ -55,7 +55,7 @@ VSlice make_slice(Arena &a, int n, bool with_occl) {
     v.thr = a.get<double>((size_t)3 * n);
     v.mrough = a.get<double>(n);
     v.occl = with_occl ? a.get<unsigned char>(n) : nullptr;
-    v.erd = nullptr;
+    v.erd = nullptr; v.erd_touched = nullptr; v.erd_seg = nullptr; v.erd_S = 0; v.erd_P0 = 0;
     return v;
 }
 
@@ -363,6 +363,18 @@ struct Backward {
                 // the reference's buffer is a fresh allocation per render call; fresh pages read as zero
                 ea.erd = eb.erd = arena.get<double>((size_t)12 * L);
                 exec::zero(ea.erd, sizeof(double) * 12 * L);
+                if (batch.on) {
+                    // chain mode (see run_sample, "primary edges"): one copy of that buffer per sample of the batch, which
+                    // entries the batch has written, the state that travels from sample to sample, and the lanes that need it
+                    chain_n = 2 * batch.P0;
+                    ea.erd_touched = eb.erd_touched = arena.get<unsigned char>(L);
+                    erd_chain = arena.get<double>((size_t)12 * chain_n);
+                    exec::zero(erd_chain, sizeof(double) * 12 * chain_n);
+                    deferred = arena.get<int>(L);
+                    deferred_seg = arena.get<int>(kMaxBatch + 1);
+                    deferred_count = arena.get<int>(kMaxBatch);
+                    prim_dyn = arena.get<int>(kMaxBatch);
+                }
             }
             for (int k = 0; k < 3; ++k) elist[k] = arena.get<int>(L);
             nee_slots = arena.get<int>(P);
@@ -383,6 +395,11 @@ struct Backward {
             // only written on hits; lanes that reach the environment light read what an earlier hit left there,
             // like the reference's never-cleared edge_surface_points (src/pathtracer.cpp:594-600); fresh pages are 0
             exec::zero(hit_pos, sizeof(double) * 3 * L);
+            if (batch.on && scene.d.envmap != nullptr) {          // see HitPosView (stages_edge.h)
+                hp_written = arena.get<unsigned char>(L);
+                hp_violations = arena.get<int>(1);
+                exec::zero(hp_violations, sizeof(int));
+            }
             prim_recs = arena.get<PrimaryEdgeRec>(P);
             sec_recs = arena.get<SecondaryEdgeRec>(P);
             sec_picks = arena.get<SecPick>(P);
@@ -396,6 +413,13 @@ struct Backward {
     }
 
     VSlice ea, eb;                 // ping-pong vertex slices of the edge sub-paths (2P lanes each)
+    // chain mode: sample batches of a scene with mip levels (run_sample, "primary edges")
+    int chain_n = 0;                   // entries of the reference's differential buffer: 2 x pixels
+    double *erd_chain = nullptr;       // [12 x chain_n] what the last finished sample left in it
+    int *deferred = nullptr, *deferred_seg = nullptr, *deferred_count = nullptr, *prim_dyn = nullptr;
+    bool chain_mode() const { return erd_chain != nullptr; }
+    // the secondary-edge pass of depth d numbers its lanes by rank in the batch's list: map them to the samples' own entries
+    void erd_view(const int *seg) { ea.erd_seg = eb.erd_seg = seg; ea.erd_S = eb.erd_S = cur_S; ea.erd_P0 = eb.erd_P0 = batch.P0; }
     int *elist[3] = {nullptr, nullptr, nullptr};
     HLeaf *h_leaves = nullptr, *h_spill = nullptr;   // hierarchical pick: recorded leaves / spilled stack entries per list position
     GatherShared gshared{nullptr, nullptr, nullptr, nullptr, 0, 0};     // heavy slots of the gather: big candidate lists, subtree work items
@@ -404,6 +428,10 @@ struct Backward {
     exec::Fence depth_begin, adjoint_done, setup_done, walk_done, picks_begin, pickh_done;
     const bool overlap = overlap_on();
     double *edge_contrib = nullptr, *edge_tmin = nullptr, *hit_pos = nullptr;
+    unsigned char *hp_written = nullptr; int *hp_violations = nullptr;
+    HitPosView hit_view(const int *seg) const {
+        return HitPosView{hit_pos, ea.n, hp_written ? seg : nullptr, cur_S, batch.P0, hp_written, hp_violations};
+    }
     PrimaryEdgeRec *prim_recs = nullptr;
     SecondaryEdgeRec *sec_recs = nullptr;
     SecPick *sec_picks = nullptr;
@@ -472,8 +500,11 @@ struct Backward {
     // device-side counter advances in the compaction that closes a bounce which had lanes (`edim` is the host-known part).
     // `seg`: the edge lanes are 2 x compacted rank (+ side) of the samples' live-lane lists (secondary-edge pass of that depth);
     // null: 2 x slot (+ side) with P0 slots per sample (primary-edge pass).
+    // `dyn`: the per-sample dimension counters to read and advance (default: edge_dyn; the sequential part of a chain-mode
+    // primary pass runs on its own copy)
     void trace_edge_paths(const SamplerD &rng_edge, int edim, exec::Count n_act, exec::Count n_slots, int first_depth, const Queues &q,
-                          const Sink &sink, bool need_lights, const int *seg = nullptr) {
+                          const Sink &sink, bool need_lights, const int *seg = nullptr, int *dyn = nullptr) {
+        if (!dyn) dyn = edge_dyn;
         const bool has_lights = sd.num_lights > 0;
         if (need_lights && !has_lights) return;
         int cur = 1;
@@ -481,10 +512,10 @@ struct Backward {
             const VSlice &m = (k % 2 == 0) ? ea : eb;
             const VSlice &nx = (k % 2 == 0) ? eb : ea;
             int nxt = (cur == 1) ? 2 : 1;
-            exec::Count next = run_bounce(scene, sd, edge_rng_at(rng_edge, edim, nullptr, seg), edim, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt],
-                                          batch.on ? nullptr : edge_dyn, 7);
+            exec::Count next = run_bounce(scene, sd, edge_rng_at(rng_edge, edim, dyn, seg), edim, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt],
+                                          batch.on ? nullptr : dyn, 7);
             // a batch: the counter of every sample that had lanes in this bounce (the list is ascending in the lane id)
-            if (batch.on) exec::launch(cur_S, BumpDynList{edge_dyn, elist[cur], n_act.dev, n_act.upper, seg, 2 * batch.P0, 7});
+            if (batch.on) exec::launch(cur_S, BumpDynList{dyn, elist[cur], n_act.dev, n_act.upper, seg, 2 * batch.P0, 7});
             edge_rng_consumed(n_slots, 7, n_act.dev);
             n_act = next;
             cur = nxt;
@@ -509,6 +540,8 @@ struct Backward {
         // see trace_edge_paths)
         int edim = 0;
         if (edge_dyn) exec::zero(edge_dyn, sizeof(int) * kMaxBatch);
+        if (chain_mode()) exec::zero(ea.erd_touched, (size_t)ea.n);          // nothing of this batch's samples is in their copies yet
+        if (hp_written) exec::zero(hp_written, (size_t)ea.n);
         // (the whole buffers: they are component-major with the buffers' lane count as the stride, so the first 3 x n_lanes
         //  doubles of a batch that is smaller than the buffers -- the last one of a call -- are not its lanes' records)
         exec::zero(adj.thr, sizeof(double) * 3 * stride);
@@ -657,6 +690,7 @@ struct Backward {
             if (with_edges) {
                 // ---- secondary (shadow / inter-reflection) edges at this vertex, :500-706 ----
                 const exec::Count lanes = exec::scaled_count(nA, 2);
+                if (chain_mode()) erd_view(seg_of(d));
                 const SecEdgeArgs sa = early_here ? early_sa : start_picks(d, edim, nullptr, false, side);
                 join_picks();
                 debug_dump("sec_mode", sample_id, d, sec_mode, (size_t)nA.upper);
@@ -669,13 +703,13 @@ struct Backward {
                 exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
                 exec::launch(n0, RecordHits{elist[0], ea, q.h_bsdf});
                 if (ea.erd) exec::launch(n0, MirrorSurfDiff{sd, elist[0], ea});
-                launch_v(lean, nA, SecondaryEdgeWeights{sd, sec_recs, ea, hit_pos});
+                launch_v(lean, nA, SecondaryEdgeWeights{sd, sec_recs, ea, hit_view(seg_of(d))});
                 exec::zero(edge_contrib, sizeof(double) * lanes.upper);
                 launch_v(lean, n0, ShadeRecorded{sd, elist[0], ea, esink});
                 const exec::Count n1 = exec::compact_dev(elist[0], n0, elist[1], KeepHit{ea.shape});
                 trace_edge_paths(rng_edge, edim, n1, nA, d + 1, q, esink, false, seg_of(d));
                 if (side) adjoint_done.gate(main_stream);          // the only stage of the edge pass that touches the adjoint records
-                exec::launch(nA, SecondaryEdgeDerivatives{sd, grads.g, act, sec_recs, hit_pos, ea.n, edge_contrib, adj});
+                exec::launch(nA, SecondaryEdgeDerivatives{sd, grads.g, act, sec_recs, hit_view(seg_of(d)), edge_contrib, adj});
             }
         }
         // the camera-vertex adjoint runs beside the primary-edge pass unless both would add to the screen-gradient image
@@ -697,17 +731,47 @@ struct Backward {
             const EdgeSceneD &es = scene.edges->d;
             const int lanes = 2 * P;
             exec::zero(edge_contrib, sizeof(double) * lanes);
-            launch_v(lean, P, SamplePrimaryEdges{sd, es, edge_rng_at(rng_edge, edim), edim, d_image, nd, radiance_dim, prim_recs, ea, multipliers});
+            erd_view(nullptr);                  // primary-edge lanes 2 (s P0 + slot) + side ARE entry 2 slot + side of sample s's copy
+            SamplePrimaryEdges spe{sd, es, edge_rng_at(rng_edge, edim), edim, d_image, nd, radiance_dim, prim_recs, ea, multipliers};
+            if (chain_mode()) spe.batch_P0 = batch.P0;
+            launch_v(lean, P, spe);
             edim += 2;
             edge_rng_consumed_n(P, 2);
             const exec::Count n0 = exec::compact_dev((const int *)nullptr, lanes, elist[0], KeepNonZeroDir{ea.ray, ea.n});
-            if (ea.erd) exec::launch(n0, LoadLaneDiff{elist[0], ea});
-            exec::launch(n0, QueueRays{elist[0], ea, nullptr, q.bsdf});
-            exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n0, false);
-            launch_v(lean, n0, ShadePrimary{sd, elist[0], ea, q.h_bsdf, psink});
-            if (ea.erd) exec::launch(n0, MirrorSurfDiff{sd, elist[0], ea});
-            const exec::Count n1 = exec::compact_dev(elist[0], n0, elist[1], KeepHit{ea.shape});
-            trace_edge_paths(rng_edge, edim, n1, P, 0, q, esink, true);
+            // the sub-paths of the lanes listed in `list` (its length: `n`), from the first intersection to the last bounce;
+            // `chain`: their differentials come from the state the previous sample left (else: from their own entries)
+            auto sub_paths = [&](int *list, exec::Count n, const double *chain, int *dyn) {
+                if (ea.erd) exec::launch(n, LoadLaneDiff{list, ea, chain, chain_n, 2 * batch.P0});
+                exec::launch(n, QueueRays{list, ea, nullptr, q.bsdf});
+                exec::trace(scene.bvh, q.bsdf, q.h_bsdf, n, false);
+                launch_v(lean, n, ShadePrimary{sd, list, ea, q.h_bsdf, psink});
+                if (ea.erd) exec::launch(n, MirrorSurfDiff{sd, list, ea});
+                const exec::Count n1 = exec::compact_dev(list, n, elist[1], KeepHit{ea.shape});
+                trace_edge_paths(rng_edge, edim, n1, P, 0, q, esink, true, nullptr, dyn);
+            };
+            if (!chain_mode()) {
+                sub_paths(elist[0], n0, nullptr, nullptr);
+            } else {
+                // Chain mode.  The reference's differential buffer is written per slot but read per lane, and most of what a
+                // lane reads there is left over from earlier stages -- of this sample, or of EARLIER samples (DESIGN.md section
+                // 1, "stale scratch"): for those lanes the samples of a batch depend on each other, one after the other.  So:
+                // (A) the lanes whose entry this sample wrote itself (its secondary passes, the slot-indexed write above) run
+                //     as one batch, every sample on its own copy of the buffer;
+                // (B) the others sample by sample: sample s reads the state sample s - 1 left (`erd_chain`: its copy where it
+                //     wrote, else what it found), runs its lanes, and leaves its state for sample s + 1.
+                // What a lane does depends on no other lane, so the split changes nothing but the order of launches; the
+                // dimension counters of (B) start from where the pass started (`prim_dyn`).
+                exec::copy_dev(prim_dyn, edge_dyn, sizeof(int) * kMaxBatch);
+                const exec::Count nA = exec::compact_dev(elist[0], n0, elist[2], KeepTouched{ea.erd_touched, 1});
+                const exec::Count nD = exec::compact_dev(elist[0], n0, deferred, KeepTouched{ea.erd_touched, 0});
+                exec::launch(cur_S + 1, SegOffsets{deferred, nD.dev, nD.upper, 2 * batch.P0, cur_S, deferred_seg});
+                sub_paths(elist[2], nA, nullptr, nullptr);
+                for (int k = 0; k < cur_S; ++k) {
+                    exec::launch(2 * batch.P0, ExtractSegment{deferred, deferred_seg, k, elist[0], deferred_count + k});
+                    sub_paths(elist[0], exec::Count(deferred_count + k, 2 * batch.P0), erd_chain, prim_dyn);
+                    exec::launch(chain_n, ChainAdvance{erd_chain, chain_n, ea.erd, ea.n, ea.erd_touched, k});
+                }
+            }
             launch_v(lean, P, PrimaryEdgeDerivatives{sd, grads.g, prim_recs, edge_contrib, screen_grad});
         }
         if (adj_primary_aside) adjoint_done.gate(exec::ctx().stream);      // the next sample clears the adjoint records
@@ -716,8 +780,45 @@ struct Backward {
 
 } // namespace
 
+namespace {
+// A batched gradient render of an environment-lit scene found an edge ray that needs what EARLIER samples left in the
+// reference's hit-position scratch (HitPosView, stages_edge.h): nothing has been written to the caller's tensors yet (the
+// accumulators are folded into them at the very end) -- the call starts over, one sample per launch.
+struct RestartUnbatched {};
+// ... and scenes of that shape start that way the next time (an optimisation loop builds a Scene per iteration)
+std::atomic<uint64_t> g_unbatchable{0};
+uint64_t scene_shape_key(const Scene &scene) {
+    uint64_t h = 1469598103934665603ULL;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ULL; };
+    mix(scene.shapes.size());
+    for (const ShapeD &sh : scene.shapes) { mix((uint64_t)sh.num_vertices); mix((uint64_t)sh.num_triangles); }
+    mix(scene.materials.size()); mix(scene.lights.size());
+    mix((uint64_t)scene.h_envmap.values.width[0]); mix((uint64_t)scene.h_envmap.values.height[0]);
+    return h | 1;
+}
+void render_once(const Scene &scene, const rdr_render_options &opt, float *image, const float *d_image,
+                 const rdr_dscene_desc *d_scene, float *screen_gradient_image, const Tuning &tune, bool envmap_batches);
+}
+
 void render(const Scene &scene, const rdr_render_options &opt, float *image, const float *d_image,
             const rdr_dscene_desc *d_scene, float *screen_gradient_image, float * /*debug_image*/) {
+    const Tuning tune = resolve_tuning(opt.tuning);
+    TuningScope tuning_scope(tune);
+    const bool envmap_edges = scene.d.envmap != nullptr && d_image != nullptr && (scene.use_primary_edges || scene.use_secondary_edges);
+    const uint64_t key = envmap_edges ? scene_shape_key(scene) : 0;
+    bool optimistic = envmap_edges && g_unbatchable.load(std::memory_order_relaxed) != key;
+    try {
+        render_once(scene, opt, image, d_image, d_scene, screen_gradient_image, tune, optimistic);
+    } catch (const RestartUnbatched &) {
+        exec::device_sync();
+        g_unbatchable.store(key, std::memory_order_relaxed);
+        render_once(scene, opt, image, d_image, d_scene, screen_gradient_image, tune, false);
+    }
+}
+
+namespace {
+void render_once(const Scene &scene, const rdr_render_options &opt, float *image, const float *d_image,
+                 const rdr_dscene_desc *d_scene, float *screen_gradient_image, const Tuning &tune, bool envmap_batches) {
     if (opt.sampler_type != RDR_SAMPLER_SOBOL && opt.sampler_type != RDR_SAMPLER_INDEPENDENT)
         throw std::runtime_error("render: unknown sampler type");
     if (d_image && !d_scene) throw std::runtime_error("render: d_rendered_image given without d_scene");
@@ -737,8 +838,6 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     const bool has_lights = scene.d.num_lights > 0;
     if (2 + 7 * B > kSamplerDims) throw std::runtime_error("render: max_bounces exceeds the Sobol' table");
 
-    const Tuning tune = resolve_tuning(opt.tuning);
-    TuningScope tuning_scope(tune);
     PhaseTimer timer(d_image ? "render (backward)" : "render (forward)");
     Arena arena;
     {
@@ -770,7 +869,14 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     // Without either edge estimator (a loop that moves materials, textures or lights only: pyredner switches them off when
     // neither the camera nor a vertex requires a gradient) there is no such scratch and every scene is batched.
     const bool no_edge_passes = !scene.use_primary_edges && !scene.use_secondary_edges;
-    const bool batchable = sobol_plain && (lean == kLean || no_edge_passes || (!scene.has_mipmaps && scene.d.envmap == nullptr));
+    // With mip levels (and no environment light) the samples of a batch depend on each other through the reference's
+    // differential scratch, lane by lane: "chain mode" (Backward::run_sample, "primary edges") batches what does not and runs the
+    // rest sample by sample.  One worker then: the chain runs through the batches in order.
+    const bool chain = scene.has_mipmaps && !no_edge_passes;
+    // Under an environment light there is a second scratch of that kind -- the hit positions of the edge rays, read stale by the
+    // rays that reach the environment (HitPosView, stages_edge.h) -- and no way to batch a lane that reads across samples
+    // there: such a call is batched optimistically (`envmap_batches`) and starts over unbatched if a lane did (render()).
+    const bool batchable = sobol_plain && (lean == kLean || no_edge_passes || scene.d.envmap == nullptr || envmap_batches);
     const bool samples_independent = batchable && d_image != nullptr && image == nullptr;
     // A forward render is batched too -- of any scene: the stale scratch belongs to the edge passes -- : its launches deposit
     // per lane into staging planes and ResolveBatchImage adds them to the image in the reference's order (one stream, batches
@@ -852,6 +958,7 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     }
     int workers = 1;
     if (samples_independent) workers = std::max(1, std::min(tune.workers > 0 ? tune.workers : exec::sample_workers(PL, num_batches, batch.on), num_batches));
+    if (chain && batch.on) workers = 1;
 
     // Everything one sample (or sample batch) needs between its camera rays and its last gradient add.
     struct Worker {
@@ -929,6 +1036,13 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
 
             if (d_image && !w.bwd) make_backward(w);       // first sample of this worker: the GPU is busy with the stages queued above
             if (w.bwd) w.bwd->run_sample(sample_id, rng, vs, active, num_active, q, lanes, PL, S_now, w.seg);
+            // an optimistic batch of an environment-lit scene: has a lane read across samples?  (Asked after the first and after
+            // the last batch of a worker: a scene whose edge rays escape shows it at once.)
+            if (w.bwd && w.bwd->hp_violations && (b == first || b + stride >= num_batches)) {
+                int bad = 0;
+                exec::download(&bad, w.bwd->hp_violations, sizeof(int));
+                if (bad > 0) throw RestartUnbatched();
+            }
             // every slot drew dim_first + 7 x (bounces that ran) numbers this sample
             if (pcg_main) exec::launch(P, PcgAdvance{pcg_main, dim_first, w.main_dyn, nullptr});
         }
@@ -963,5 +1077,6 @@ void render(const Scene &scene, const rdr_render_options &opt, float *image, con
     exec::sync();
     timer.lap("gradient flush");
 }
+} // namespace
 
 } // namespace rdr

@@ -98,14 +98,38 @@ struct MirrorSurfDiff {
         if (v.shape[p] < 0) return;
         RayDiff out;
         surf_at(sc.shapes[v.shape[p]], v.tri[p], load_ray(v, p), load_rdiff(v, p), out);
-        st_rdiff(v.erd, v.n, p, out);
+        st_erd(v, p, out);
     }
 };
+// `chain` (sample batches in chain mode, the sequential part): the lanes read the state the previous sample left -- entry
+// p % lanes_per_sample of the chain buffer -- instead of their own sample's entry.
 struct LoadLaneDiff {
-    const int *active; VSlice v;
+    const int *active; VSlice v; const double *chain; int chain_n, lanes_per_sample;
     RDR_FN void operator()(int idx) const {
         int p = active[idx];
-        store_rdiff(v, p, ld_rdiff(v.erd, v.n, p));
+        store_rdiff(v, p, chain ? ld_rdiff(chain, chain_n, p % lanes_per_sample) : ld_erd(v, p));
+    }
+};
+// Chain mode: after sample s of a batch, the state the next sample finds: entry l of the sample's copy where the sample
+// wrote it, else what was there before.
+struct ChainAdvance {
+    double *chain; int chain_n; const double *erd; int erd_n; const unsigned char *touched; int sample;
+    RDR_FN void operator()(int l) const {
+        const int i = sample * chain_n + l;
+        if (!touched[i]) return;
+        for (int k = 0; k < 12; ++k) chain[(size_t)k * chain_n + l] = erd[(size_t)k * erd_n + i];
+    }
+};
+// Chain mode: primary-edge lanes whose differential entry was written during this batch (by the sample's own secondary passes
+// or by the primary sampler's slot-indexed write) / the others
+struct KeepTouched { const unsigned char *touched; int want; RDR_FN bool operator()(int p) const { return (touched[p] != 0) == (want != 0); } };
+// dst[i] = src[seg[s] + i] for the lanes of sample s; the count lands in *count_out
+struct ExtractSegment {
+    const int *src; const int *seg; int s; int *dst; int *count_out;
+    RDR_FN void operator()(int i) const {
+        const int b = seg[s], e = seg[s + 1];
+        if (i == 0) *count_out = e - b;
+        if (i < e - b) dst[i] = src[b + i];
     }
 };
 struct FillDouble { double *p; double value; RDR_FN void operator()(int i) const { p[i] = value; } };
@@ -116,6 +140,7 @@ struct SamplePrimaryEdges {
     const float *d_image; int nd, radiance_dim;
     PrimaryEdgeRec *recs; VSlice v;       // lanes 2*slot, 2*slot+1
     double *multipliers;                  // [2P x nd] per-channel weights of the two rays, or null
+    int batch_P0 = 0;                     // sample batches: slots per sample (0: one sample)
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); multipliers = nullptr; nd = 3; radiance_dim = 0; }
     RDR_FN void make_mid() { mid_scene(sc); multipliers = nullptr; nd = 3; radiance_dim = 0; }
     RDR_FN void operator()(int slot) const {
@@ -209,7 +234,8 @@ struct SamplePrimaryEdges {
         st3(v.thr, v.n, l0, 0, w_up);
         st3(v.thr, v.n, l1, 0, w_lo);
         if (!sc.no_diffs) primary_ray_with_diff(sc.cam, pt, rd);
-        if (v.erd) st_rdiff(v.erd, v.n, slot, rd);            // [quirk] slot-indexed; lanes read theirs in LoadLaneDiff
+        // [quirk] slot-indexed; lanes read theirs in LoadLaneDiff.  (A batch: slot s * P0 + k is entry k of sample s's copy.)
+        if (v.erd) st_erd(v, batch_P0 > 0 ? slot + (slot / batch_P0) * batch_P0 : slot, rd);
         else { store_rdiff(v, l0, rd); store_rdiff(v, l1, rd); }
     }
 };
@@ -1210,7 +1236,7 @@ struct SecEdgeFinish {
             brd.dir_dy = ddy - 2 * (-dot(wi, h) * c.sp.dn_dy + ddn_dy * h);
         }
         store_rdiff(ev, l0, brd); store_rdiff(ev, l1, brd);
-        if (ev.erd) { st_rdiff(ev.erd, ev.n, l0, brd); st_rdiff(ev.erd, ev.n, l1, brd); }
+        if (ev.erd) { st_erd(ev, l0, brd); st_erd(ev, l1, brd); }
         V3 nt = ld3(a.v.thr, a.v.n, p, 0) * f * dc * ew / s.nee_pmf;
         st3(ev.thr, ev.n, l0, 0, nt);
         st3(ev.thr, ev.n, l1, 0, -nt);
@@ -1227,8 +1253,26 @@ RDR_FN V3 isect_jacobian(V3 org, V3 dir, V3 p, V3 n, V3 l) {
     return t * (l - dir * (dot(l, n) / dot(dir, n)));
 }
 
+// Where the edge rays of a secondary pass hit: written on hits only, and read by SecondaryEdgeDerivatives for every lane that
+// carries radiance -- for a lane that reached the ENVIRONMENT light that is whatever an earlier pass left at its index, like the
+// reference's never-cleared edge_surface_points (src/pathtracer.cpp:584-600, 702)  [quirk].  A sample batch keeps one copy
+// per sample (lane 2 (rank) + side of the batch's list -> entry 2 (rank within the sample) + side of sample s, via `seg`), and
+// marks what the batch has written: a read of an entry the SAME sample has not written during this batch would need what
+// earlier samples left there -- it is counted, and render() then renders the call again one sample at a time.
+struct HitPosView {
+    double *pos; int n;                          // 3 x n, stride n
+    const int *seg; int S, P0;                   // null / 0: one sample, lanes are entries
+    unsigned char *written; int *violations;     // null outside batches
+    RDR_FN int index(int lane) const {
+        if (!seg) return lane;
+        const int idx = lane >> 1;
+        int s = 0;
+        while (s + 1 < S && seg[s + 1] <= idx) ++s;
+        return lane + 2 * (s * P0 - seg[s]);
+    }
+};
 struct SecondaryEdgeWeights {
-    SceneD sc; const SecondaryEdgeRec *recs; VSlice ev; double *hit_pos;   // hit_pos: 3 x n, stride ev.n
+    SceneD sc; const SecondaryEdgeRec *recs; VSlice ev; HitPosView hp;
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(ev); }
     RDR_FN void make_mid() { mid_scene(sc); }
     RDR_FN void scale_lane(const SecondaryEdgeRec &rec, int l) const {
@@ -1244,7 +1288,11 @@ struct SecondaryEdgeWeights {
         }
         RayDiff tmp;
         Surf hp = surf_at(sc.shapes[ev.shape[l]], ev.tri[l], load_ray(ev, l), load_rdiff(ev, l), tmp, !sc.no_diffs);
-        st3(hit_pos, ev.n, l, 0, hp.position);
+        {
+            const int hi = this->hp.index(l);
+            st3(this->hp.pos, this->hp.n, hi, 0, hp.position);
+            if (this->hp.written) this->hp.written[hi] = 1;
+        }
         V3 dir = hp.position - rec.sp_pos;
         double d2 = len_sq(dir);
         if (d2 < 1e-8f) { st3(ev.thr, ev.n, l, 0, v3(0)); return; }
@@ -1285,7 +1333,7 @@ struct SecondaryEdgeWeights {
 
 struct SecondaryEdgeDerivatives {
     SceneD sc; GScene g; const int *active; const SecondaryEdgeRec *recs;
-    const double *hit_pos; int n_lanes; const double *edge_contrib; AdjState adj;
+    HitPosView hp; const double *edge_contrib; AdjState adj;
     RDR_FN void operator()(int idx) const {
         const SecondaryEdgeRec &rec = recs[idx];
         if (rec.edge.shape_id < 0) return;
@@ -1295,7 +1343,9 @@ struct SecondaryEdgeDerivatives {
         for (int k = 0; k < 2; ++k) {
             double contrib = edge_contrib[2 * idx + k];
             if (contrib == 0) continue;
-            V3 x = ld3(hit_pos, n_lanes, 2 * idx + k, 0);
+            const int hi = hp.index(2 * idx + k);
+            if (hp.written && !hp.written[hi]) atomic_fetch_add(hp.violations, 1);      // (see HitPosView)
+            V3 x = ld3(hp.pos, hp.n, hi, 0);
             V3 pos = rec.sp_pos;
             V3 d0 = a - pos, d1 = b - pos;
             dp += (cross(d1, d0) + cross(x - pos, d1) + cross(d0, x - pos)) * contrib;   // Eq. 16 (errata)

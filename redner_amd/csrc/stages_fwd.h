@@ -41,8 +41,30 @@ struct VSlice {
     // left at its lane index.  Stages mirror every write the reference makes so that those stale
     // reads see the same values.  [quirk]
     double *erd;
+    // Sample batches of such scenes ("chain mode", render.cpp): the buffer belongs to one sample at a time in the reference, so
+    // the batch keeps one copy per sample -- entry l of sample s at s * 2 P0 + l, which is where the primary-edge lanes of a
+    // batch live anyway.  A secondary-edge pass of a batch numbers its lanes 2 x (rank in the batch's concatenated live-lane
+    // list) + side: `erd_seg` (where each sample's part of that list starts) maps them to the sample's own entries.
+    // `erd_touched` marks the entries written during the current batch: a primary-edge lane whose entry is not marked would
+    // read what EARLIER SAMPLES left there and is handed to the sequential part of the pass (render.cpp).
+    unsigned char *erd_touched;
+    const int *erd_seg; int erd_S, erd_P0;
 };
 RDR_FN void st_rdiff(double *b, int n, int i, const RayDiff &r);
+RDR_FN RayDiff ld_rdiff(const double *b, int n, int i);
+RDR_FN int erd_index(const VSlice &v, int p) {
+    if (!v.erd_seg) return p;
+    const int idx = p >> 1;
+    int s = 0;
+    while (s + 1 < v.erd_S && v.erd_seg[s + 1] <= idx) ++s;          // <= 16 samples per batch
+    return p + 2 * (s * v.erd_P0 - v.erd_seg[s]);
+}
+RDR_FN RayDiff ld_erd(const VSlice &v, int p) { return ld_rdiff(v.erd, v.n, erd_index(v, p)); }
+RDR_FN void st_erd(const VSlice &v, int p, const RayDiff &r) {
+    const int i = erd_index(v, p);
+    st_rdiff(v.erd, v.n, i, r);
+    if (v.erd_touched) v.erd_touched[i] = 1;
+}
 
 RDR_FN V3 ld3(const double *b, int n, int i, int k) { return V3{b[(size_t)(k) * n + i], b[(size_t)(k + 1) * n + i], b[(size_t)(k + 2) * n + i]}; }
 RDR_FN void st3(double *b, int n, int i, int k, V3 v) { b[(size_t)(k) * n + i] = v.x; b[(size_t)(k + 1) * n + i] = v.y; b[(size_t)(k + 2) * n + i] = v.z; }
@@ -102,7 +124,7 @@ struct Sink {
 // so after inlining the compiler drops the other camera models, the environment-light estimators and the
 // G-buffer channels -- and with them the registers (and scratch) those paths would pin.
 RDR_FN void lean_scene(SceneD &sc) { sc.envmap = nullptr; sc.cam.kind = kCamPerspective; sc.cam.distortion.defined = 0; sc.no_diffs = 1; sc.plain_materials = 1; }
-RDR_FN void lean_slice(VSlice &v) { v.rdiff = nullptr; v.erd = nullptr; }
+RDR_FN void lean_slice(VSlice &v) { v.rdiff = nullptr; v.erd = nullptr; v.erd_touched = nullptr; v.erd_seg = nullptr; }
 // "Mid" specialisation: pinhole camera without lens distortion, no environment light, radiance-only output -- but image
 // textures, mip levels (hence ray differentials), normal maps and vertex colours are all live.  What a textured scene lit by
 // area lights renders (BASELINE config 5's stand-in); the general stages carry three more camera models, the environment
@@ -365,12 +387,12 @@ struct BounceSample {
         V2 buv = v2(rng.draw(slot, dim + 4), rng.draw(slot, dim + 5));
         double bw = rng.draw(slot, dim + 6);
         // a sampler that bails out (one-sided surface seen from behind) leaves the differential untouched
-        RayDiff wo_rd = vn.erd ? ld_rdiff(vn.erd, vn.n, p) : raydiff_zero();
+        RayDiff wo_rd = vn.erd ? ld_erd(vn, p) : raydiff_zero();
         double next_mr;
         V3 dir = bsdf_sample_dir(*c.mat, c.sp, c.wi, buv, bw, c.mrough, c.rd_surf, wo_rd, next_mr, !sc.no_diffs);
         store_ray(vn, p, c.sp.position, dir);
         store_rdiff(vn, p, wo_rd);
-        if (vn.erd) st_rdiff(vn.erd, vn.n, p, wo_rd);
+        if (vn.erd) st_erd(vn, p, wo_rd);
         vn.mrough[p] = next_mr;
         Ray nr = make_ray(c.sp.position, dir);
         put_ray(q_bsdf, idx, nr, len_sq(dir) <= 1e-3f);
@@ -483,7 +505,7 @@ struct BounceContrib {
         if (hb.shape >= 0) {
             RayDiff tmp;
             bp = surf_at(sc.shapes[hb.shape], hb.prim, load_ray(vn, p), load_rdiff(vn, p), tmp, !sc.no_diffs);
-            if (vn.erd) st_rdiff(vn.erd, vn.n, p, tmp);
+            if (vn.erd) st_erd(vn, p, tmp);
         }
         V3 thr = ld3(v.thr, v.n, p, 0);
         BounceEval e = eval_bounce(sc, c, thr, !blocked, pk, lp, ld.uv, hb.shape, bp, load_ray(vn, p).dir);
