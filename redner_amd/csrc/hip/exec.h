@@ -177,6 +177,7 @@ size_t pool_cached_bytes();           // bytes parked in the free lists right no
 size_t memory_available();            // what a call can still get: free device memory + what is parked in the cache
 double memory_held_by_others();       // fraction of the device's memory that neither is free nor came from this pool (torch's allocator, other processes)
 void pool_set_cap(long long bytes);   // bound of the cache per device; negative = the default (rdr_set_pool_cap_mb)
+size_t pool_cap_bytes();              // that bound
 size_t pool_device_mallocs();          // number of hipMalloc calls made by the pool so far (tests: steady state adds none)
 inline std::atomic<size_t> &host_count_reads_ref() { static std::atomic<size_t> n{0}; return n; }
 inline size_t host_count_reads() { return host_count_reads_ref().load(); }     // live-lane counts read back by the host so far

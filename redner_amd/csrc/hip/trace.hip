@@ -65,6 +65,8 @@ size_t pool_cap(const Pool &pl) {
 }
 }
 
+size_t pool_cap_bytes() { Pool &pl = pool(); std::lock_guard<std::mutex> lk(pl.lock); return pool_cap(pl); }
+
 void pool_set_cap(long long bytes) {
     Pool &pl = pool();
     std::lock_guard<std::mutex> lk(pl.lock);

@@ -765,6 +765,9 @@ struct Backward {
                 const exec::Count nA = exec::compact_dev(elist[0], n0, elist[2], KeepTouched{ea.erd_touched, 1});
                 const exec::Count nD = exec::compact_dev(elist[0], n0, deferred, KeepTouched{ea.erd_touched, 0});
                 exec::launch(cur_S + 1, SegOffsets{deferred, nD.dev, nD.upper, 2 * batch.P0, cur_S, deferred_seg});
+                static const bool tell_chain = std::getenv("RDR_DEBUG_BATCH") != nullptr;
+                if (tell_chain) std::fprintf(stderr, "[render] chain mode: %d of %d primary-edge lanes need the previous sample's scratch (sequential part)\n",
+                                             exec::read_count(nD), exec::read_count(n0));
                 sub_paths(elist[2], nA, nullptr, nullptr);
                 for (int k = 0; k < cur_S; ++k) {
                     exec::launch(2 * batch.P0, ExtractSegment{deferred, deferred_seg, k, elist[0], deferred_count + k});
@@ -920,6 +923,16 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
             if (d_image) per_lane += 4.0 * lay.nd;
             return per_lane * lanes;
         };
+        // Buffers that do not fit the buffer cache (exec::pool_cap_bytes: 16 GiB unless the caller raised it) are allocated and
+        // released by EVERY call -- ~25 ms per GB on this runtime: a 32-spp gradient render of the config-5 stand-in in 16-sample
+        // batches (67 GB) ran at 12.4 Msamples/s against 28.6 in 4-sample batches (16.8 GB), and at 29.4 with a cache that holds
+        // the 67 GB (profiles/r4_notes.md).  A call of many batches pays that once per 8 + batches (the 256-spp benchmark: 64.4
+        // against 64.6 Msamples/s); a short one gets the batches that fit.
+        if (tune.batch_lanes == 0 && tune.mem_available_mb < 0) {
+            const double cap = (double)exec::pool_cap_bytes();
+            auto batches_at = [&](int S_try) { return (opt.num_samples + S_try - 1) / S_try; };
+            while (batch.S > 1 && bytes_needed(batch.S) > cap && batches_at(batch.S) < 8) batch.S = (batch.S + 1) / 2;
+        }
         if (tune.mem_available_mb >= 0 || bytes_needed(batch.S) > 1073741824.0) {        // small frames: not worth asking the driver
             const double room = 0.8 * (tune.mem_available_mb >= 0 ? tune.mem_available_mb * 1048576.0 : (double)exec::memory_available());      // (override: tests)
             while (batch.S > 1 && bytes_needed(batch.S) > room) batch.S = (batch.S + 1) / 2;

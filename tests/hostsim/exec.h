@@ -48,6 +48,7 @@ inline size_t pool_cached_bytes() { return 0; }
 inline size_t memory_available() { return ~(size_t)0; }
 inline double memory_held_by_others() { return 0.0; }
 inline void pool_set_cap(long long) {}
+inline size_t pool_cap_bytes() { return ~(size_t)0; }
 inline int current_device() { return 0; }
 inline void upload_async(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void upload_flush() {}

@@ -27,7 +27,7 @@ def compare(out, gold):
     reported (`single_pass_rel_l2`, next to `oracle_selfdiff`: how far the single pass moves under an equivalent evaluation
     order, and `ref64_convergence`: K = 16 vs K = 64 stripes)."""
     gold = {k: gold[k] for k in (gold.files if hasattr(gold, 'files') else gold)}
-    prefixes = ('selfdiff_', 'ref64_', 'ref64conv_', 'ref256_', 'ref256conv_')
+    prefixes = ('selfdiff_', 'ref64_', 'ref64conv_', 'ref256_', 'ref256conv_', 'ref16_')
     aux = {p: {k[len(p):]: v for k, v in gold.items() if k.startswith(p)} for p in prefixes}
     gold = {k: v for k, v in gold.items() if not k.startswith(prefixes)}
     for k, v in aux['ref256_'].items():              # a fixture with a finer striped sum: that one is the value compared with
@@ -62,6 +62,13 @@ def compare(out, gold):
                 entry['oracle_not_converged'] = True
         if k in aux['selfdiff_']:
             entry['oracle_selfdiff'] = float(aux['selfdiff_'][k])
+        if k in aux['ref16_']:
+            # a large tensor with a striped oracle sum (make_ref_rows.py): reported next to the single pass; rows are judged
+            # against it (the fp32 accumulation error of a hot vertex is not a different sample)
+            g16 = torch.from_numpy(np.asarray(aux['ref16_'][k]))
+            entry['rel_l2_vs_ref16'] = rel_l2(mine, g16)
+            entry['single_pass_vs_ref16'] = rel_l2(g, g16)
+            g = g16
         if k.endswith('_vertices') and g.dim() == 2 and g.shape[0] > ACCUMULATOR_ELEMS:
             row_err = (mine.double() - g.double()).norm(dim=1)
             entry['flipped_rows'] = int((row_err > 1e-5 * gn).sum())
