@@ -267,6 +267,11 @@ uint64_t rdr_trim_cache(void);
 typedef struct rdr_debug_counters { uint64_t device_mallocs, host_count_reads; } rdr_debug_counters;
 void rdr_debug_counters_get(rdr_debug_counters *out);
 
+/* Test hook: the triangle hierarchy the kernels of this Scene built (bvh_gpu.cpp) against the host builder's on the same
+ * arrays: the number of records that differ (0: identical), -1 when this Scene's hierarchy is a refit or was not built by
+ * kernels, -2 on error. */
+int rdr_debug_bvh_check(const rdr_scene *scene);
+
 /* Test hook: writes the edge list and both edge hierarchies (links, edge ids, weights, costs) as
  * text, for the build-order parity test against the reference (tests/test_edge_build.py). */
 int rdr_debug_dump_edges(const rdr_scene *scene, const char *path);

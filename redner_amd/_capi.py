@@ -129,7 +129,7 @@ class DebugCounters(C.Structure):
 EXPORTS = ('rdr_scene_create', 'rdr_scene_destroy', 'rdr_scene_max_generic_texture_dimension',
            'rdr_render', 'rdr_compute_num_channels', 'rdr_last_error',
            'rdr_trace_stats_enable', 'rdr_trace_stats_reset', 'rdr_trace_stats_get', 'rdr_scene_trace',
-           'rdr_debug_counters_get', 'rdr_trim_cache', 'rdr_debug_dump_edges',
+           'rdr_debug_counters_get', 'rdr_trim_cache', 'rdr_debug_dump_edges', 'rdr_debug_bvh_check',
            'rdr_set_stream', 'rdr_set_pool_cap_mb', 'rdr_set_build_flags')
 
 _lib = None
@@ -172,6 +172,8 @@ def load(path=None):
     lib.rdr_debug_counters_get.argtypes = [C.POINTER(DebugCounters)]
     lib.rdr_trim_cache.restype = C.c_uint64
     lib.rdr_trim_cache.argtypes = []
+    lib.rdr_debug_bvh_check.restype = C.c_int
+    lib.rdr_debug_bvh_check.argtypes = [C.c_void_p]
     lib.rdr_set_stream.restype = None
     lib.rdr_set_stream.argtypes = [C.c_void_p]
     lib.rdr_set_pool_cap_mb.restype = None

@@ -89,7 +89,9 @@ struct Builder {
             float ext = cb.hi[best_axis] - cb.lo[best_axis];
             float scale = kBins / ext;
             float lo = cb.lo[best_axis];
-            Prim *it = std::partition(prims + first, prims + first + count, [&](const Prim &p) {
+            // (stable: the order of a leaf's triangles is then a function of the input order alone, and equals the device
+            //  builder's ballot-ranked partition, bvh_gpu.cpp)
+            Prim *it = std::stable_partition(prims + first, prims + first + count, [&](const Prim &p) {
                 int bi = std::min(kBins - 1, std::max(0, (int)((p.c[best_axis] - lo) * scale)));
                 return bi <= best_bin;
             });

@@ -9,6 +9,8 @@
 #include <exception>
 #include <mutex>
 #include <string>
+#include <vector>
+#include <cstdlib>
 
 namespace {
 thread_local std::string g_last_error;
@@ -146,6 +148,55 @@ int rdr_debug_dump_edges(const rdr_scene *scene, const char *path) {
     }
     fclose(f);
     return 0;
+}
+
+/* Test hook: the hierarchy this Scene's kernels built against the host builder's (bvh.cpp) on the same mesh arrays -- node
+ * records, leaf order, triangle records, 4-wide records.  Returns the number of records that differ (0: identical), or -1
+ * when the Scene's hierarchy is a refit of an earlier build / was not built by kernels. */
+int rdr_debug_bvh_check(const rdr_scene *scene) {
+    try {
+        const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
+        if (!s.bvh_dev || s.bvh_dev->parent) return -1;
+        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+        exec::select_device(1, s.gpu_index);
+        use_caller_stream();
+        std::vector<rt::MeshView> meshes(s.shapes.size());
+        for (size_t i = 0; i < s.shapes.size(); ++i) meshes[i] = rt::MeshView{s.h_vertices[i].data(), s.h_indices[i].data(), s.shapes[i].num_triangles};
+        const rt::BvhHost h = rt::build_bvh(meshes);
+        const rt::BvhDev &d = *s.bvh_dev;
+        int bad = 0;
+        if ((int)h.nodes.size() != d.num_nodes || (int)h.ids.size() != 2 * d.num_slots || (int)h.wide.size() != d.num_wide ||
+            h.depth != d.depth || h.wide_stack_need != d.wide_stack_need)
+            return 1000000 + std::abs((int)h.nodes.size() - d.num_nodes);
+        std::vector<rt::Node> nodes(d.num_nodes);
+        std::vector<int> ids((size_t)2 * d.num_slots);
+        std::vector<float> tris((size_t)9 * d.num_slots);
+        std::vector<rt::Node4> wide(d.num_wide);
+        exec::download(nodes.data(), d.nodes, sizeof(rt::Node) * nodes.size());
+        exec::download(ids.data(), d.ids, sizeof(int) * ids.size());
+        exec::download(tris.data(), d.tris, sizeof(float) * tris.size());
+        exec::download(wide.data(), d.wide, sizeof(rt::Node4) * wide.size());
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            const rt::Node &a = nodes[i], &b = h.nodes[i];
+            bool same = a.a == b.a && a.b == b.b;
+            for (int k = 0; k < 3; ++k) same = same && a.lo[k] == b.lo[k] && a.hi[k] == b.hi[k];
+            bad += !same;
+        }
+        for (size_t i = 0; i < ids.size(); ++i) bad += ids[i] != h.ids[i];
+        for (size_t i = 0; i < tris.size(); ++i) bad += !(tris[i] == h.tris[i]);
+        for (size_t i = 0; i < wide.size(); ++i) {
+            const rt::Node4 &a = wide[i], &b = h.wide[i];
+            bool same = a.aux[0] == b.aux[0];
+            for (int k = 0; k < 4; ++k)
+                same = same && a.link[k] == b.link[k] && a.lox[k] == b.lox[k] && a.loy[k] == b.loy[k] && a.loz[k] == b.loz[k] &&
+                       a.hix[k] == b.hix[k] && a.hiy[k] == b.hiy[k] && a.hiz[k] == b.hiz[k];
+            bad += !same;
+        }
+        return bad;
+    } catch (const std::exception &e) {
+        set_error(e.what());
+        return -2;
+    }
 }
 
 int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, int num_rays, int any_hit) {

@@ -195,6 +195,7 @@ inline void copy_dev(void *dst, const void *src, size_t bytes) {          // dev
 }
 inline void sync() { check(hipStreamSynchronize(ctx().stream), "sync"); }
 constexpr bool kDeviceEdgeTrees = true;         // the edge hierarchies are built by kernels (edges_gpu.cpp)
+constexpr bool kDeviceBvh = true;               // ... and so is the triangle hierarchy (bvh_gpu.cpp)
 __host__ __device__ inline void gather_stats_add(long, long, int, int) {}      // a hook of the CPU debugging harness
 inline void device_sync() { (void)hipDeviceSynchronize(); }        // every stream of the device (error paths; never throws)
 // Batched transfers for the Scene build (trace.hip): every array goes through one pinned staging buffer, the copies are

@@ -1,6 +1,7 @@
 // scene.cpp -- Scene construction (see scene.h).
 #include "scene.h"
 #include "tuning.h"
+#include "bvh_gpu.h"
 #include "hostpool.h"
 #include "surface.h"
 #include "sobol.h"
@@ -360,11 +361,14 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     // A Scene with the index buffers of the previous one (an optimisation loop moves vertices, pyredner builds a Scene per
     // forward call, render_pytorch.py:609) keeps that hierarchy's topology and refits its boxes; hits do not depend on the
     // hierarchy (raytri.h), and it is rebuilt once its inner surface area has grown by more than 30 %.  RDR_BUILD_NO_REFIT: always build.
-    struct TopologyCache { std::vector<std::vector<int>> indices; rt::BvhHost bvh; };
+    // On the GPU build the hierarchy never exists on the host: bvh_gpu.cpp builds it from the caller's device arrays, or --
+    // same connectivity as the last build -- refits a copy of that build's records (below, once the shape table is uploaded).
+    struct TopologyCache { std::vector<std::vector<int>> indices; rt::BvhHost bvh; std::shared_ptr<rt::BvhDev> dev; int gpu_index = -1; };
     static TopologyCache *topo_cache = new TopologyCache();          // guarded by the API lock (capi.cpp)
     const bool refit_allowed = !(s.build_flags & RDR_BUILD_NO_REFIT);
     rt::BvhHost bvh_built;
     auto bvh_job = hostpool::run([&meshes, &bvh_built, &s, refit_allowed] {      // (joins in its destructor on an early exit)
+        if (exec::kDeviceBvh) return;
         bool same = refit_allowed && topo_cache->indices.size() == s.h_indices.size() && !topo_cache->bvh.nodes.empty();
         for (size_t i = 0; same && i < s.h_indices.size(); ++i) same = topo_cache->indices[i] == s.h_indices[i];
         if (same) {
@@ -487,7 +491,44 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         if (sync_edges || timer.on) s.edge_data();
     }
     timer.lap("edge structures");
-    {
+    if (exec::kDeviceBvh) {
+        bvh_job.wait();
+        // {vertices, indices} per shape, for the kernels that read the caller's arrays
+        std::vector<const void *> refs((size_t)2 * std::max(num_shapes, 1), nullptr);
+        size_t total = 0;
+        for (int i = 0; i < num_shapes; ++i) { refs[2 * i] = s.shapes[i].vertices; refs[2 * i + 1] = s.shapes[i].indices; total += (size_t)s.shapes[i].num_triangles; }
+        const void *d_refs = to_device(s, refs.data(), refs.size());
+        bool same = refit_allowed && topo_cache->dev && topo_cache->gpu_index == s.gpu_index && topo_cache->indices.size() == s.h_indices.size();
+        for (size_t i = 0; same && i < s.h_indices.size(); ++i) same = topo_cache->indices[i] == s.h_indices[i];
+        auto dev = std::make_shared<rt::BvhDev>();
+        bool built = false;
+        if (same) {
+            rt::refit_tri_bvh_device(*topo_cache->dev, d_refs, *dev);
+            dev->parent = topo_cache->dev;
+            double area = 0;
+            exec::upload_flush();                    // (the shape table above travels through the staging buffer)
+            exec::download(&area, dev->area, sizeof(double));
+            if (!(dev->inner_area > 0) || area / dev->inner_area > 1.3) dev = std::make_shared<rt::BvhDev>();      // gone stale: build
+            else built = true;
+        }
+        if (!built) {
+            std::vector<int> prim_ids;
+            prim_ids.reserve(2 * total);
+            for (int i = 0; i < num_shapes; ++i)
+                for (int t = 0; t < s.shapes[i].num_triangles; ++t) { prim_ids.push_back(i); prim_ids.push_back(t); }
+            rt::BvhBuildParams prm;
+            if (const char *e = std::getenv("RDR_BVH_BINS")) prm.bins = std::min(64, std::max(2, std::atoi(e)));
+            if (const char *e = std::getenv("RDR_BVH_TCOST")) prm.trav_cost = (float)std::atof(e);
+            if (const char *e = std::getenv("RDR_BVH_LEAF")) prm.leaf_max = std::min(4, std::max(1, std::atoi(e)));
+            rt::build_tri_bvh_device(d_refs, prim_ids.data(), (int)total, prm, *dev);
+            topo_cache->indices = s.h_indices;
+            topo_cache->dev = dev;
+            topo_cache->gpu_index = s.gpu_index;
+        }
+        s.bvh_dev = dev;
+        s.bvh = dev->view();
+        timer.lap("triangle hierarchy (device)");
+    } else {
         bvh_job.wait();
         s.bvh_host = std::move(bvh_built);
         s.bvh.num_nodes = (int)s.bvh_host.nodes.size();

@@ -10,6 +10,7 @@
 #pragma once
 #include "../../include/redner_amd.h"
 #include "bvh.h"
+#include "bvh_gpu.h"
 #include "scene_data.h"
 #include <string>
 #include <vector>
@@ -59,7 +60,8 @@ struct Scene {
     std::vector<std::vector<int>> h_indices, h_uv_indices, h_normal_indices;
     std::vector<double> light_pmf, light_cdf, light_areas, area_cdf_pool;
     std::vector<int> area_cdf_offset;
-    rt::BvhHost bvh_host;
+    rt::BvhHost bvh_host;                        // CPU debugging harness only: the GPU build keeps the hierarchy on the device
+    std::shared_ptr<rt::BvhDev> bvh_dev;         // (bvh_gpu.cpp)
 
     // device view
     SceneD d;

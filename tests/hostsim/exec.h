@@ -42,6 +42,7 @@ inline void upload(void *dst, const void *src, size_t bytes) { memcpy(dst, src, 
 inline void download(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void copy_dev(void *dst, const void *src, size_t bytes) { memcpy(dst, src, bytes); }
 inline void sync() {}
+constexpr bool kDeviceBvh = false;            // ... nor a device builder of the triangle hierarchy: bvh.cpp builds it
 constexpr bool kDeviceEdgeTrees = false;      // the harness has no kernels: the host builder of edges.cpp builds the edge hierarchies
 inline void device_sync() {}
 inline size_t pool_cached_bytes() { return 0; }

@@ -183,3 +183,56 @@ def test_gpu_traversal_kernel_forms(gpu_backend, env):
     r = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
     assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
+
+
+# ---- the hierarchy the kernels build (bvh_gpu.cpp) ----------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('builder', ['single_triangle', 'two_triangles', 'bunny_box', 'living_room_standin', 'triangle_soup_large'])
+def test_device_built_hierarchy_equals_host_builder(gpu_backend, builder):
+    """Binned SAH by kernels, level by level: node records, leaf order, triangle records and the 4-wide records equal what the
+    host builder (bvh.cpp) makes of the same arrays -- every record (rdr_debug_bvh_check downloads and compares)."""
+    from redner_amd import _capi
+    dev = torch.device('cuda:0')
+    gpu_backend.set_build_flags(_capi.BUILD_NO_REFIT)         # a fresh build, whatever the previous test left in the caches
+    try:
+        sc = getattr(scenes, builder)(dev, resolution=(16, 16))
+        args = RenderFunction.serialize_scene(sc, 1, 1, sampler_type=gpu_backend.SamplerType.sobol, device=dev)
+        u = RenderFunction.unpack_args((1, 2), args[0], args[1:])
+        assert _capi.lib().rdr_debug_bvh_check(u.scene._handle) == 0
+    finally:
+        gpu_backend.set_build_flags(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('any_hit', [0, 1])
+def test_refitted_hierarchy_equals_host_rule(gpu_backend, any_hit):
+    """A Scene with the previous Scene's connectivity and moved vertices: its hierarchy is a device-side refit of the previous
+    build (triangle records, boxes level by level, wide records); hits still equal the brute-force rule, for both forms."""
+    from redner_amd import _capi
+    dev = torch.device('cuda:0')
+
+    def make(shift):
+        sc = scenes.bunny_box(dev, resolution=(16, 16))
+        cpu_sc = scenes.bunny_box(torch.device('cpu'), resolution=(16, 16))
+        for s, c in zip(sc.shapes, cpu_sc.shapes):
+            n = c.vertices.numel()
+            delta = shift * torch.sin(torch.arange(n, dtype=torch.float32) * 0.37).reshape(c.vertices.shape)
+            c.vertices = (c.vertices.detach() + delta)
+            s.vertices = c.vertices.to(dev)
+        args = RenderFunction.serialize_scene(sc, 1, 1, sampler_type=gpu_backend.SamplerType.sobol, device=dev)
+        return cpu_sc, RenderFunction.unpack_args((1, 2), args[0], args[1:])
+
+    _, first = make(0.0)                                   # (keeps the topology cache's build alive)
+    cpu_sc, u = make(0.02)
+    assert _capi.lib().rdr_debug_bvh_check(u.scene._handle) == -1        # a refit, not a build
+    n = 600
+    rays = _rays(cpu_sc, n, 5)
+    d_rays = torch.from_numpy(rays).to(dev)
+    ref = _brute_force([s.vertices.detach().numpy() for s in cpu_sc.shapes], [s.indices.numpy() for s in cpu_sc.shapes], rays, any_hit)
+    d_hits = torch.zeros(n, 2, dtype=torch.int32, device=dev)
+    assert _capi.lib().rdr_scene_trace(u.scene._handle, d_rays.data_ptr(), d_hits.data_ptr(), n, any_hit) == 0      # (the 4-wide records)
+    hits = d_hits.cpu().numpy()
+    if any_hit:
+        assert np.array_equal(hits[:, 0] >= 0, ref[:, 0] >= 0)
+    else:
+        assert np.array_equal(hits, ref)
