@@ -8,8 +8,9 @@
 // edge_node_merge, shared with the host builder), with no fused contraction, and every choice the reference makes by
 // iteration order is made by the same order here:
 //   * codes            one thread per edge; scene bounds by a one-workgroup min/max reduction (exact)
-//   * sort             rocPRIM's stable LSD radix sort on the 64-bit code, payload = edge id (input ids ascend, so stable =
-//                      the reference's order of equal codes); a plain library sort, as DESIGN.md allows for plain library ops
+//   * sort             our own stable LSD radix sort on the 64-bit code, payload = edge id (input ids ascend, so stable =
+//                      the reference's order of equal codes): eight passes of 8 bits -- per-workgroup digit histograms, one
+//                      scan, and a scatter that ranks equal digits inside a wave by ballots (radix_* kernels below)
 //   * radix tree       one thread per interior node (Karras 2012), ties by edge id
 //   * bounds           one thread per leaf climbs; whoever reaches a node second finds both children complete (counters)
 //   * treelets         in order of radix-tree height, one launch per height, one WAVE per node: the wave restructures the
@@ -26,7 +27,6 @@
 
 #include <algorithm>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 #include <limits>
 #include <stdexcept>
 
@@ -34,6 +34,90 @@ namespace rdr {
 namespace {
 
 struct Box6D { V3 p_min, p_max, d_min, d_max; };
+
+// ---- stable LSD radix sort of (64-bit key, int payload) pairs, 8 bits per pass, wave64-native ------------------------------
+// Per pass: (1) radix_hist: every 256-thread workgroup counts the digits of its 256 x kSortItems keys in LDS and writes the
+// counts digit-major (hist[digit * blocks + block]); (2) radix_scan: one workgroup turns that table into exclusive offsets --
+// digit-major order IS the output order: all keys of digit 0 by block, then digit 1, ...; (3) radix_scatter: a workgroup
+// walks its keys in input order, 256 at a time: the lanes of a wave that hold the same digit find each other with eight
+// ballots (one per digit bit), a lane's rank among them is a popcount below its lane, the waves' counts per digit are
+// combined through LDS in wave order, and a running per-digit base carries over to the next 256 keys.  Equal digits keep
+// their input order at every step, so every pass -- and the whole sort -- is stable.
+constexpr int kSortItems = 8;                      // keys per thread and pass
+constexpr int kSortTile = 256 * kSortItems;
+__global__ void __launch_bounds__(256) radix_hist_kernel(const uint64_t *keys, int n, int shift, int blocks, int *hist) {
+    __shared__ int cnt[256];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kSortTile;
+    for (int it = 0; it < kSortItems; ++it) {
+        const int i = base + it * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&cnt[(int)((keys[i] >> shift) & 255u)], 1);
+    }
+    __syncthreads();
+    hist[threadIdx.x * blocks + blockIdx.x] = cnt[threadIdx.x];
+}
+__global__ void __launch_bounds__(256) radix_scan_kernel(int *hist, int total) {       // exclusive scan of `total` ints, one workgroup
+    __shared__ int part[256];
+    const int per = (total + 255) / 256;
+    const int beg = threadIdx.x * per, end = min(beg + per, total);
+    int s = 0;
+    for (int i = beg; i < end; ++i) s += hist[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int i = 0; i < 256; ++i) { const int t = part[i]; part[i] = run; run += t; } }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = beg; i < end; ++i) { const int t = hist[i]; hist[i] = run; run += t; }
+}
+__global__ void __launch_bounds__(256) radix_scatter_kernel(const uint64_t *keys_in, const int *vals_in, int n, int shift, int blocks,
+                                                            const int *offsets, uint64_t *keys_out, int *vals_out) {
+    __shared__ int digit_base[256];            // where the next key of each digit goes
+    __shared__ int wave_cnt[4][256];           // this round: keys of each digit held by each wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    digit_base[threadIdx.x] = offsets[threadIdx.x * blocks + blockIdx.x];
+    const int base = blockIdx.x * kSortTile;
+    for (int it = 0; it < kSortItems; ++it) {
+        for (int w = 0; w < 4; ++w) wave_cnt[w][threadIdx.x] = 0;
+        __syncthreads();
+        const int i = base + it * 256 + threadIdx.x;
+        const bool valid = i < n;
+        uint64_t key = 0; int val = 0, digit = 0;
+        if (valid) { key = keys_in[i]; val = vals_in[i]; digit = (int)((key >> shift) & 255u); }
+        unsigned long long same = __ballot(valid);
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot(valid && ((digit >> b) & 1));
+            same &= ((digit >> b) & 1) ? m : ~m;
+        }
+        const int rank = __popcll(same & ((1ull << lane) - 1ull));
+        if (valid && rank == 0) wave_cnt[wave][digit] = __popcll(same);       // the first lane of each digit group
+        __syncthreads();
+        if (valid) {
+            int before = 0;
+            for (int w = 0; w < wave; ++w) before += wave_cnt[w][digit];
+            const int at = digit_base[digit] + before + rank;
+            keys_out[at] = key; vals_out[at] = val;
+        }
+        __syncthreads();
+        digit_base[threadIdx.x] += wave_cnt[0][threadIdx.x] + wave_cnt[1][threadIdx.x] + wave_cnt[2][threadIdx.x] + wave_cnt[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+// sorts n pairs from (keys_in, vals_in) into (keys_out, vals_out); (keys_tmp, vals_tmp): n entries of scratch; hist: 256 x blocks ints
+inline void radix_sort_pairs_u64(hipStream_t s, uint64_t *keys_tmp, int *vals_tmp, const uint64_t *keys_in, const int *vals_in,
+                                 uint64_t *keys_out, int *vals_out, int n, int *hist) {
+    const int blocks = (n + kSortTile - 1) / kSortTile;
+    // pass k reads src_k and writes dst_k: in -> tmp -> out -> tmp -> out -> tmp -> out -> tmp -> out (8 passes)
+    const uint64_t *ksrc = keys_in; const int *vsrc = vals_in;
+    for (int pass = 0; pass < 8; ++pass) {
+        uint64_t *kdst = (pass & 1) ? keys_out : keys_tmp;
+        int *vdst = (pass & 1) ? vals_out : vals_tmp;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ksrc, n, 8 * pass, blocks, hist);
+        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(256), 0, s, hist, 256 * blocks);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ksrc, vsrc, n, 8 * pass, blocks, (const int *)hist, kdst, vdst);
+        ksrc = kdst; vsrc = vdst;
+    }
+}
 
 __device__ inline V3 vmin_std(V3 a, V3 b) { return V3{dmin_std(a.x, b.x), dmin_std(a.y, b.y), dmin_std(a.z, b.z)}; }
 __device__ inline V3 vmax_std(V3 a, V3 b) { return V3{dmax_std(a.x, b.x), dmax_std(a.y, b.y), dmax_std(a.z, b.z)}; }
@@ -616,10 +700,10 @@ void build_edge_trees_device(EdgeData &ed) {
         hipLaunchKernelGGL(scene_bounds_kernel, dim3(1), dim3(256), 0, s, (const Box6D *)sb_part, (const int *)nullptr, sb_blocks, sb);
         hipLaunchKernelGGL(codes_kernel, grid_of(n), dim3(256), 0, s, bounds, ids_in, n, sb, t.is3d, codes_in);
         {
-            size_t temp_bytes = 0;
-            exec::check(rocprim::radix_sort_pairs(nullptr, temp_bytes, codes_in, codes, ids_in, ids, (size_t)n, 0, 64, s), "radix_sort_pairs (size)");
-            void *temp = talloc(temp_bytes);
-            exec::check(rocprim::radix_sort_pairs(temp, temp_bytes, codes_in, codes, ids_in, ids, (size_t)n, 0, 64, s), "radix_sort_pairs");
+            uint64_t *codes_tmp = (uint64_t *)talloc(sizeof(uint64_t) * (size_t)n);
+            int *ids_tmp = (int *)talloc(sizeof(int) * (size_t)n);
+            int *hist = (int *)talloc(sizeof(int) * 256 * (size_t)((n + kSortTile - 1) / kSortTile));
+            radix_sort_pairs_u64(s, codes_tmp, ids_tmp, codes_in, ids_in, codes, ids, n, hist);
         }
         t.nodes = (EdgeNode *)alloc(sizeof(EdgeNode) * (size_t)total);
         t.below = (int *)talloc(sizeof(int) * (size_t)total);

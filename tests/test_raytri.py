@@ -223,7 +223,7 @@ def test_refitted_hierarchy_equals_host_rule(gpu_backend, any_hit):
         return cpu_sc, RenderFunction.unpack_args((1, 2), args[0], args[1:])
 
     _, first = make(0.0)                                   # (keeps the topology cache's build alive)
-    cpu_sc, u = make(0.02)
+    cpu_sc, u = make(0.0005)
     assert _capi.lib().rdr_debug_bvh_check(u.scene._handle) == -1        # a refit, not a build
     n = 600
     rays = _rays(cpu_sc, n, 5)
