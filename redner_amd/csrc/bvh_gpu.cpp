@@ -505,6 +505,22 @@ void refit_tri_bvh_device(const BvhDev &src, const void *d_shapes, BvhDev &d) { 
     exec::check(hipGetLastError(), "bvh refit launch");
 }
 
+void refit_box_bvh_device(const BvhDev &src, const float *d_boxes, BvhDev &d) {
+    hipStream_t st = exec::ctx().stream;
+    d.num_nodes = src.num_nodes; d.num_slots = src.num_slots; d.depth = src.depth;
+    d.level_first = src.level_first; d.inner_area = src.inner_area;
+    d.ids = src.ids;
+    d.nodes = take<Node>(d, (size_t)src.num_nodes);
+    d.area = take<double>(d, 1);
+    exec::copy_dev(d.nodes, src.nodes, sizeof(Node) * src.num_nodes);
+    for (int l = (int)d.level_first.size() - 2; l >= 0; --l) {
+        const int first = d.level_first[l], end = d.level_first[l + 1];
+        if (end > first) hipLaunchKernelGGL(refit_level_kernel, grid_of(end - first), dim3(256), 0, st, d.nodes, first, end, (const float *)nullptr, d_boxes, (const int *)d.ids);
+    }
+    hipLaunchKernelGGL(inner_area_kernel, dim3(1), dim3(256), 0, st, d.nodes, d.num_nodes, d.area);
+    exec::check(hipGetLastError(), "bvh refit launch");
+}
+
 BvhDev::~BvhDev() { for (void *p : owned) exec::pool_free(p); }
 
 } // namespace rt

@@ -35,5 +35,6 @@ struct BvhDev {
 void build_tri_bvh_device(const void *d_shapes, const int *h_prim_ids, int n, const BvhBuildParams &prm, BvhDev &out);
 void build_box_bvh_device(const float *d_boxes, int n, const BvhBuildParams &prm, BvhDev &out);
 void refit_tri_bvh_device(const BvhDev &src, const void *d_shapes, BvhDev &out);
+void refit_box_bvh_device(const BvhDev &src, const float *d_boxes, BvhDev &out);      // boxes indexed by src.ids[2 slot + 1]
 
 }

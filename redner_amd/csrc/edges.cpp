@@ -634,7 +634,9 @@ EdgeData *compute_edge_data(const Scene &scene) {
         static GatherCache *gather_cache = new GatherCache();            // one build at a time (build_lock above; scene.cpp: EdgeBuilder)
         rt::BvhHost gather_built;
         double &expand_out = ed->edge_bounds_expand;
-        auto gather_job = hostpool::run([&gather_built, &edges, &canon, &can_of, &cs_ids, &ncs_ids, shapes, ne, &expand_out, cache_allowed] {
+        const bool gather_on_device = ed->device_trees && exec::kDeviceBvh;
+        EdgeData *edp = ed.get();
+        auto gather_job = hostpool::run([&gather_built, &edges, &canon, &can_of, &cs_ids, &ncs_ids, shapes, ne, &expand_out, cache_allowed, gather_on_device, edp] {
             // mean absolute deviation of the endpoints -> billboard half-width
             std::vector<int> all_ids(cs_ids);
             all_ids.insert(all_ids.end(), ncs_ids.begin(), ncs_ids.end());
@@ -666,6 +668,14 @@ EdgeData *compute_edge_data(const Scene &scene) {
                     boxes[6 * (size_t)i + 3 + k] = std::nextafterf((float)hi[k], std::numeric_limits<float>::infinity());
                 }
             }
+            if (gather_on_device) {
+                // built / refitted by kernels when the structures are published (publish_edge_data -> gather_hierarchy_device)
+                edp->gather_boxes = std::move(boxes);
+                edp->gather_cur_of.assign((size_t)nc, -1);
+                for (int i = 0; i < ne; ++i) edp->gather_cur_of[can_of[i]] = i;
+                edp->gather_canon = canon;
+                return;
+            }
             bool have = false;
             if (cache_allowed && !gather_cache->bvh.nodes.empty() && gather_cache->canon.size() == canon.size() &&
                 std::memcmp(gather_cache->canon.data(), canon.data(), sizeof(EdgeD) * canon.size()) == 0) {
@@ -696,6 +706,7 @@ EdgeData *compute_edge_data(const Scene &scene) {
             gather_job.wait();
             ed->cs_ids = cs_ids; ed->ncs_ids = ncs_ids;
             ed->gather = std::move(gather_built);
+            ed->gather_refit_allowed = cache_allowed;
             if (ed->gather.depth + 2 > 64) throw std::runtime_error("edge gather hierarchy deeper than the traversal stack (64)");
             if (ed->gather.ids.size() / 2 >= ((size_t)1 << 24) || ed->gather.nodes.size() >= ((size_t)1 << 30))
                 throw std::runtime_error("edge gather hierarchy: more than 2^24 edges are not supported");
@@ -885,6 +896,7 @@ void publish_edge_data(EdgeData &ed) {
     }
     if (ed.device_trees) {
         if (d.gather.num_tris > 0) d.gather.ids = (const int *)up(ed.gather.ids.data(), sizeof(int) * ed.gather.ids.size());
+        if (!ed.gather_boxes.empty()) gather_hierarchy_device(ed);
         timer.lap("device copies");
         if (!ed.cs_ids.empty() || !ed.ncs_ids.empty()) build_edge_trees_device(ed);
         timer.lap("hierarchies (device)");

@@ -15,6 +15,7 @@
 #pragma once
 #include "surface.h"
 #include "bvh.h"
+#include "bvh_gpu.h"
 #include <vector>
 
 namespace rdr {
@@ -251,7 +252,12 @@ struct EdgeData {
     int cs_leaves = 0, ncs_leaves = 0;
     int max_stack = 2;             // see EdgeSceneD::max_stack
     double edge_bounds_expand = 0;
-    rt::BvhHost gather;            // see EdgeSceneD::gather
+    rt::BvhHost gather;            // see EdgeSceneD::gather (CPU debugging harness; the GPU build: gather_dev)
+    // GPU build: the billboard hierarchy is built / refitted by kernels (bvh_gpu.cpp) from these boxes of the CANONICAL edges;
+    // gather_cur_of: canonical edge -> current edge id (-1: not in the list)
+    std::vector<float> gather_boxes; std::vector<int> gather_cur_of; std::vector<EdgeD> gather_canon;
+    std::shared_ptr<rt::BvhDev> gather_dev;
+    bool gather_refit_allowed = true;
     std::vector<GatherLeaf> gleaf;
     std::vector<EdgeGeom> geom;                  // per edge, what EdgeSceneD::geom will hold
     std::vector<EdgeNodeP> cs_fat, ncs_fat;      // the samplers' interior-node records (EdgeSceneD::cs_nodes / ncs_nodes)
@@ -272,6 +278,7 @@ void publish_edge_data(EdgeData &ed);
 // edges_gpu.cpp (not part of the CPU debugging harness): both hierarchies, leaf order, sampler and gather records on the
 // calling thread's stream; and the node arrays back on the host for rdr_debug_dump_edges.
 void build_edge_trees_device(EdgeData &ed);
+void gather_hierarchy_device(EdgeData &ed);      // edges_gpu.cpp: EdgeSceneD::gather from ed.gather_boxes (build or refit, by kernels)
 void download_edge_trees(EdgeData &ed);
 void delete_edge_data(EdgeData *e);
 

@@ -652,6 +652,56 @@ inline dim3 grid_of(int n) { return dim3((unsigned)((n + 255) / 256)); }
 // Builds both hierarchies and everything derived from them on the calling thread's stream.  Inputs already on the device:
 // d.geom (per-edge geometry), d.gather (the billboard hierarchy with its slot -> edge table).  ed.owned receives what the
 // samplers (and the debug dump) read -- node arrays, the samplers' records, the gather's leaf records -- released with the Scene.  Returns after the one read-back the host needs: the depth of the deeper tree.
+// The billboard hierarchy of the NEE-mode gather over the canonical edges' boxes: built by the kernels of bvh_gpu.cpp, or --
+// same canonical edges as the last build (an optimisation loop moves vertices) -- a refit of a copy of that build's records;
+// the leaf slots are then re-pointed to the CURRENT edge ids.
+__global__ void __launch_bounds__(256) gather_ids_kernel(const int *canon_ids, const int *cur_of, int slots, int *out) {
+    const int sl = blockIdx.x * 256 + threadIdx.x;
+    if (sl < slots) { out[2 * sl] = 0; out[2 * sl + 1] = cur_of[canon_ids[2 * sl + 1]]; }
+}
+void gather_hierarchy_device(EdgeData &ed) {
+    struct Cache { std::vector<EdgeD> canon; std::shared_ptr<rt::BvhDev> tree; int device = -1; };
+    static Cache *cache = new Cache();                 // one build at a time (scene.cpp: EdgeBuilder)
+    hipStream_t s = exec::ctx().stream;
+    const int nc = (int)ed.gather_cur_of.size();
+    if (nc == 0) return;
+    auto up = [&](const void *src, size_t bytes) -> void * {
+        void *p = exec::pool_alloc(bytes);
+        ed.owned.push_back(p);
+        exec::upload_async(p, src, bytes);
+        return p;
+    };
+    const float *boxes = (const float *)up(ed.gather_boxes.data(), sizeof(float) * ed.gather_boxes.size());
+    const int *cur_of = (const int *)up(ed.gather_cur_of.data(), sizeof(int) * (size_t)nc);
+    auto tree = std::make_shared<rt::BvhDev>();
+    bool have = false;
+    const int device = exec::current_device();
+    if (ed.gather_refit_allowed && cache->tree && cache->device == device && cache->canon.size() == ed.gather_canon.size() &&
+        std::memcmp(cache->canon.data(), ed.gather_canon.data(), sizeof(EdgeD) * ed.gather_canon.size()) == 0) {
+        rt::refit_box_bvh_device(*cache->tree, boxes, *tree);
+        tree->parent = cache->tree;
+        double area = 0;
+        exec::upload_flush();
+        exec::download(&area, tree->area, sizeof(double));
+        have = tree->inner_area > 0 && area / tree->inner_area <= 1.3;
+        if (!have) tree = std::make_shared<rt::BvhDev>();
+    }
+    if (!have) {
+        exec::upload_flush();                     // the boxes travel through the staging buffer; the build synchronises per level
+        rt::build_box_bvh_device(boxes, nc, rt::BvhBuildParams{}, *tree);
+        cache->canon = ed.gather_canon;
+        cache->tree = tree;
+        cache->device = device;
+    }
+    if (tree->depth + 2 > 64) throw std::runtime_error("edge gather hierarchy deeper than the traversal stack (64)");
+    if ((size_t)tree->num_slots >= ((size_t)1 << 24)) throw std::runtime_error("edge gather hierarchy: more than 2^24 edges are not supported");
+    int *ids = (int *)exec::pool_alloc(sizeof(int) * 2 * (size_t)tree->num_slots);
+    ed.owned.push_back(ids);
+    hipLaunchKernelGGL(gather_ids_kernel, grid_of(tree->num_slots), dim3(256), 0, s, (const int *)tree->ids, cur_of, tree->num_slots, ids);
+    ed.gather_dev = tree;
+    ed.d.gather = rt::BvhD{tree->nodes, nullptr, ids, tree->num_nodes, tree->num_slots, tree->depth + 2};
+}
+
 void build_edge_trees_device(EdgeData &ed) {
     hipStream_t s = exec::ctx().stream;
     auto alloc = [&](size_t bytes) -> void * { void *p = exec::pool_alloc(bytes ? bytes : 16); ed.owned.push_back(p); return p; };
