@@ -875,7 +875,7 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
     // With mip levels (and no environment light) the samples of a batch depend on each other through the reference's
     // differential scratch, lane by lane: "chain mode" (Backward::run_sample, "primary edges") batches what does not and runs the
     // rest sample by sample.  One worker then: the chain runs through the batches in order.
-    const bool chain = scene.has_mipmaps && !no_edge_passes;
+    const bool chain = (scene.has_mipmaps || scene.d.envmap != nullptr) && !no_edge_passes;      // (under an environment light: the hit-position scratch)
     // Under an environment light there is a second scratch of that kind -- the hit positions of the edge rays, read stale by the
     // rays that reach the environment (HitPosView, stages_edge.h) -- and no way to batch a lane that reads across samples
     // there: such a call is batched optimistically (`envmap_batches`) and starts over unbatched if a lane did (render()).
@@ -971,7 +971,7 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
     }
     int workers = 1;
     if (samples_independent) workers = std::max(1, std::min(tune.workers > 0 ? tune.workers : exec::sample_workers(PL, num_batches, batch.on), num_batches));
-    if (chain && batch.on) workers = 1;
+    if (chain) workers = 1;            // (also one sample per launch: the scratch chain runs through the samples in order)
 
     // Everything one sample (or sample batch) needs between its camera rays and its last gradient add.
     struct Worker {
