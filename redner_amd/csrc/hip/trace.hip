@@ -73,7 +73,17 @@ void pool_set_cap(long long bytes) {
     pl.cap_override = bytes;
 }
 
+// RDR_POOL_POISON=1 (debugging): every block handed out is filled with 0xFF bytes (NaN as a double or float, -1 as an int) on
+// the calling thread's stream -- a buffer that is read before it is written then fails the same way every time instead of
+// depending on what the pool last kept in it (fresh device memory is zero; the CPU harness gets zero pages from malloc).
+static void *pool_alloc_raw(size_t bytes);
 void *pool_alloc(size_t bytes) {
+    void *p = pool_alloc_raw(bytes);
+    static const bool poison = std::getenv("RDR_POOL_POISON") != nullptr;
+    if (poison) check(hipMemsetAsync(p, 0xFF, std::max<size_t>(bytes, 16), ctx().stream), "pool poison");
+    return p;
+}
+static void *pool_alloc_raw(size_t bytes) {
     const size_t want = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
     int dev = 0;
     (void)hipGetDevice(&dev);

@@ -150,8 +150,25 @@ def _distance(mine, ref, skip=()):
     return None
 
 
+ORACLE_UNSTABLE = []
+
+
 def _compare(mine, ref, render_oracle):
-    """-> None or the first failure that the striped sum does not explain."""
+    """-> None or the first failure that the striped sum does not explain.  GPU leg: a failure is first checked against the
+    ORACLE's own reproducibility -- the reference reads scratch it never wrote (module docstring), and in a process that also
+    holds the HIP runtime's thousands of mappings glibc can run out of mmap regions (vm.max_map_count / M_MMAP_MAX) and hand
+    the oracle recycled heap memory instead of zero pages: a second oracle render of the same scene then differs from the
+    first.  Such scenes are listed (ORACLE_UNSTABLE) and compared with the second render."""
+    bad = _compare_once(mine, ref, render_oracle)
+    if bad and ON_GPU and bad not in ('keys differ',):
+        ref2 = render_oracle(None)
+        if _distance(ref2, ref) is not None:
+            ORACLE_UNSTABLE.append(SCENE[0])
+            return _compare_once(mine, ref2, render_oracle)
+    return bad
+
+
+def _compare_once(mine, ref, render_oracle):
     excused = set()
     while True:
         bad = _distance(mine, ref, excused)
@@ -561,8 +578,7 @@ def _main(lib):
     # the oracle, which builds everything from scratch each time
     for seed in range(FIRST, 21, STRIDE):
         for step in range(6):
-            outs = []
-            for backend in (oracle, redner):
+            def loop_step(backend):
                 sc = _scene_mesh(seed, torch.device('cpu'))
                 rng = np.random.RandomState(100 * seed + step)
                 with torch.no_grad():
@@ -581,9 +597,15 @@ def _main(lib):
                 o = {'image': _np(img), 'cam_position': sc.camera.position.grad.numpy(), 'light0': sc.area_lights[0].intensity.grad.numpy()}
                 for i, sh in enumerate(sc.shapes[:-1]):
                     o['shape%d' % i] = sh.vertices.grad.numpy()
-                outs.append(o)
+                return o
+            ref, mine = loop_step(oracle), loop_step(redner)
             SCENE[0] = 'loop %d step %d' % (seed, step)
-            bad = _distance(outs[1], outs[0])
+            bad = _distance(mine, ref)
+            if bad and ON_GPU:                       # (see _compare: is the oracle's own render reproducible?)
+                ref2 = loop_step(oracle)
+                if _distance(ref2, ref) is not None:
+                    ORACLE_UNSTABLE.append(SCENE[0])
+                    bad = _distance(mine, ref2)
             if bad:
                 failures['loop %d step %d' % (seed, step)] = bad
     # degenerate geometry: a triangle with two coinciding corners, with collinear corners, and two identical triangles
@@ -666,6 +688,7 @@ def _main(lib):
         if not d <= 1e-4 * n + 1e-9:
             failures['screen gradient %d' % seed] = '%.3e' % (d / max(n, 1e-300))
     print('FLIPS ' + json.dumps(FLIPS))
+    print('ORACLE_UNSTABLE ' + json.dumps(ORACLE_UNSTABLE))
     print('SCENES %d' % len(SEEN))
     print('FUZZ ' + json.dumps(failures))
 
@@ -703,18 +726,21 @@ GPU_KEYS = ('RDR_BATCH', 'RDR_FORCE_GENERAL', 'FUZZ_STRIDE', 'FUZZ_OFFSET', 'RDR
                                      'RDR_TRACE_REFILL_ALL=1 FUZZ_STRIDE=8 FUZZ_OFFSET=5'])
 def test_random_scenes_gpu_vs_oracle(gpu_backend, variant):
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MALLOC_MMAP_THRESHOLD_='1024',
+    # (8 KiB: every scratch buffer of the reference that matters is larger at these frame sizes, and the process keeps far fewer
+    #  mappings than with the harness legs' 1 KiB -- see _compare)
+    env = dict(os.environ, MALLOC_MMAP_THRESHOLD_='8192',
                PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get('PYTHONPATH', '')]))
     for k in GPU_KEYS:
         env.pop(k, None)
     env.update(dict(kv.split('=') for kv in variant.split()))
     out = subprocess.check_output([sys.executable, os.path.abspath(__file__), 'gpu'], env=env, timeout=900).decode()
     grab = lambda tag: [l for l in out.splitlines() if l.startswith(tag + ' ')][-1][len(tag) + 1:]
-    flips, scenes = json.loads(grab('FLIPS')), int(grab('SCENES'))
+    flips, scenes, unstable = json.loads(grab('FLIPS')), int(grab('SCENES')), json.loads(grab('ORACLE_UNSTABLE'))
     path = os.environ.get('RDR_PARITY_REPORT')
     if path:
         with open(path, 'a') as f:
-            f.write(json.dumps({'case': 'fuzz_gpu_vs_live_oracle [%s]' % variant, 'backend': 'gpu', 'scenes': scenes, 'edge_flips': flips}) + '\n')
+            f.write(json.dumps({'case': 'fuzz_gpu_vs_live_oracle [%s]' % variant, 'backend': 'gpu', 'scenes': scenes, 'edge_flips': flips,
+                                'oracle_not_reproducible': unstable}) + '\n')
     assert json.loads(grab('FUZZ')) == {}
     assert scenes >= 60
     # different (equally valid) draws of single edge samples, see _edge_flip: listed above, and rare -- or something is wrong
