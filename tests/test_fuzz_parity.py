@@ -155,10 +155,12 @@ ORACLE_UNSTABLE = []
 
 def _compare(mine, ref, render_oracle):
     """-> None or the first failure that the striped sum does not explain.  GPU leg: a failure is first checked against the
-    ORACLE's own reproducibility -- the reference reads scratch it never wrote (module docstring), and in a process that also
-    holds the HIP runtime's thousands of mappings glibc can run out of mmap regions (vm.max_map_count / M_MMAP_MAX) and hand
-    the oracle recycled heap memory instead of zero pages: a second oracle render of the same scene then differs from the
-    first.  Such scenes are listed (ORACLE_UNSTABLE) and compared with the second render."""
+    ORACLE's own reproducibility -- the reference reads scratch it never wrote (module docstring); the legs run under
+    MALLOC_MMAP_THRESHOLD_=1024 (large chunks are fresh zero mappings) AND MALLOC_PERTURB_=255 (glibc zero-fills every
+    chunk: also the small ones, and the large ones should the process run out of mappings beside the HIP runtime), which
+    makes that scratch read as zero; should a second oracle render of a failing scene still differ from the first, the
+    scene is listed (ORACLE_UNSTABLE) and compared with the second render.  (Found the hard way: with an 8 KiB threshold and
+    no zero fill the oracle's own two renders of four pixel-centre scenes differed by up to 30 % in a vertex gradient.)"""
     bad = _compare_once(mine, ref, render_oracle)
     if bad and ON_GPU and bad not in ('keys differ',):
         ref2 = render_oracle(None)
@@ -703,7 +705,7 @@ def _main(lib):
 def test_random_scenes_hostsim_vs_oracle(hostsim_backend, variant):
     from conftest import HOSTSIM_LIB
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MALLOC_MMAP_THRESHOLD_='1024',
+    env = dict(os.environ, MALLOC_MMAP_THRESHOLD_='1024', MALLOC_PERTURB_='255',
                PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get('PYTHONPATH', '')]))
     for k in ('RDR_BATCH', 'RDR_FORCE_GENERAL', 'FUZZ_STRIDE', 'RDR_BATCH_LANES', 'RDR_GATHER_BUDGET', 'RDR_GATHER_CAPS', 'RDR_NO_REFIT',
               'RDR_NO_EDGE_CACHE'):
@@ -726,9 +728,9 @@ GPU_KEYS = ('RDR_BATCH', 'RDR_FORCE_GENERAL', 'FUZZ_STRIDE', 'FUZZ_OFFSET', 'RDR
                                      'RDR_TRACE_REFILL_ALL=1 FUZZ_STRIDE=8 FUZZ_OFFSET=5'])
 def test_random_scenes_gpu_vs_oracle(gpu_backend, variant):
     here = os.path.dirname(os.path.abspath(__file__))
-    # (8 KiB: every scratch buffer of the reference that matters is larger at these frame sizes, and the process keeps far fewer
-    #  mappings than with the harness legs' 1 KiB -- see _compare)
-    env = dict(os.environ, MALLOC_MMAP_THRESHOLD_='8192',
+    # MALLOC_PERTURB_=255: glibc then fills every chunk it hands out with 0x00 (perturb byte ^ 0xff) -- the scratch the
+    # reference reads without having written it is zero whether the chunk is a fresh mapping or recycled heap (see _compare)
+    env = dict(os.environ, MALLOC_MMAP_THRESHOLD_='1024', MALLOC_PERTURB_='255',
                PYTHONPATH=os.pathsep.join([os.path.dirname(here), here, os.environ.get('PYTHONPATH', '')]))
     for k in GPU_KEYS:
         env.pop(k, None)
@@ -741,7 +743,7 @@ def test_random_scenes_gpu_vs_oracle(gpu_backend, variant):
         with open(path, 'a') as f:
             f.write(json.dumps({'case': 'fuzz_gpu_vs_live_oracle [%s]' % variant, 'backend': 'gpu', 'scenes': scenes, 'edge_flips': flips,
                                 'oracle_not_reproducible': unstable}) + '\n')
-    assert json.loads(grab('FUZZ')) == {}
+    assert json.loads(grab('FUZZ')) == {}, (grab('FUZZ')[:3000], 'oracle not reproducible: %s' % unstable, 'flips: %s' % flips)
     assert scenes >= 60
     # different (equally valid) draws of single edge samples, see _edge_flip: listed above, and rare -- or something is wrong
     assert len(flips) <= 2, flips

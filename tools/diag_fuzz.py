@@ -1,8 +1,9 @@
 """GPU box: one scene of tests/test_fuzz_parity.py (family seed) by the oracle and by the product library under several tunings;
 prints per-tensor distances and the rows that stand out.  python tools/diag_fuzz.py mesh 118"""
 import os, sys
-if os.environ.get('MALLOC_MMAP_THRESHOLD_') != '1024':
+if os.environ.get('MALLOC_MMAP_THRESHOLD_') != '1024' or os.environ.get('MALLOC_PERTURB_') != '255':
     os.environ['MALLOC_MMAP_THRESHOLD_'] = '1024'
+    os.environ['MALLOC_PERTURB_'] = '255'
     os.execv(sys.executable, [sys.executable] + sys.argv)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]

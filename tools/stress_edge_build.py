@@ -2,8 +2,9 @@
 beside a forward render on the calling thread, as in a training loop -- against the oracle's, link for link.  Hunts races in
 the device build (radix sort, radix tree, treelets).  python tools/stress_edge_build.py [rounds]"""
 import ctypes, os, sys, glob, importlib.util
-if os.environ.get('MALLOC_MMAP_THRESHOLD_') != '1024':
+if os.environ.get('MALLOC_MMAP_THRESHOLD_') != '1024' or os.environ.get('MALLOC_PERTURB_') != '255':
     os.environ['MALLOC_MMAP_THRESHOLD_'] = '1024'
+    os.environ['MALLOC_PERTURB_'] = '255'
     os.execv(sys.executable, [sys.executable] + sys.argv)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
