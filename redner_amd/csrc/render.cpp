@@ -924,14 +924,15 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
             return per_lane * lanes;
         };
         // Buffers that do not fit the buffer cache (exec::pool_cap_bytes: 16 GiB unless the caller raised it) are allocated and
-        // released by EVERY call -- ~25 ms per GB on this runtime: a 32-spp gradient render of the config-5 stand-in in 16-sample
-        // batches (67 GB) ran at 12.4 Msamples/s against 28.6 in 4-sample batches (16.8 GB), and at 29.4 with a cache that holds
-        // the 67 GB (profiles/r4_notes.md).  A call of many batches pays that once per 8 + batches (the 256-spp benchmark: 64.4
-        // against 64.6 Msamples/s); a short one gets the batches that fit.
+        // released by EVERY call, and device memory that another process has used before is scrubbed when it is handed out:
+        // ~25 ms per GB on a box that has been in use (a fresh box allocates 48 GB in no time, which is how this went unnoticed
+        // for a round).  The 256-spp benchmark in 16-sample batches (48 GB of buffers) ran at 64.3 Msamples/s on a fresh box and
+        // at 50.1 after the test suite had run there; a 32-spp gradient render of the config-5 stand-in at 12.4 against 28.6 in
+        // 4-sample batches (profiles/r4_notes.md).  So a batch is as large as fits the cache -- 5 samples of 1024 x 1024 by
+        // default (63 Msamples/s), 16 once the caller raises the bound (rdr_set_pool_cap_mb(49152): 64.8).
         if (tune.batch_lanes == 0 && tune.mem_available_mb < 0) {
             const double cap = (double)exec::pool_cap_bytes();
-            auto batches_at = [&](int S_try) { return (opt.num_samples + S_try - 1) / S_try; };
-            while (batch.S > 1 && bytes_needed(batch.S) > cap && batches_at(batch.S) < 8) batch.S = (batch.S + 1) / 2;
+            while (batch.S > 1 && bytes_needed(batch.S) > cap) --batch.S;
         }
         if (tune.mem_available_mb >= 0 || bytes_needed(batch.S) > 1073741824.0) {        // small frames: not worth asking the driver
             const double room = 0.8 * (tune.mem_available_mb >= 0 ? tune.mem_available_mb * 1048576.0 : (double)exec::memory_available());      // (override: tests)
