@@ -46,11 +46,13 @@ struct Arena {
     }
 };
 
-VSlice make_slice(Arena &a, int n, bool with_occl) {
+// `with_rdiff` false: the lean stages neither store nor read ray differentials (stages_fwd.h: lean_slice nulls the pointer in
+// every kernel) -- 96 of a slice's 185 bytes per lane, 30 % of everything a gradient render of a plain scene allocates
+VSlice make_slice(Arena &a, int n, bool with_occl, bool with_rdiff = true) {
     VSlice v;
     v.n = n;
     v.ray = a.get<double>((size_t)6 * n);
-    v.rdiff = a.get<double>((size_t)12 * n);
+    v.rdiff = with_rdiff ? a.get<double>((size_t)12 * n) : nullptr;
     v.shape = a.get<int>(n); v.tri = a.get<int>(n);
     v.thr = a.get<double>((size_t)3 * n);
     v.mrough = a.get<double>(n);
@@ -357,8 +359,8 @@ struct Backward {
             edge_dyn = arena.get<int>(kMaxBatch);
             hoist_dyn = arena.get<int>(kMaxBatch);
             const int L = 2 * P;                      // edge lanes: two rays per sample slot
-            ea = make_slice(arena, L, false);
-            eb = make_slice(arena, L, false);
+            ea = make_slice(arena, L, false, lean != kLean);
+            eb = make_slice(arena, L, false, lean != kLean);
             if (scene.has_mipmaps) {
                 // the reference's buffer is a fresh allocation per render call; fresh pages read as zero
                 ea.erd = eb.erd = arena.get<double>((size_t)12 * L);
@@ -918,7 +920,8 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
         auto bytes_needed = [&](int S_try) {
             const double lanes = (double)S_try * P;
             const int wk = !samples_independent ? 1 : (tune.workers > 0 ? tune.workers : (lanes < (double)(1 << 20) ? 2 : 1));
-            double per_lane = (400.0 * (B + 1) + 1200.0) * wk;
+            // (measured, bunny_box at max_bounces 4: 2.9 KB per lane with ray differentials, 2.0 KB without -- the lean kernels)
+            double per_lane = (lean == kLean ? 280.0 * (B + 1) + 760.0 : 400.0 * (B + 1) + 1200.0) * wk;
             if (forward_batches) per_lane += 4.0 * lay.nd * (B + 1);
             if (d_image) per_lane += 4.0 * lay.nd;
             return per_lane * lanes;
@@ -988,7 +991,7 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
     };
     auto make_worker = [&](Worker &w) {
         w.vs.resize(B + 1);
-        for (int d = 0; d <= B; ++d) w.vs[d] = make_slice(w.arena, PL, d < B);
+        for (int d = 0; d <= B; ++d) w.vs[d] = make_slice(w.arena, PL, d < B, lean != kLean);
         w.active = w.arena.get<int>((size_t)(B + 1) * PL);
         w.q.nee = w.arena.get<rt::RayRec>((size_t)2 * PL); w.q.bsdf = w.arena.get<rt::RayRec>((size_t)2 * PL);
         w.q.h_nee = w.arena.get<rt::HitRec>((size_t)2 * PL); w.q.h_bsdf = w.arena.get<rt::HitRec>((size_t)2 * PL);
