@@ -132,7 +132,7 @@ def cpu_baseline(a, gpu_rd=None, gpu_dev=None):
     ref = oracle_util.load_oracle()
     cpu = torch.device('cpu')
     lines, best, check = [], None, None
-    for res, spp, min_reps, budget in ((256, 4, 3, 30.0), (a.res, 1, 3, 70.0)):
+    for res, spp, min_reps, budget in ((256, 4, 3, 30.0), (a.res, 1, 3, 90.0)):
         p = Prepared(ref, build_scene(a, cpu, res), spp, spp, 0, a.max_bounces, cpu)
         t0 = time.time()
         p.step(0)                                   # first pass (starts the thread pool, faults the pages in); also the step the GPU is compared with

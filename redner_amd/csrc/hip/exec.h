@@ -146,6 +146,9 @@ __device__ inline void accum_plain(double *p, double v) {
     unsafeAtomicAdd(p, v);
 }
 __host__ inline void accum_plain(double *p, double v) { *p += v; }
+// fp64 atomic add on an ordinary buffer (no replicas: NOT for the gradient accumulators)
+__device__ inline void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+__host__ inline void atomic_add_f64(double *p, double v) { *p += v; }
 __device__ inline int atomic_fetch_add(int *p, int v) { return atomicAdd(p, v); }
 __host__ inline int atomic_fetch_add(int *p, int v) { int o = *p; *p += v; return o; }
 }

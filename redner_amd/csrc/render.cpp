@@ -401,6 +401,14 @@ struct Backward {
                 hp_written = arena.get<unsigned char>(L);
                 hp_violations = arena.get<int>(1);
                 exec::zero(hp_violations, sizeof(int));
+                // stale reads across the samples of a batch are recorded and replayed after the sweep (HitPosView)
+                hp_event_cap = L;
+                hp_events = arena.get<HitEvent>((size_t)hp_event_cap);
+                hp_event_count = arena.get<int>(1);
+                exec::zero(hp_event_count, sizeof(int));
+                hp_carry = arena.get<double>((size_t)3 * 2 * batch.P0);
+                exec::zero(hp_carry, sizeof(double) * 3 * 2 * batch.P0);       // (the reference's fresh pages)
+                replay_live = arena.get<unsigned char>(P);
             }
             prim_recs = arena.get<PrimaryEdgeRec>(P);
             sec_recs = arena.get<SecondaryEdgeRec>(P);
@@ -431,8 +439,12 @@ struct Backward {
     const bool overlap = overlap_on();
     double *edge_contrib = nullptr, *edge_tmin = nullptr, *hit_pos = nullptr;
     unsigned char *hp_written = nullptr; int *hp_violations = nullptr;
-    HitPosView hit_view(const int *seg) const {
-        return HitPosView{hit_pos, ea.n, hp_written ? seg : nullptr, cur_S, batch.P0, hp_written, hp_violations};
+    HitEvent *hp_events = nullptr; int *hp_event_count = nullptr; int hp_event_cap = 0;
+    double *hp_carry = nullptr;        // [3 x 2 P0] what the batch found in the scratch (state after the previous batch)
+    unsigned char *replay_live = nullptr;
+    HitPosView hit_view(const int *seg, int depth = 0) const {
+        return HitPosView{hit_pos, ea.n, hp_written ? seg : nullptr, cur_S, batch.P0, hp_written, hp_violations,
+                          hp_events, hp_event_count, hp_event_cap, depth};
     }
     PrimaryEdgeRec *prim_recs = nullptr;
     SecondaryEdgeRec *sec_recs = nullptr;
@@ -711,7 +723,7 @@ struct Backward {
                 const exec::Count n1 = exec::compact_dev(elist[0], n0, elist[1], KeepHit{ea.shape});
                 trace_edge_paths(rng_edge, edim, n1, nA, d + 1, q, esink, false, seg_of(d));
                 if (side) adjoint_done.gate(main_stream);          // the only stage of the edge pass that touches the adjoint records
-                exec::launch(nA, SecondaryEdgeDerivatives{sd, grads.g, act, sec_recs, hit_view(seg_of(d)), edge_contrib, adj});
+                exec::launch(nA, SecondaryEdgeDerivatives{sd, grads.g, act, sec_recs, hit_view(seg_of(d), d), edge_contrib, adj});
             }
         }
         // the camera-vertex adjoint runs beside the primary-edge pass unless both would add to the screen-gradient image
@@ -780,6 +792,36 @@ struct Backward {
             launch_v(lean, P, PrimaryEdgeDerivatives{sd, grads.g, prim_recs, edge_contrib, screen_grad});
         }
         if (adj_primary_aside) adjoint_done.gate(exec::ctx().stream);      // the next sample clears the adjoint records
+        if (hp_events) replay_stale_hits(main_rng, vs, active, num_active, stride);
+    }
+
+    // Replay (sample batches under an environment light).  An edge ray that reaches the environment reads the hit position an
+    // earlier pass left at its entry of the reference's scratch (HitPosView); where that pass belongs to an EARLIER SAMPLE of the
+    // batch the value was not known when the sweep came by, and the term was recorded instead of added.  It is linear in that
+    // position, and the adjoint stages are linear in (adjoint record, upstream gradient): so now that every sample's passes have
+    // run, the recorded terms are put into EMPTY adjoint records -- depth by depth, deepest first, as the sweep met them -- and
+    // the same stages, with weight 0 and restricted to the lanes that carry something, take them down the paths to the camera
+    // and into the gradient buffers.  The sum is the sequential result up to the order of fp64 additions.  Then the state the
+    // next batch finds.  (No event, no work: every launch trims itself to the marked lanes / the event count.)
+    void replay_stale_hits(const SamplerD &rng, std::vector<VSlice> &vs, int *active, std::vector<exec::Count> &num_active, int stride) {
+        const int lanes = cur_S * batch.P0;
+        exec::zero(adj.thr, sizeof(double) * 3 * stride);
+        exec::zero(adj.ray_dir, sizeof(double) * 3 * stride);
+        exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * stride);
+        exec::zero(replay_live, (size_t)stride);
+        const exec::Count n_events(hp_event_count, hp_event_cap);
+        const int dim0 = opt.sample_pixel_center ? 0 : 2;
+        for (int d = B - 1; d >= 0; --d) {
+            if (num_active[d].upper <= 0) continue;
+            const int *act = active + (size_t)d * stride;
+            AdjBounceArgs ba{sd, grads.g, rng, dim0 + 7 * d, act, vs[d], vs[d + 1], d_image, nd, radiance_dim, 0.0, adj};
+            launch_v(lean, num_active[d], AdjBounceScatterLive{AdjBounceScatter{ba}, replay_live});
+            exec::launch(n_events, InjectHitEvents{sd, grads.g, hp_events, d, hit_pos, ea.n, hp_written, hp_carry, 2 * batch.P0, adj, replay_live});
+        }
+        launch_v(lean, lanes, AdjPrimaryLive{AdjPrimary{sd, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, 0.0,
+                                                        adj, screen_grad, ch}, replay_live});
+        exec::launch(2 * batch.P0, HitPosCarryAdvance{hp_carry, 2 * batch.P0, cur_S, hit_pos, ea.n, hp_written});
+        exec::zero(hp_event_count, sizeof(int));
     }
 };
 

@@ -440,6 +440,25 @@ struct AdjPrimary {
     }
 };
 
+// The adjoint stages restricted to the lanes marked in `live` (the replay of recorded stale reads, stages_edge.h: HitPosView):
+// run with weight 0 they carry an adjoint that was put into the records down to the camera and into the gradient buffers --
+// the stages are linear in (adjoint record, upstream image gradient) -- and do nothing for the other lanes.
+struct AdjBounceScatterLive {
+    static constexpr int kMidBlocksPerCU = AdjBounceScatter::kMidBlocksPerCU, kMinBlocksPerCU = AdjBounceScatter::kMinBlocksPerCU,
+                         kLeanBlocksPerCU = AdjBounceScatter::kLeanBlocksPerCU;
+    AdjBounceScatter f; const unsigned char *live;
+    RDR_FN void make_lean() { f.make_lean(); }
+    RDR_FN void make_mid() { f.make_mid(); }
+    RDR_FN void operator()(int idx) const { if (!live[f.a.active[idx]]) return; RDR_INLINE_CALL f(idx); }
+};
+struct AdjPrimaryLive {
+    static constexpr int kMidBlocksPerCU = AdjPrimary::kMidBlocksPerCU, kMinBlocksPerCU = AdjPrimary::kMinBlocksPerCU;
+    AdjPrimary f; const unsigned char *live;
+    RDR_FN void make_lean() { f.make_lean(); }
+    RDR_FN void make_mid() { f.make_mid(); }
+    RDR_FN void operator()(int p) const { if (!live[p]) return; RDR_INLINE_CALL f(p); }
+};
+
 // fp64 accumulators -> the caller's fp32 gradient tensors (+=), all tensors in one launch: lane i owns element i of the
 // replicated block, sums its replicas in fixed order and finds the tensor it belongs to in the sorted segment table.
 struct FlushSegment { size_t begin, count; float *out; };      // elements [begin, begin + count) of the block

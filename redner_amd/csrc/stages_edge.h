@@ -1257,12 +1257,18 @@ RDR_FN V3 isect_jacobian(V3 org, V3 dir, V3 p, V3 n, V3 l) {
 // carries radiance -- for a lane that reached the ENVIRONMENT light that is whatever an earlier pass left at its index, like the
 // reference's never-cleared edge_surface_points (src/pathtracer.cpp:584-600, 702)  [quirk].  A sample batch keeps one copy
 // per sample (lane 2 (rank) + side of the batch's list -> entry 2 (rank within the sample) + side of sample s, via `seg`), and
-// marks what the batch has written: a read of an entry the SAME sample has not written during this batch would need what
-// earlier samples left there -- it is counted, and render() then renders the call again one sample at a time.
+// marks what the batch has written: a read of an entry the SAME sample has not written during this batch needs what EARLIER
+// SAMPLES left there, which in a batch is only known once every sample's passes have run.  The term that depends on it is
+// LINEAR in the position (SecondaryEdgeDerivatives), and so is everything the adjoint sweep does with it afterwards: the read
+// is recorded as a HitEvent and its whole contribution is replayed after the sweep (render.cpp: "replay"; InjectHitEvents
+// below).  Only when the event list overflows is the read counted as a violation, and render() renders the call again one
+// sample at a time.
+struct HitEvent { int p, entry, shape_id, v0, v1, depth; double contrib; V3 sp_pos; };
 struct HitPosView {
     double *pos; int n;                          // 3 x n, stride n
     const int *seg; int S, P0;                   // null / 0: one sample, lanes are entries
     unsigned char *written; int *violations;     // null outside batches
+    HitEvent *events; int *event_count; int event_cap, depth;
     RDR_FN int index(int lane) const {
         if (!seg) return lane;
         const int idx = lane >> 1;
@@ -1344,7 +1350,12 @@ struct SecondaryEdgeDerivatives {
             double contrib = edge_contrib[2 * idx + k];
             if (contrib == 0) continue;
             const int hi = hp.index(2 * idx + k);
-            if (hp.written && !hp.written[hi]) atomic_fetch_add(hp.violations, 1);      // (see HitPosView)
+            if (hp.written && !hp.written[hi]) {                                        // (see HitPosView)
+                const int at = hp.events ? atomic_fetch_add(hp.event_count, 1) : hp.event_cap;
+                if (at < hp.event_cap) hp.events[at] = HitEvent{p, hi, rec.edge.shape_id, rec.edge.v0, rec.edge.v1, hp.depth, contrib, rec.sp_pos};
+                else atomic_fetch_add(hp.violations, 1);
+                continue;
+            }
             V3 x = ld3(hp.pos, hp.n, hi, 0);
             V3 pos = rec.sp_pos;
             V3 d0 = a - pos, d1 = b - pos;
@@ -1359,6 +1370,45 @@ struct SecondaryEdgeDerivatives {
         double *gv = g.shapes[rec.edge.shape_id].vertices;
         accum3(gv + 3 * rec.edge.v0, da);
         accum3(gv + 3 * rec.edge.v1, db);
+    }
+};
+
+// Replay of the recorded stale reads (HitPosView): the position an event's lane would have found in the reference's scratch is
+// the latest write of an EARLIER sample of the batch to the same entry -- every sample's final state is known now -- else what
+// the batch found there (`carry`).  The event's terms go where SecondaryEdgeDerivatives would have put them: the edge's two
+// vertices, and the shading point's adjoint position, from where the replayed adjoint sweep carries it on; `live` marks the
+// lanes that sweep has to run.
+struct InjectHitEvents {
+    SceneD sc; GScene g; const HitEvent *events; int depth;
+    const double *pos; int n; const unsigned char *written; const double *carry; int entries_per_sample;      // 2 P0
+    AdjState adj; unsigned char *live;
+    RDR_FN void operator()(int i) const {
+        const HitEvent e = events[i];
+        if (e.depth != depth) return;
+        const int s = e.entry / entries_per_sample, l = e.entry - s * entries_per_sample;
+        V3 x = ld3(carry, entries_per_sample, l, 0);
+        for (int t = s - 1; t >= 0; --t)
+            if (written[t * entries_per_sample + l]) { x = ld3(pos, n, t * entries_per_sample + l, 0); break; }
+        const EdgeD edge{e.shape_id, e.v0, e.v1, 0, 0};
+        V3 a = edge_v0(sc.shapes, edge), b = edge_v1(sc.shapes, edge);
+        V3 d0 = a - e.sp_pos, d1 = b - e.sp_pos;
+        V3 dp = (cross(d1, d0) + cross(x - e.sp_pos, d1) + cross(d0, x - e.sp_pos)) * e.contrib;
+        V3 da = cross(d1, x - e.sp_pos) * e.contrib, db = cross(x - e.sp_pos, d0) * e.contrib;
+        atomic_add_f64(adj.point + (size_t)0 * adj.n + e.p, dp.x);       // (both lanes of a slot may be events: atomic adds)
+        atomic_add_f64(adj.point + (size_t)1 * adj.n + e.p, dp.y);
+        atomic_add_f64(adj.point + (size_t)2 * adj.n + e.p, dp.z);
+        live[e.p] = 1;
+        double *gv = g.shapes[e.shape_id].vertices;
+        accum3(gv + 3 * e.v0, da);
+        accum3(gv + 3 * e.v1, db);
+    }
+};
+// after a batch: what the next batch finds in the scratch: per entry the write of the batch's last sample that wrote it
+struct HitPosCarryAdvance {
+    double *carry; int entries_per_sample, S; const double *pos; int n; const unsigned char *written;
+    RDR_FN void operator()(int l) const {
+        for (int t = S - 1; t >= 0; --t)
+            if (written[t * entries_per_sample + l]) { st3(carry, entries_per_sample, l, 0, ld3(pos, n, t * entries_per_sample + l, 0)); return; }
     }
 };
 

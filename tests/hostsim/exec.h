@@ -26,6 +26,7 @@ namespace rdr {
 inline void accum(double *p, double v) { *p += v; }
 inline void accum_plain(double *p, double v) { *p += v; }
 inline void accum_texel(double *p, double v) { *p += v; }
+inline void atomic_add_f64(double *p, double v) { *p += v; }
 inline int atomic_fetch_add(int *p, int v) { int o = *p; *p += v; return o; }
 }
 
