@@ -828,9 +828,10 @@ struct Backward {
 } // namespace
 
 namespace {
-// A batched gradient render of an environment-lit scene found an edge ray that needs what EARLIER samples left in the
-// reference's hit-position scratch (HitPosView, stages_edge.h): nothing has been written to the caller's tensors yet (the
-// accumulators are folded into them at the very end) -- the call starts over, one sample per launch.
+// A batched gradient render of an environment-lit scene records the reads of the reference's hit-position scratch that reach
+// across the samples of a batch and replays them after the sweep (Backward::replay_stale_hits).  Should the event list
+// overflow (two entries per lane: not seen), nothing has been written to the caller's tensors yet (the accumulators are folded
+// into them at the very end): the call starts over, one sample per launch.
 struct RestartUnbatched {};
 // ... and scenes of that shape start that way the next time (an optimisation loop builds a Scene per iteration)
 std::atomic<uint64_t> g_unbatchable{0};
@@ -921,8 +922,9 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
     // rest sample by sample.  One worker then: the chain runs through the batches in order.
     const bool chain = (scene.has_mipmaps || scene.d.envmap != nullptr) && !no_edge_passes;      // (under an environment light: the hit-position scratch)
     // Under an environment light there is a second scratch of that kind -- the hit positions of the edge rays, read stale by the
-    // rays that reach the environment (HitPosView, stages_edge.h) -- and no way to batch a lane that reads across samples
-    // there: such a call is batched optimistically (`envmap_batches`) and starts over unbatched if a lane did (render()).
+    // rays that reach the environment (HitPosView, stages_edge.h): reads that reach across the samples of a batch are recorded
+    // and replayed after the sweep (Backward::replay_stale_hits); `envmap_batches` is false only for the second attempt of a
+    // call whose event list overflowed (render()).
     const bool batchable = sobol_plain && (lean == kLean || no_edge_passes || scene.d.envmap == nullptr || envmap_batches);
     const bool samples_independent = batchable && d_image != nullptr && image == nullptr;
     // A forward render is batched too -- of any scene: the stale scratch belongs to the edge passes -- : its launches deposit
@@ -1095,8 +1097,8 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
 
             if (d_image && !w.bwd) make_backward(w);       // first sample of this worker: the GPU is busy with the stages queued above
             if (w.bwd) w.bwd->run_sample(sample_id, rng, vs, active, num_active, q, lanes, PL, S_now, w.seg);
-            // an optimistic batch of an environment-lit scene: has a lane read across samples?  (Asked after the first and after
-            // the last batch of a worker: a scene whose edge rays escape shows it at once.)
+            // a batch of an environment-lit scene: did the list of recorded stale reads overflow?  (Asked after the first and after
+            // the last batch of a worker.)
             if (w.bwd && w.bwd->hp_violations && (b == first || b + stride >= num_batches)) {
                 int bad = 0;
                 exec::download(&bad, w.bwd->hp_violations, sizeof(int));

@@ -10,9 +10,10 @@ timeout 1200 python bench.py 2> $OUT/bench_default.err | tail -1 > $OUT/bench_de
 timeout 600 python bench.py --workload living_room_standin --spp 64 --steps 2 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_living_room_standin.json
 timeout 600 python bench.py --workload living_room_standin_envmap --spp 64 --steps 2 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_living_room_standin_envmap.json
 RDR_BATCH=1 timeout 600 python bench.py --workload living_room_standin --spp 64 --steps 2 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_living_room_standin_one_sample_per_launch.json
-{ for cfg in "256 4" "256 4 move" "256 16" "128 8" "512 4" "64 4"; do echo "== $cfg"; python tools/small_loop_timing.py $cfg 2>&1 | tail -4; done; } > $OUT/small_loop.txt
+{ for cfg in "256 4" "256 4 move" "256 16" "128 8" "512 4" "64 4"; do echo "== $cfg"; python tools/small_loop_timing.py $cfg 2>&1 | tail -4; done;
+  for sc in envmap_sphere living_room_standin living_room_standin_envmap; do for b in 16 1; do echo "== $sc 256 4, RDR_BATCH=$b"; SMALL_LOOP_SCENE=$sc RDR_BATCH=$b python tools/small_loop_timing.py 256 4 2>&1 | tail -4; done; done; } > $OUT/small_loop.txt
 python tools/parked_bytes.py 2>&1 | tail -1 > $OUT/parked.txt
-RDR_POOL_CAP_MB=49152 timeout 600 python bench.py --steps 2 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_pool_cap_48g.json
+RDR_POOL_CAP_MB=65536 timeout 600 python bench.py --steps 2 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_pool_cap_64g.json
 RDR_BATCH=1 timeout 600 python bench.py --steps 1 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_one_sample_per_launch.json
 # the multi-rank path of bench.py, rehearsed with two ranks on the ONE GPU of this box (gloo; the number is not a measurement)
 RDR_BENCH_SHARE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 1 --spp 32 --no-cpu-baseline --no-profile --no-self-check --no-alone-leg 2> $OUT/bench_two_ranks_shared_gpu.err | tail -1 > $OUT/bench_two_ranks_shared_gpu.json
@@ -25,5 +26,5 @@ RDR_NO_OVERLAP=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format cs
 cp $OUT/stats_alone/*/*_kernel_stats.csv $OUT/kernel_stats_alone.csv
 rm -rf $OUT/stats $OUT/stats_alone
 cd $GRAFT_REPO_ROOT
-cat $OUT/pytest.log | tail -8; cut -c1-300 $OUT/bench_default.json; echo; for f in living_room_standin living_room_standin_envmap living_room_standin_one_sample_per_launch pool_cap_48g one_sample_per_launch two_ranks_shared_gpu; do python -c "
+cat $OUT/pytest.log | tail -8; cut -c1-300 $OUT/bench_default.json; echo; for f in living_room_standin living_room_standin_envmap living_room_standin_one_sample_per_launch pool_cap_64g one_sample_per_launch two_ranks_shared_gpu; do python -c "
 import json; d=json.loads(open('$OUT/bench_$f.json').read()); print('$f', round(d['value'],2), 'roofline', round(d['roofline']['frac'],3))"; done; cat $OUT/small_loop.txt | grep -E "==|iteration"; cat $OUT/parked.txt $OUT/scene_build.txt

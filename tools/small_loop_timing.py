@@ -11,8 +11,10 @@ import scenes
 dev = torch.device('cuda:0')
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-sc = scenes.bunny_box(dev, resolution=(res, res))
+# SMALL_LOOP_SCENE=<builder of tests/scenes.py> (default bunny_box), e.g. envmap_sphere / living_room_standin_envmap
+sc = getattr(scenes, os.environ.get('SMALL_LOOP_SCENE', 'bunny_box'))(dev, resolution=(res, res))
 verts = [s.vertices for s in sc.shapes]
+bounces = 6 if os.environ.get('SMALL_LOOP_SCENE', '').startswith('living_room') else 4
 for v in verts:
     v.requires_grad_(True)
 # `move`: the vertices change every iteration (a geometry optimisation: every Scene builds its edge structures);
@@ -26,7 +28,7 @@ for it in range(12):
                 v.add_(1e-4 * torch.sin(torch.arange(v.numel(), device=v.device, dtype=torch.float32) + it).reshape(v.shape))
     torch.cuda.synchronize()
     t0 = time.time()
-    args = RenderFunction.serialize_scene(sc, spp, 4, sampler_type=rd.SamplerType.sobol, device=dev, backend=rd)
+    args = RenderFunction.serialize_scene(sc, spp, bounces, sampler_type=rd.SamplerType.sobol, device=dev, backend=rd)
     t1 = time.time()
     img = RenderFunction.apply(it + 1, *args)
     torch.cuda.synchronize()
