@@ -461,7 +461,7 @@ static __global__ void __launch_bounds__(256) compact_scan(int *block_counts, in
 
 template <class P>
 __global__ void __launch_bounds__(256) compact_scatter(const int *in, int n, const int *count, P pred, const int *block_offsets, int *out,
-                                                        const int *out_base) {
+                                                        const int *out_base, int *pos_out) {
     __shared__ int wave_tot[kCompactItems][4];
     if (count) { const int c = *count; n = c < n ? c : n; }
     if (out_base) out += *out_base;
@@ -481,7 +481,10 @@ __global__ void __launch_bounds__(256) compact_scatter(const int *in, int n, con
     for (int it = 0; it < kCompactItems; ++it) {
         int before = 0;
         for (int w = 0; w < wave; ++w) before += wave_tot[it][w];
-        if (keep[it]) out[off + before + rank[it]] = val[it];
+        if (keep[it]) {
+            out[off + before + rank[it]] = val[it];
+            if (pos_out) pos_out[off + before + rank[it]] = base + it * 256 + (int)threadIdx.x;      // where the item came from
+        }
         off += wave_tot[it][0] + wave_tot[it][1] + wave_tot[it][2] + wave_tot[it][3];
     }
 }
@@ -496,8 +499,10 @@ CompactScratch &compact_scratch(int nblocks);
 // compact_dev: nothing comes back to the host.  The kept items go to out[*append_at ...] (append_at null: out[0 ...]) and
 // the returned Count says how many items `out` now holds (in device memory) and what the host can bound it by.
 int *new_count();                    // trace.hip: a device int from a per-thread ring, for one compaction's result
+// `pos_out` (optional): pos_out[k] = position in the input list of the k-th kept item.
 template <class P>
-inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const Count *append_at = nullptr, int *dyn = nullptr, int inc = 0) {
+inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const Count *append_at = nullptr, int *dyn = nullptr, int inc = 0,
+                         int *pos_out = nullptr) {
     const int base_upper = append_at ? append_at->upper : 0;
     if (n.upper <= 0) return append_at ? *append_at : Count(0);
     int nblocks = (n.upper + kCompactTile - 1) / kCompactTile;
@@ -510,7 +515,7 @@ inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const 
     hipLaunchKernelGGL(compact_count<P>, dim3(nblocks), dim3(256), 0, st, in, n.upper, n.dev, pred, sc.block_counts);
     const int ticket = ++sc.ticket;
     hipLaunchKernelGGL(compact_scan, dim3(1), dim3(256), 0, st, sc.block_counts, nblocks, sc.total, ticket, result, base, n.upper, n.dev, dyn, inc);
-    hipLaunchKernelGGL(compact_scatter<P>, dim3(nblocks), dim3(256), 0, st, in, n.upper, n.dev, pred, sc.block_counts, out, base);
+    hipLaunchKernelGGL(compact_scatter<P>, dim3(nblocks), dim3(256), 0, st, in, n.upper, n.dev, pred, sc.block_counts, out, base, pos_out);
     check(hipGetLastError(), "compact launch");
     return Count(result, n.upper + base_upper);
 }

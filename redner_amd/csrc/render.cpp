@@ -64,6 +64,19 @@ VSlice make_slice(Arena &a, int n, bool with_occl, bool with_rdiff = true) {
 struct Queues {
     rt::RayRec *nee, *bsdf;
     rt::HitRec *h_nee, *h_bsdf;
+    int *pos[2];                   // fused bounces: queue slot of every entry of the current live-lane list (ping-pong)
+};
+
+// Bounces of one chain of paths (the camera paths of a sample batch, or the sub-paths of one edge pass).  Fused form (Sobol'
+// sampler; RDR_TUNE_NO_FUSED_BOUNCE switches it off): the stage that evaluates bounce d also draws the rays of bounce d + 1
+// (stages_fwd.h: BounceContribSample), so from the second bounce on the rays sit at the positions of the PREVIOUS live-lane
+// list: `queue_n` entries, a lane's slot in `qpos`.
+struct BounceChain {
+    bool fused = false;
+    bool have_rays = false;        // the rays of the bounce about to run were drawn by the previous bounce's stage
+    const int *qpos = nullptr;
+    exec::Count queue_n{0};
+    int flip = 0;
 };
 
 struct ChannelLayout { int nd, radiance_dim; ChannelsD ch; };
@@ -137,12 +150,18 @@ inline int side_index(int k, int lanes) { return lanes >= (1 << 19) ? k + 2 : k;
 
 // One NEE + BSDF bounce over the live lanes of `v`; fills `vn` and the next live-lane list.  The lane count stays on the
 // device (exec::Count); `dyn` / `dyn_inc`: the dimension counter that advances if this bounce had lanes to run.
+// `chain` / `vnn` (fused form): the chain's state, and the slice that receives the rays of the NEXT bounce (null: this is the
+// chain's last bounce)
 exec::Count run_bounce(const Scene &scene, const SceneD &sd, const SamplerD &rng, int dim, int rng_shift,
                        const int *active, exec::Count num_active, const VSlice &v, const VSlice &vn,
                        const Queues &q, const Sink &sink, int *next_active, int *dyn = nullptr, int dyn_inc = 0,
-                       bool shadow_rays_coherent = false) {
+                       bool shadow_rays_coherent = false, BounceChain *chain = nullptr, const VSlice *vnn = nullptr) {
     const int lean = scene_kind(scene, sink.ch);
-    launch_v(lean, num_active, BounceSample{sd, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
+    const bool fused = chain && chain->fused;
+    const bool drawn = fused && chain->have_rays;                      // this bounce's rays exist already
+    const exec::Count queue_n = drawn ? chain->queue_n : num_active;
+    const int *qpos = drawn ? chain->qpos : nullptr;
+    if (!drawn) launch_v(lean, num_active, BounceSample{sd, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
     // the shadow-ray and the continuation-ray queue are traced side by side: both kernels wait on dependent loads
     // with a fraction of their lanes active (profiles/r1_notes.md), so they fill each other's gaps
     const bool side = overlap_on();
@@ -156,17 +175,35 @@ exec::Count run_bounce(const Scene &scene, const SceneD &sd, const SamplerD &rng
         {
             exec::StreamScope on(exec::side_stream(side_index(1, num_active.upper)));
             queued->gate(exec::ctx().stream);
-            exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true, shadow_rays_coherent);
+            exec::trace(scene.bvh, q.nee, q.h_nee, queue_n, true, shadow_rays_coherent);
             shadow_done->after(exec::ctx().stream);
         }
-        exec::trace(scene.bvh, q.bsdf, q.h_bsdf, num_active, false);
+        exec::trace(scene.bvh, q.bsdf, q.h_bsdf, queue_n, false);
         shadow_done->gate(main_stream);
     } else {
-        exec::trace(scene.bvh, q.nee, q.h_nee, num_active, true, shadow_rays_coherent);
-        exec::trace(scene.bvh, q.bsdf, q.h_bsdf, num_active, false);
+        exec::trace(scene.bvh, q.nee, q.h_nee, queue_n, true, shadow_rays_coherent);
+        exec::trace(scene.bvh, q.bsdf, q.h_bsdf, queue_n, false);
     }
-    launch_v(lean, num_active, BounceContrib{sd, rng, dim, rng_shift, active, v, vn, q.h_nee, q.h_bsdf, sink});
-    return exec::compact_dev(active, num_active, next_active, KeepHit{vn.shape}, nullptr, dyn, dyn_inc);
+    const BounceContrib contrib{sd, rng, dim, rng_shift, active, v, vn, q.h_nee, q.h_bsdf, sink};
+    if (!fused) {
+        launch_v(lean, num_active, contrib);
+        return exec::compact_dev(active, num_active, next_active, KeepHit{vn.shape}, nullptr, dyn, dyn_inc);
+    }
+    if (vnn) {
+        // ... and the rays of the next bounce: the next list's lanes are drawn HERE, at this list's positions
+        launch_v(lean, num_active, BounceContribSample{contrib, BounceSample{sd, rng, dim + 7, rng_shift, active, vn, *vnn, q.nee, q.bsdf}, qpos});
+    } else if (qpos) {
+        launch_v(lean, num_active, BounceContribSample{contrib, BounceSample{sd, rng, dim + 7, rng_shift, active, vn, vn, nullptr, nullptr}, qpos, 1});
+    } else {
+        launch_v(lean, num_active, contrib);
+    }
+    int *pos_out = q.pos[chain->flip];
+    chain->flip ^= 1;
+    const exec::Count next = exec::compact_dev(active, num_active, next_active, KeepHit{vn.shape}, nullptr, dyn, dyn_inc, pos_out);
+    chain->have_rays = vnn != nullptr;
+    chain->qpos = pos_out;
+    chain->queue_n = num_active;
+    return next;
 }
 
 // ---- gradient accumulators ------------------------------------------------------------------------
@@ -522,12 +559,15 @@ struct Backward {
         const bool has_lights = sd.num_lights > 0;
         if (need_lights && !has_lights) return;
         int cur = 1;
+        BounceChain chain;
+        // (lean scenes: the textured forms of the fused stage need 430-520 B of scratch per lane at their register cap)
+        chain.fused = pcg_edge == nullptr && lean == kLean && !tuning().has(RDR_TUNE_NO_FUSED_BOUNCE);
         for (int depth = first_depth, k = 0; depth < B && n_act.upper > 0; ++depth, ++k) {
             const VSlice &m = (k % 2 == 0) ? ea : eb;
             const VSlice &nx = (k % 2 == 0) ? eb : ea;
             int nxt = (cur == 1) ? 2 : 1;
             exec::Count next = run_bounce(scene, sd, edge_rng_at(rng_edge, edim, dyn, seg), edim, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt],
-                                          batch.on ? nullptr : dyn, 7);
+                                          batch.on ? nullptr : dyn, 7, false, &chain, depth + 1 < B ? &m : nullptr);
             // a batch: the counter of every sample that had lanes in this bounce (the list is ascending in the lane id)
             if (batch.on) exec::launch(cur_S, BumpDynList{dyn, elist[cur], n_act.dev, n_act.upper, seg, 2 * batch.P0, 7});
             edge_rng_consumed(n_slots, 7, n_act.dev);
@@ -1039,6 +1079,7 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
         w.active = w.arena.get<int>((size_t)(B + 1) * PL);
         w.q.nee = w.arena.get<rt::RayRec>((size_t)2 * PL); w.q.bsdf = w.arena.get<rt::RayRec>((size_t)2 * PL);
         w.q.h_nee = w.arena.get<rt::HitRec>((size_t)2 * PL); w.q.h_bsdf = w.arena.get<rt::HitRec>((size_t)2 * PL);
+        w.q.pos[0] = w.arena.get<int>((size_t)2 * PL); w.q.pos[1] = w.arena.get<int>((size_t)2 * PL);
         w.num_active.assign(B + 2, exec::Count(0));
         if (pcg_main) w.main_dyn = w.arena.get<int>(1);
         if (batch.on) w.seg = w.arena.get<int>((size_t)(B + 1) * (kMaxBatch + 1));
@@ -1086,10 +1127,13 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
             // queued and one without lanes does nothing (the live-lane counts stay on the device, exec::Count) ----
             int dim = opt.sample_pixel_center ? 0 : 2;
             const int dim_first = dim;
+            BounceChain chain;
+            chain.fused = pcg_main == nullptr && lean == kLean && !tune.has(RDR_TUNE_NO_FUSED_BOUNCE);
             for (int d = 0; d < B && num_active[d].upper > 0 && has_lights; ++d) {
                 num_active[d + 1] = run_bounce(scene, sd, rng, dim, 0, active + (size_t)d * PL, num_active[d],
                                                vs[d], vs[d + 1], q, sink_of(d + 1), active + (size_t)(d + 1) * PL, w.main_dyn, 7,
-                                               d == 0);        // shadow rays of the camera vertices: neighbouring origins
+                                               d == 0,         // shadow rays of the camera vertices: neighbouring origins
+                                               &chain, d + 1 < B ? &vs[d + 2] : nullptr);
                 if (num_active[d + 1].dev && d_image) segments(d + 1);
                 dim += 7;
             }

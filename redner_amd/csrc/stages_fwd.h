@@ -347,8 +347,12 @@ struct BounceSample {
     rt::RayRec *q_nee, *q_bsdf;
     RDR_FN void operator()(int idx) const {
         int p = active[idx];
-        int slot = p >> rng_shift;
         VertexCtx c = load_vertex(sc, v, p);
+        RDR_INLINE_CALL sample_from(c, p, idx);
+    }
+    // the bounce of lane p from its vertex `c`; the two rays go to queue slot idx
+    RDR_FN void sample_from(const VertexCtx &c, int p, int idx) const {
+        int slot = p >> rng_shift;
         // next-event estimation ray
         LightDraw ld = draw_light(rng, slot, dim);
         LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
@@ -490,7 +494,13 @@ struct BounceContrib {
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v); lean_slice(vn); lean_channels(sink.ch); }
     RDR_FN void make_mid() { mid_scene(sc); lean_channels(sink.ch); }
     RDR_FN void operator()(int idx) const {
-        int p = active[idx];
+        VertexCtx next;
+        RDR_INLINE_CALL contrib(active[idx], idx, next);
+    }
+    // the bounce of lane p whose query results sit in queue slot qi; `next`: the vertex the continuation ray reached (valid
+    // when the function returns true) -- what load_vertex(sc, vn, p) would rebuild from the slice: BounceContribSample goes on
+    // from it without the reload
+    RDR_FN bool contrib(int p, int idx, VertexCtx &next) const {
         int slot = p >> rng_shift;
         VertexCtx c = load_vertex(sc, v, p);
         LightDraw ld = draw_light(rng, slot, dim);
@@ -504,8 +514,16 @@ struct BounceContrib {
         Surf bp = surf_zero();
         if (hb.shape >= 0) {
             RayDiff tmp;
-            bp = surf_at(sc.shapes[hb.shape], hb.prim, load_ray(vn, p), load_rdiff(vn, p), tmp, !sc.no_diffs);
+            next.ray = load_ray(vn, p);
+            next.rd_in = load_rdiff(vn, p);
+            bp = surf_at(sc.shapes[hb.shape], hb.prim, next.ray, next.rd_in, tmp, !sc.no_diffs);
             if (vn.erd) st_erd(vn, p, tmp);
+            next.rd_surf = tmp;
+            next.shape = &sc.shapes[hb.shape];
+            next.mat = &sc.materials[next.shape->material_id];
+            next.sp = bp; next.sp.plain = sc.plain_materials;
+            next.wi = -next.ray.dir;
+            next.mrough = vn.mrough[p];
         }
         V3 thr = ld3(v.thr, v.n, p, 0);
         BounceEval e = eval_bounce(sc, c, thr, !blocked, pk, lp, ld.uv, hb.shape, bp, load_ray(vn, p).dir);
@@ -516,6 +534,38 @@ struct BounceContrib {
             px[0] += float(sink.weight * pc.x); px[1] += float(sink.weight * pc.y); px[2] += float(sink.weight * pc.z);
         }
         if (sink.edge_contrib) sink.edge_contrib[p] += sum(sink.weight * pc);
+        return hb.shape >= 0;
+    }
+};
+
+// ---- stage: BounceContrib of bounce d and BounceSample of bounce d + 1 in one launch (round 4) ------------------------------
+// The vertex a lane's continuation ray reached is rebuilt by BounceContrib (hit triangle -> surface point) and would be
+// rebuilt again, from the slice, by the next bounce's BounceSample: here the lane goes straight on and draws its next two rays
+// from the vertex it has in registers -- one launch (and one launch tail) per bounce less, no reload of ray / ids / triangle
+// record.  The lanes are those of bounce d's list; a lane whose ray missed leaves two dead queue slots.  The rays of bounce
+// d + 1 therefore sit at the positions of bounce d's list: `qpos` (from the compaction that made this list) says where a
+// lane's query results are.  Same arithmetic on the same operands as the two stages: bit-identical results.  Sobol' only: the
+// PCG sampler's states advance between the bounces (render.cpp).
+struct BounceContribSample {
+    static constexpr int kMidBlocksPerCU = 3;
+    static constexpr int kMinBlocksPerCU = 3;
+    BounceContrib c; BounceSample s;          // s: v = c.vn, vn = the slice after it, dim = c.dim + 7 (its `active` is not used)
+    const int *qpos;                          // queue slot of list position idx (null: idx itself)
+    int contrib_only = 0;                     // the chain's last bounce: nothing follows
+    RDR_FN void make_lean() { c.make_lean(); s.make_lean(); }
+    RDR_FN void make_mid() { c.make_mid(); s.make_mid(); }
+    RDR_FN void operator()(int idx) const {
+        const int p = c.active[idx];
+        VertexCtx next;
+        bool hit;
+        RDR_INLINE_CALL hit = c.contrib(p, qpos ? qpos[idx] : idx, next);
+        if (contrib_only) return;
+        if (hit) { RDR_INLINE_CALL s.sample_from(next, p, idx); }
+        else {
+            Ray dead = make_ray(v3(0), v3(0));
+            put_ray(s.q_nee, idx, dead, true);
+            put_ray(s.q_bsdf, idx, dead, true);
+        }
     }
 };
 

@@ -107,10 +107,12 @@ inline int compact(const int *in, int n, int *out, const P &pred) {
     return c;
 }
 template <class P>
-inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const Count *append_at = nullptr, int *dyn = nullptr, int inc = 0) {
+inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const Count *append_at = nullptr, int *dyn = nullptr, int inc = 0,
+                         int *pos_out = nullptr) {
     const int n_in = n.value();
     const int base = append_at ? append_at->value() : 0;
     int *result = new_count();
+    if (pos_out) { int c = 0; for (int i = 0; i < n_in; ++i) { const int p = in ? in[i] : i; if (pred(p)) pos_out[base + c++] = i; } }
     *result = base + compact(in, n_in, out + base, pred);
     if (dyn && n_in > 0) *dyn += inc;
     return Count(result, n.upper + (append_at ? append_at->upper : 0));
