@@ -150,6 +150,14 @@ inline int side_index(int k, int lanes) { return lanes >= (1 << 19) ? k + 2 : k;
 
 // One NEE + BSDF bounce over the live lanes of `v`; fills `vn` and the next live-lane list.  The lane count stays on the
 // device (exec::Count); `dyn` / `dyn_inc`: the dimension counter that advances if this bounce had lanes to run.
+// When to fuse (measured, bunny_box, `profiles/r4_notes.md`): a 256 x 256 x 4 spp optimisation-loop iteration -- chains of
+// launches that each last as long as their longest lane -- 12.4 -> 11.5 ms; the 1024 x 1024 benchmark 62.7 -> 58.5 Msamples/s:
+// the fused stage holds 188 registers (two waves per SIMD where BounceContrib runs three and BounceSample five) and the next
+// bounce's queues keep the dead slots of the lanes that missed.  So: chains of up to 2^19 lanes; plain scenes only (the textured
+// forms of the fused stage need 430-520 B of scratch per lane at their register cap); the stateless sampler only.
+inline bool fuse_bounces(bool pcg, int kind, int chain_lanes) {
+    return !pcg && kind == kLean && chain_lanes <= (1 << 19) && !tuning().has(RDR_TUNE_NO_FUSED_BOUNCE);
+}
 // `chain` / `vnn` (fused form): the chain's state, and the slice that receives the rays of the NEXT bounce (null: this is the
 // chain's last bounce)
 exec::Count run_bounce(const Scene &scene, const SceneD &sd, const SamplerD &rng, int dim, int rng_shift,
@@ -560,8 +568,7 @@ struct Backward {
         if (need_lights && !has_lights) return;
         int cur = 1;
         BounceChain chain;
-        // (lean scenes: the textured forms of the fused stage need 430-520 B of scratch per lane at their register cap)
-        chain.fused = pcg_edge == nullptr && lean == kLean && !tuning().has(RDR_TUNE_NO_FUSED_BOUNCE);
+        chain.fused = fuse_bounces(pcg_edge != nullptr, lean, n_act.upper);
         for (int depth = first_depth, k = 0; depth < B && n_act.upper > 0; ++depth, ++k) {
             const VSlice &m = (k % 2 == 0) ? ea : eb;
             const VSlice &nx = (k % 2 == 0) ? eb : ea;
@@ -1128,7 +1135,7 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
             int dim = opt.sample_pixel_center ? 0 : 2;
             const int dim_first = dim;
             BounceChain chain;
-            chain.fused = pcg_main == nullptr && lean == kLean && !tune.has(RDR_TUNE_NO_FUSED_BOUNCE);
+            chain.fused = fuse_bounces(pcg_main != nullptr, lean, 2 * lanes);
             for (int d = 0; d < B && num_active[d].upper > 0 && has_lights; ++d) {
                 num_active[d + 1] = run_bounce(scene, sd, rng, dim, 0, active + (size_t)d * PL, num_active[d],
                                                vs[d], vs[d + 1], q, sink_of(d + 1), active + (size_t)(d + 1) * PL, w.main_dyn, 7,

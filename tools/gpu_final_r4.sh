@@ -11,7 +11,7 @@ timeout 600 python bench.py --workload living_room_standin --spp 64 --steps 2 --
 timeout 600 python bench.py --workload living_room_standin_envmap --spp 64 --steps 2 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_living_room_standin_envmap.json
 RDR_BATCH=1 timeout 600 python bench.py --workload living_room_standin --spp 64 --steps 2 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_living_room_standin_one_sample_per_launch.json
 { for cfg in "256 4" "256 4 move" "256 16" "128 8" "512 4" "64 4"; do echo "== $cfg"; python tools/small_loop_timing.py $cfg 2>&1 | tail -4; done;
-  for sc in envmap_sphere living_room_standin living_room_standin_envmap; do for b in 16 1; do echo "== $sc 256 4, RDR_BATCH=$b"; SMALL_LOOP_SCENE=$sc RDR_BATCH=$b python tools/small_loop_timing.py 256 4 2>&1 | tail -4; done; done; } > $OUT/small_loop.txt
+  for sc in living_room_standin living_room_standin_envmap; do for b in 16 1; do echo "== $sc 256 4, RDR_BATCH=$b"; SMALL_LOOP_SCENE=$sc RDR_BATCH=$b python tools/small_loop_timing.py 256 4 2>&1 | tail -4; done; done; } > $OUT/small_loop.txt
 python tools/parked_bytes.py 2>&1 | tail -1 > $OUT/parked.txt
 RDR_POOL_CAP_MB=65536 timeout 600 python bench.py --steps 2 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_pool_cap_64g.json
 RDR_BATCH=1 timeout 600 python bench.py --steps 1 --no-cpu-baseline --no-profile --no-self-check 2> /dev/null | tail -1 > $OUT/bench_one_sample_per_launch.json
