@@ -17,6 +17,11 @@ outside the timed region and reported separately; inputs 
 `--workload living_room_standin` is BASELINE config 5's stand-in (tests/scenes.py): the general kernels
 (mip-mapped textures, two-sided materials, ray differentials), max_bounces 6, camera-pose gradients.
 
+The library runs with its defaults (at most 16 GiB of device memory parked between calls: 7 Sobol' samples of this frame per
+launch); a process that raises the bound (redner.set_pool_cap_mb(65536) / RDR_POOL_CAP_MB) gets 16 samples per launch and
++1-2 % (profiles/r4_notes.md).  per_rank_ms_per_step / per_rank_render_ms_per_step: every rank's wall time per step and the part
+of it inside render() (the rest: the one collective per step + waiting for the slowest rank).
+
 Extra objects in the JSON line:
   roofline      -- the closest-hit traversal kernel by SURVEY.md section 8d: algorithmic bytes (40 B per ray +
                    32 B per node record + 36 B per triangle tested, counted by the instrumented kernel on the
