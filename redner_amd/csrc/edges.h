@@ -278,6 +278,7 @@ void publish_edge_data(EdgeData &ed);
 // edges_gpu.cpp (not part of the CPU debugging harness): both hierarchies, leaf order, sampler and gather records on the
 // calling thread's stream; and the node arrays back on the host for rdr_debug_dump_edges.
 void build_edge_trees_device(EdgeData &ed);
+void drop_gather_cache();                        // the billboard hierarchy kept for the next Scene's refit (rdr_trim_cache)
 void gather_hierarchy_device(EdgeData &ed);      // edges_gpu.cpp: EdgeSceneD::gather from ed.gather_boxes (build or refit, by kernels)
 void download_edge_trees(EdgeData &ed);
 void delete_edge_data(EdgeData *e);

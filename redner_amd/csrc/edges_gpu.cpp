@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <stdexcept>
 
 namespace rdr {
@@ -659,9 +660,18 @@ __global__ void __launch_bounds__(256) gather_ids_kernel(const int *canon_ids, c
     const int sl = blockIdx.x * 256 + threadIdx.x;
     if (sl < slots) { out[2 * sl] = 0; out[2 * sl + 1] = cur_of[canon_ids[2 * sl + 1]]; }
 }
+namespace {
+struct GatherTreeCache { std::mutex lock; std::vector<EdgeD> canon; std::shared_ptr<rt::BvhDev> tree; int device = -1; };
+GatherTreeCache *gather_tree_cache() { static GatherTreeCache *c = new GatherTreeCache(); return c; }
+}
+void drop_gather_cache() {
+    GatherTreeCache *c = gather_tree_cache();
+    std::lock_guard<std::mutex> lk(c->lock);            // (the edge-builder thread may be in gather_hierarchy_device)
+    c->canon.clear(); c->tree.reset(); c->device = -1;
+}
 void gather_hierarchy_device(EdgeData &ed) {
-    struct Cache { std::vector<EdgeD> canon; std::shared_ptr<rt::BvhDev> tree; int device = -1; };
-    static Cache *cache = new Cache();                 // one build at a time (scene.cpp: EdgeBuilder)
+    GatherTreeCache *cache = gather_tree_cache();      // one build at a time (scene.cpp: EdgeBuilder); rdr_trim_cache() may drop it
+    std::lock_guard<std::mutex> cache_lock(cache->lock);
     hipStream_t s = exec::ctx().stream;
     const int nc = (int)ed.gather_cur_of.size();
     if (nc == 0) return;

@@ -379,6 +379,7 @@ struct Backward {
     GradStore &grads;              // shared by the sample workers: every add is an atomic
     Arena arena;
     AdjState adj;
+    int adj_point_doubles = kAdjPointDoubles;
 
     ChannelsD ch;
     int lean = kGeneral;               // which stage specialisation the scene qualifies for (kLean / kMid / kGeneral)
@@ -397,7 +398,9 @@ struct Backward {
         adj.n = P; adj.plain = 0;
         adj.thr = arena.get<double>((size_t)3 * P);
         adj.ray_dir = arena.get<double>((size_t)3 * P);
-        adj.point = arena.get<double>((size_t)kAdjPointDoubles * P);
+        // (the lean stages keep no uv / uv-derivative / colour adjoints: 15 of the 24 components, stages_bwd.h: AdjState::plain)
+        adj_point_doubles = lean == kLean ? 15 : kAdjPointDoubles;
+        adj.point = arena.get<double>((size_t)adj_point_doubles * P);
         const bool edges_on = scene.edges && scene.edges->d.num_edges > 0 &&
                               (scene.use_primary_edges || scene.use_secondary_edges);
         if (edges_on) {
@@ -607,7 +610,7 @@ struct Backward {
         //  doubles of a batch that is smaller than the buffers -- the last one of a call -- are not its lanes' records)
         exec::zero(adj.thr, sizeof(double) * 3 * stride);
         exec::zero(adj.ray_dir, sizeof(double) * 3 * stride);
-        exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * stride);
+        exec::zero(adj.point, sizeof(double) * adj_point_doubles * stride);
         const int dim0 = opt.sample_pixel_center ? 0 : 2;
         const bool pickh_fused = tuning().has(RDR_TUNE_PICKH_FUSED);     // A/B: the one-loop form
         const bool pickh_lazy = tuning().has(RDR_TUNE_PICKH_LAZY);       // A/B: per-field node loads
@@ -854,7 +857,7 @@ struct Backward {
         const int lanes = cur_S * batch.P0;
         exec::zero(adj.thr, sizeof(double) * 3 * stride);
         exec::zero(adj.ray_dir, sizeof(double) * 3 * stride);
-        exec::zero(adj.point, sizeof(double) * kAdjPointDoubles * stride);
+        exec::zero(adj.point, sizeof(double) * adj_point_doubles * stride);
         exec::zero(replay_live, (size_t)stride);
         const exec::Count n_events(hp_event_count, hp_event_cap);
         const int dim0 = opt.sample_pixel_center ? 0 : 2;
@@ -1012,7 +1015,7 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
             const double lanes = (double)S_try * P;
             const int wk = !samples_independent ? 1 : (tune.workers > 0 ? tune.workers : (lanes < (double)(1 << 20) ? 2 : 1));
             // (measured, bunny_box at max_bounces 4: 2.9 KB per lane with ray differentials, 2.0 KB without -- the lean kernels)
-            double per_lane = (lean == kLean ? 280.0 * (B + 1) + 760.0 : 400.0 * (B + 1) + 1200.0) * wk;
+            double per_lane = (lean == kLean ? 270.0 * (B + 1) + 690.0 : 400.0 * (B + 1) + 1200.0) * wk;
             if (forward_batches) per_lane += 4.0 * lay.nd * (B + 1);
             if (d_image) per_lane += 4.0 * lay.nd;
             return per_lane * lanes;

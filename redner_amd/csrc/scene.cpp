@@ -158,9 +158,14 @@ struct EdgeCache {
     std::shared_future<std::shared_ptr<EdgeData>> result;
 };
 static EdgeCache *edge_cache() { static EdgeCache *c = new EdgeCache(); return c; }
+// The last triangle hierarchy that was BUILT (index buffers + the build): a Scene with the same connectivity refits a copy of it.
+struct TopologyCache { std::vector<std::vector<int>> indices; rt::BvhHost bvh; std::shared_ptr<rt::BvhDev> dev; int gpu_index = -1; };
+static TopologyCache *topology_cache() { static TopologyCache *c = new TopologyCache(); return c; }
 void drop_edge_cache() {
     EdgeCache *c = edge_cache();
     *c = EdgeCache();                // the device structures go when the last Scene that shares them does
+    *topology_cache() = TopologyCache();
+    drop_gather_cache();
 }
 
 Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, int num_shapes,
@@ -363,11 +368,10 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     // hierarchy (raytri.h), and it is rebuilt once its inner surface area has grown by more than 30 %.  RDR_BUILD_NO_REFIT: always build.
     // On the GPU build the hierarchy never exists on the host: bvh_gpu.cpp builds it from the caller's device arrays, or --
     // same connectivity as the last build -- refits a copy of that build's records (below, once the shape table is uploaded).
-    struct TopologyCache { std::vector<std::vector<int>> indices; rt::BvhHost bvh; std::shared_ptr<rt::BvhDev> dev; int gpu_index = -1; };
-    static TopologyCache *topo_cache = new TopologyCache();          // guarded by the API lock (capi.cpp)
+    TopologyCache *topo_cache = topology_cache();                    // guarded by the API lock (capi.cpp)
     const bool refit_allowed = !(s.build_flags & RDR_BUILD_NO_REFIT);
     rt::BvhHost bvh_built;
-    auto bvh_job = hostpool::run([&meshes, &bvh_built, &s, refit_allowed] {      // (joins in its destructor on an early exit)
+    auto bvh_job = hostpool::run([&meshes, &bvh_built, &s, refit_allowed, topo_cache] {      // (joins in its destructor on an early exit)
         if (exec::kDeviceBvh) return;
         bool same = refit_allowed && topo_cache->indices.size() == s.h_indices.size() && !topo_cache->bvh.nodes.empty();
         for (size_t i = 0; same && i < s.h_indices.size(); ++i) same = topo_cache->indices[i] == s.h_indices[i];

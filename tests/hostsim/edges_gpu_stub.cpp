@@ -6,6 +6,7 @@ namespace rdr {
 void build_edge_trees_device(EdgeData &) { throw std::runtime_error("harness: no device edge builder"); }
 void download_edge_trees(EdgeData &) { throw std::runtime_error("harness: no device edge builder"); }
 void gather_hierarchy_device(EdgeData &) { throw std::runtime_error("harness: no device edge builder"); }
+void drop_gather_cache() {}
 }
 
 #include "bvh_gpu.h"
