@@ -1014,8 +1014,9 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
         auto bytes_needed = [&](int S_try) {
             const double lanes = (double)S_try * P;
             const int wk = !samples_independent ? 1 : (tune.workers > 0 ? tune.workers : (lanes < (double)(1 << 20) ? 2 : 1));
-            // (measured, bunny_box at max_bounces 4: 2.9 KB per lane with ray differentials, 2.0 KB without -- the lean kernels)
-            double per_lane = (lean == kLean ? 270.0 * (B + 1) + 690.0 : 400.0 * (B + 1) + 1200.0) * wk;
+            // (measured, bunny_box at max_bounces 4: 2.9 KB per lane with ray differentials, 1.98 KB for the lean kernels, which keep
+            //  neither them nor the uv / colour adjoints)
+            double per_lane = (lean == kLean ? 260.0 * (B + 1) + 660.0 : 400.0 * (B + 1) + 1200.0) * wk;
             if (forward_batches) per_lane += 4.0 * lay.nd * (B + 1);
             if (d_image) per_lane += 4.0 * lay.nd;
             return per_lane * lanes;
