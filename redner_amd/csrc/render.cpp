@@ -1026,8 +1026,8 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
         // ~25 ms per GB on a box that has been in use (a fresh box allocates 48 GB in no time, which is how this went unnoticed
         // for a round).  The 256-spp benchmark in 16-sample batches (48 GB of buffers) ran at 64.3 Msamples/s on a fresh box and
         // at 50.1 after the test suite had run there; a 32-spp gradient render of the config-5 stand-in at 12.4 against 28.6 in
-        // 4-sample batches (profiles/r4_notes.md).  So a batch is as large as fits the cache -- 5 samples of 1024 x 1024 by
-        // default (63 Msamples/s), 16 once the caller raises the bound (rdr_set_pool_cap_mb(49152): 64.8).
+        // 4-sample batches (profiles/r4_notes.md).  So a batch is as large as fits the cache -- 8 samples of 1024 x 1024 by
+        // default (63 Msamples/s), 16 once the caller raises the bound (rdr_set_pool_cap_mb(65536): 64-65).
         if (tune.batch_lanes == 0 && tune.mem_available_mb < 0) {
             const double cap = (double)exec::pool_cap_bytes();
             while (batch.S > 1 && bytes_needed(batch.S) > cap) --batch.S;
