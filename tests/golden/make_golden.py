@@ -153,6 +153,9 @@ CONFIG_CASES = {
     # BASELINE config 5's stand-in (tests/scenes.py) at a size where the mid-specialised kernels run with full waves,
     # both sample-independent streams and mip-mapped texture gradients (texel tensors: 512 x 512 x 3 per material)
     'living_room_standin_256x256x4': ('living_room_standin', 256, 4, 6),
+    # ... and its environment-map + SVBRDF-texture variant at 8 spp (round 4): two sample batches of four on the GPU -- chain mode
+    # (mip levels), the replay of stale hit positions (edge rays that leave the open front of the room), the general kernels
+    'living_room_standin_envmap_256x256x8': ('living_room_standin_envmap', 256, 8, 6),
 }
 
 # Cases whose backward pass can only be reproduced sample-for-sample by a build that shares the oracle's libm
@@ -399,8 +402,10 @@ def main():
     # wrote (slot- vs lane-indexed, src/edge.cpp:608 vs src/scene.cpp:585), i.e. whatever malloc returned.
     # Force every large allocation onto fresh zero pages so the fixtures do not depend on heap history;
     # this only matters for scenes with mip-mapped textures.  glibc reads the variable at start-up.
-    if os.environ.get('MALLOC_MMAP_THRESHOLD_') != '65536':
+    # (MALLOC_PERTURB_=255, round 4: glibc zero-fills every chunk it hands out, also the ones below the threshold)
+    if os.environ.get('MALLOC_MMAP_THRESHOLD_') != '65536' or os.environ.get('MALLOC_PERTURB_') != '255':
         os.environ['MALLOC_MMAP_THRESHOLD_'] = '65536'
+        os.environ['MALLOC_PERTURB_'] = '255'
         os.execv(sys.executable, [sys.executable] + sys.argv)
     if not os.path.exists(os.path.join(HERE, 'bunny_box_scene.npz')) or '--scene' in sys.argv:
         export_bunny_box()
