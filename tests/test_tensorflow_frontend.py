@@ -1,0 +1,239 @@
+"""The TensorFlow surface (redner_amd/render_tensorflow.py) against the PyTorch surface: the same
+scene, seed and upstream gradient through `render(seed, *serialize_scene(...))` + GradientTape and through
+`RenderFunction.apply` + backward() must give the same image and the same gradient for every differentiable tensor --
+both end in the same `redner.*` calls, so on the CPU harness the comparison is bit for bit.
+
+This image has no TensorFlow: unless a real one is importable the tests run on the torch-backed stand-in of the tf functions
+involved (tests/tf_standin: test infrastructure).  What that leaves unverified is stated in render_tensorflow.py's header."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import scenes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+try:
+    import tensorflow as tf                       # a real TensorFlow wins
+    REAL_TF = not getattr(tf, '__version__', '').endswith('standin')
+except ImportError:
+    sys.path.insert(0, os.path.join(HERE, 'tf_standin'))
+    import tensorflow as tf
+    REAL_TF = False
+
+from redner_amd.render_pytorch import RenderFunction  # noqa: E402
+
+
+def _var(t):
+    return None if t is None else tf.Variable(t.detach().cpu().numpy())
+
+
+def _int(t):
+    return None if t is None else tf.constant(t.detach().cpu().numpy().astype(np.int32))
+
+
+def tf_scene_from(sc, rt):
+    """The torch scene of tests/scenes.py rebuilt over TensorFlow tensors; -> (scene, {name: (tf variable, torch tensor)})."""
+    pairs = {}
+
+    def v(name, t):
+        if t is None:
+            return None
+        x = _var(t)
+        pairs[name] = (x, t)
+        return x
+
+    def texture(name, tex):
+        if tex is None:
+            return None
+        levels = [v('%s.level%d' % (name, k), l) for k, l in enumerate(tex.mipmap)]
+        return rt.Texture(levels[0] if tex.constant else levels, uv_scale=v(name + '.uv_scale', tex.uv_scale))
+
+    c = sc.camera
+    cam = rt.Camera(position=v('cam.position', c.position), look_at=v('cam.look_at', c.look_at), up=v('cam.up', c.up),
+                    cam_to_world=v('cam.cam_to_world', c.cam_to_world), intrinsic_mat=v('cam.intrinsic_mat', c.intrinsic_mat),
+                    clip_near=c.clip_near, resolution=c.resolution, viewport=c.viewport, camera_type=c.camera_type,
+                    distortion_params=v('cam.distortion_params', c.distortion_params))
+    shapes = [rt.Shape(v('shape%d.vertices' % i, s.vertices), _int(s.indices), s.material_id, uvs=v('shape%d.uvs' % i, s.uvs),
+                       normals=v('shape%d.normals' % i, s.normals), uv_indices=_int(s.uv_indices),
+                       normal_indices=_int(s.normal_indices), colors=v('shape%d.colors' % i, s.colors))
+              for i, s in enumerate(sc.shapes)]
+    mats = []
+    for i, m in enumerate(sc.materials):
+        mm = rt.Material(diffuse_reflectance=texture('mat%d.diffuse' % i, m.diffuse_reflectance),
+                         specular_reflectance=texture('mat%d.specular' % i, m.specular_reflectance) if m.compute_specular_lighting else None,
+                         roughness=texture('mat%d.roughness' % i, m.roughness),
+                         generic_texture=texture('mat%d.generic' % i, m.generic_texture),
+                         normal_map=texture('mat%d.normal_map' % i, m.normal_map),
+                         two_sided=m.two_sided, use_vertex_color=m.use_vertex_color)
+        mats.append(mm)
+    lights = [rt.AreaLight(l.shape_id, v('light%d.intensity' % i, l.intensity), l.two_sided, l.directly_visible)
+              for i, l in enumerate(sc.area_lights)]
+    env = None
+    if sc.envmap is not None:
+        e = sc.envmap
+        env = rt.EnvironmentMap(texture('env.values', e.values), env_to_world=v('env.env_to_world', e.env_to_world),
+                                directly_visible=e.directly_visible)
+    return rt.Scene(cam, shapes, mats, lights, env), pairs
+
+
+def _both(rd, rt, name, res, spp, bounces, dev, channels=None):
+    """-> (torch image, tf image as numpy, {tensor name: (torch grad, tf grad as numpy or None)})"""
+    sc = getattr(scenes, name)(dev, resolution=res)
+    for t in _leaves(sc):
+        t.requires_grad_(True)
+    kw = dict(sampler_type=rd.SamplerType.sobol, channels=channels)
+    args = RenderFunction.serialize_scene(sc, spp, bounces, device=dev, backend=rd, **kw)
+    img = RenderFunction.apply(7, *args)
+    gen = torch.Generator().manual_seed(3)
+    weight = torch.rand(img.shape, generator=gen).to(dev)
+    (img * weight).sum().backward()
+
+    rt.set_use_gpu(dev.type == 'cuda')
+    tsc, pairs = tf_scene_from(sc, rt)
+    targs = rt.serialize_scene(tsc, spp, bounces, backend=rd, **kw)
+    names = sorted(pairs)
+    with tf.GradientTape() as tape:
+        timg = rt.render(7, *targs)
+        loss = tf.reduce_sum(timg * tf.constant(weight.cpu().numpy()))
+    tgrads = tape.gradient(loss, [pairs[n][0] for n in names])
+    grads = {}
+    for n, g in zip(names, tgrads):
+        ref = pairs[n][1].grad
+        grads[n] = (ref, None if g is None else g.numpy())
+    return img.detach().cpu().numpy(), timg.numpy(), grads
+
+
+def _leaves(sc):
+    out = []
+    c = sc.camera
+    out += [t for t in (c.position, c.look_at, c.up) if t is not None]
+    for s in sc.shapes:
+        out += [t for t in (s.vertices, s.uvs, s.normals, s.colors) if t is not None]
+    for m in sc.materials:
+        for tex in (m.diffuse_reflectance, m.specular_reflectance, m.roughness, m.generic_texture, m.normal_map):
+            if tex is not None:
+                out += [l for l in tex.mipmap if l.is_leaf]
+    out += [l.intensity for l in sc.area_lights]
+    if sc.envmap is not None:
+        out += [l for l in sc.envmap.values.mipmap if l.is_leaf]
+    return [t for t in out if t.is_floating_point() and t.is_leaf]
+
+
+CASES = [('single_triangle', (32, 32), 2, 1, None), ('textured_sphere', (24, 24), 2, 2, 'gbuffer'),
+         ('envmap_sphere', (24, 24), 2, 2, None)]
+
+
+def _channels(rd, kind):
+    if kind == 'gbuffer':
+        return [rd.channels.radiance, rd.channels.depth, rd.channels.uv, rd.channels.generic_texture, rd.channels.shape_id]
+    return None
+
+
+def _compare(img, timg, grads, exact):
+    assert img.shape == timg.shape
+    assert np.array_equal(img, timg)            # forward renders are deterministic, on the GPU too
+    differentiable = 0
+    for n, (ref, got) in grads.items():
+        if ref is None:
+            # the PyTorch surface has no gradient for it (not a leaf that requires one) -- nothing to compare
+            continue
+        ref = ref.detach().cpu().numpy()
+        assert got is not None, n
+        assert got.shape == ref.shape, n
+        differentiable += 1
+        if exact:
+            assert np.array_equal(ref, got), n
+        else:
+            scale = np.linalg.norm(ref.astype(np.float64))
+            assert np.linalg.norm(ref.astype(np.float64) - got) <= 1e-5 * scale + 1e-12, n        # fp64 atomics: order only
+    assert differentiable >= 3
+
+
+@pytest.mark.parametrize('name,res,spp,bounces,kind', CASES)
+def test_tensorflow_surface_equals_pytorch_surface(hostsim_backend, name, res, spp, bounces, kind):
+    import redner_amd.render_tensorflow as rt
+    rd = hostsim_backend
+    img, timg, grads = _both(rd, rt, name, res, spp, bounces, torch.device('cpu'), _channels(rd, kind))
+    _compare(img, timg, grads, exact=True)
+    assert any(n.startswith('cam.') for n in grads) and any(n.endswith('.vertices') for n in grads)
+
+
+def test_screen_gradient_and_options(hostsim_backend):
+    import redner_amd.render_tensorflow as rt
+    rd = hostsim_backend
+    dev = torch.device('cpu')
+    sc = scenes.two_triangles(dev, resolution=(32, 32))
+    rt.set_use_gpu(False)
+    tsc, _pairs = tf_scene_from(sc, rt)
+    ref = RenderFunction.visualize_screen_gradient(None, 5, sc, 2, 1, sampler_type=rd.SamplerType.sobol, device=dev, backend=rd)
+    got = rt.visualize_screen_gradient(None, 5, tsc, 2, 1, sampler_type=rd.SamplerType.sobol, backend=rd)
+    assert np.array_equal(ref.numpy(), got.numpy()) and np.abs(got.numpy()).max() > 0
+    # (forward, backward) sample counts and the correlated-stream switch reach the options
+    args = rt.serialize_scene(tsc, (2, 3), 1, sampler_type=rd.SamplerType.sobol, backend=rd)
+    assert args[0]['num_samples'] == (2, 3)
+    img, ctx = rt.forward(11, *args)
+    assert ctx.seeds == (11, 11 + 1000003)
+    rt.set_use_correlated_random_number(True)
+    try:
+        assert rt.forward(11, *args)[1].seeds == (11, 11)
+    finally:
+        rt.set_use_correlated_random_number(False)
+    # a camera built from a field of view equals the PyTorch surface's
+    cam = rt.Camera(position=tf.constant([0.0, 0.0, -5.0]), look_at=tf.constant([0.0, 0.0, 0.0]), up=tf.constant([0.0, 1.0, 0.0]),
+                    fov=tf.constant([45.0]), resolution=(32, 32))
+    assert np.allclose(cam.intrinsic_mat.numpy(), sc.camera.intrinsic_mat.numpy(), rtol=1e-6)
+    # a non-finite scene tensor is refused before anything is rendered
+    tsc.shapes[0].vertices.assign(np.full((3, 3), np.nan, np.float32))
+    with pytest.raises(AssertionError):
+        rt.render(1, *rt.serialize_scene(tsc, 1, 1, backend=rd))
+
+
+@pytest.mark.skipif(REAL_TF, reason='TensorFlow is installed')
+def test_module_needs_tensorflow():
+    """Without TensorFlow the module does not import -- and nothing else of the package needs it."""
+    code = 'import redner_amd, redner_amd.render_pytorch\ntry:\n    import redner_amd.render_tensorflow\nexcept ModuleNotFoundError as e:\n    assert e.name == "tensorflow"; print("refused")\n'
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(HERE))
+    out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'refused' in out.stdout, out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,res,spp,bounces,kind', CASES)
+def test_tensorflow_surface_gpu(gpu_backend, name, res, spp, bounces, kind):
+    """The same on the MI355X: the stand-in's tensors are HIP device tensors handed over through DLPack, the render is
+    libredner_amd.so's."""
+    import redner_amd.render_tensorflow as rt
+    rd = gpu_backend
+    img, timg, grads = _both(rd, rt, name, res, spp, bounces, torch.device('cuda:0'), _channels(rd, kind))
+    _compare(img, timg, grads, exact=False)
+
+
+REF_TF = '/root/reference/pyredner_tensorflow'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_TF), reason='no reference checkout (only in the build container)')
+def test_dropin_serves_the_reference_tensorflow_package():
+    """The other way to TensorFlow: the reference's own `pyredner_tensorflow` over the drop-in `redner` module
+    (redner_amd.install()).  It cannot be imported here (no TensorFlow, and its data_ptr op is compiled against one), so
+    what is checked is the contract: every `redner.<name>` its sources use exists in the drop-in -- except the xatlas
+    UV-unwrapping classes, which are not on the path (out of scope)."""
+    import glob
+    import re
+    from redner_amd import redner
+    used = set()
+    for path in glob.glob(os.path.join(REF_TF, '*.py')):
+        used |= set(re.findall(r'(?<![A-Za-z_])redner\.([A-Za-z_]\w*(?:\.[A-Za-z_]\w*)?)', open(path).read()))
+    assert len(used) > 30
+    missing = []
+    for name in sorted(used):
+        obj = redner
+        for part in name.split('.'):
+            if not hasattr(obj, part):
+                missing.append(name)
+                break
+            obj = getattr(obj, part)
+    assert set(missing) <= {'UVTriMesh', 'TextureAtlas'}, missing
