@@ -276,6 +276,12 @@ int rdr_debug_bvh_check(const rdr_scene *scene);
  * text, for the build-order parity test against the reference (tests/test_edge_build.py). */
 int rdr_debug_dump_edges(const rdr_scene *scene, const char *path);
 
+/* Test hook: sin / cos / atan2 / atan / acos / log / pow as the kernels evaluate them (csrc/libm_exact.h: glibc 2.35's
+ * results bit for bit -- the reference's CPU path calls glibc, src/camera.h:142-191, src/material.h, src/envmap.h), one
+ * argument per lane; HOST pointers, `y` may be NULL for the one-argument functions.
+ * fn: 0 sin(x), 1 cos(x), 2 atan2(x, y), 3 atan(x), 4 acos(x), 5 log(x), 6 pow(x, y). */
+int rdr_debug_libm(int fn, const double *x, const double *y, double *out, int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,7 +130,7 @@ EXPORTS = ('rdr_scene_create', 'rdr_scene_destroy', 'rdr_scene_max_generic_textu
            'rdr_render', 'rdr_compute_num_channels', 'rdr_last_error',
            'rdr_trace_stats_enable', 'rdr_trace_stats_reset', 'rdr_trace_stats_get', 'rdr_scene_trace',
            'rdr_debug_counters_get', 'rdr_trim_cache', 'rdr_debug_dump_edges', 'rdr_debug_bvh_check',
-           'rdr_set_stream', 'rdr_set_pool_cap_mb', 'rdr_set_build_flags')
+           'rdr_set_stream', 'rdr_set_pool_cap_mb', 'rdr_set_build_flags', 'rdr_debug_libm')
 
 _lib = None
 _lib_path = None
@@ -184,6 +184,8 @@ def load(path=None):
     lib.rdr_trace_stats_get.argtypes = [C.POINTER(TraceStats)]
     lib.rdr_scene_trace.restype = C.c_int
     lib.rdr_scene_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.rdr_debug_libm.restype = C.c_int
+    lib.rdr_debug_libm.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _lib, _lib_path = lib, path
     return lib
 

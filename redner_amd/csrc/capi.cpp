@@ -24,6 +24,25 @@ thread_local void *g_user_stream = nullptr;
 void use_caller_stream() { exec::ctx().stream = (hipStream_t)g_user_stream; }
 }
 
+// rdr_debug_libm: one argument per lane through the routines every stage calls
+struct LibmProbe {
+    int fn; const double *x, *y; double *out;
+    RDR_FN void operator()(int i) const {
+        const double a = x[i], b = y[i];
+        double r;
+        switch (fn) {
+            case 0: r = gm::sin(a); break;
+            case 1: r = gm::cos(a); break;
+            case 2: r = gm::atan2(a, b); break;
+            case 3: r = gm::atan(a); break;
+            case 4: r = gm::acos(a); break;
+            case 5: r = gm::log(a); break;
+            default: r = gm::pow(a, b); break;
+        }
+        out[i] = r;
+    }
+};
+
 extern "C" {
 
 const char *rdr_last_error(void) { return g_last_error.c_str(); }
@@ -208,6 +227,30 @@ int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, in
         use_caller_stream();
         exec::trace(s.bvh, reinterpret_cast<const rt::RayRec *>(rays), reinterpret_cast<rt::HitRec *>(hits), num_rays, any_hit != 0);
         exec::sync();
+        return 0;
+    } catch (const std::exception &e) {
+        set_error(e.what());
+        return 1;
+    }
+}
+
+/* Test hook: the library's transcendental routines (libm_exact.h) evaluated by a kernel on `n` arguments (HOST pointers;
+ * `y` only for the two-argument functions).  fn: 0 sin, 1 cos, 2 atan2(x, y), 3 atan, 4 acos, 5 log, 6 pow(x, y). */
+int rdr_debug_libm(int fn, const double *x, const double *y, double *out, int n) {
+    try {
+        g_last_error.clear();
+        if (fn < 0 || fn > 6 || n < 0) throw std::runtime_error("rdr_debug_libm: bad arguments");
+        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+        exec::select_device(1, -1);
+        use_caller_stream();
+        const size_t bytes = sizeof(double) * (size_t)n;
+        double *dx = (double *)exec::dmalloc(bytes), *dy = (double *)exec::dmalloc(bytes), *dout = (double *)exec::dmalloc(bytes);
+        exec::upload(dx, x, bytes);
+        if (y) exec::upload(dy, y, bytes); else exec::zero(dy, bytes);
+        exec::launch(exec::Count(n), LibmProbe{fn, dx, dy, dout});
+        exec::download(out, dout, bytes);
+        exec::sync();
+        exec::dfree(dx); exec::dfree(dy); exec::dfree(dout);
         return 0;
     } catch (const std::exception &e) {
         set_error(e.what());

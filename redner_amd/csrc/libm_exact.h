@@ -1513,4 +1513,8 @@ RDR_FN double pow(double x, double y) {
     return pow_exp(ehi, elo, sign_bias);
 }
 
+// a float (or integer) argument means another glibc routine in the reference: refuse it
+double sin(float) = delete; double cos(float) = delete; double atan(float) = delete; double acos(float) = delete; double log(float) = delete;
+double atan2(float, float) = delete; double pow(float, float) = delete; double pow(double, int) = delete; double pow(float, int) = delete;
+
 } // namespace gm

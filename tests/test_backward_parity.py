@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden.make_golden import CASES, SAMPLE_EXACT_ON_CPU_ONLY, render_case
+from golden.make_golden import CASES, render_case
 from parity_util import GOLD, assert_parity, compare, record
 
 
@@ -27,10 +27,11 @@ def test_backward_hostsim(hostsim_backend, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', [c for c in CASES if c not in SAMPLE_EXACT_ON_CPU_ONLY])
+@pytest.mark.parametrize('name', list(CASES))
 def test_backward_gpu(gpu_backend, name):
     """Includes bunny_box_96x96x8: big enough that side streams, the second sample worker and the wave-summed
-    gradient scatters are all active, compared with the oracle's fixture."""
+    gradient scatters are all active, compared with the oracle's fixture -- and the fisheye / panorama cameras WITH secondary
+    edge sampling (make_golden.CHAOTIC_PICK_CASES): sample-exact on the GPU since its sin / cos / atan2 are glibc's."""
     _check(gpu_backend, torch.device('cuda:0'), name, 'gpu')
 
 

@@ -245,10 +245,10 @@ def _render_rich(backend, seed, spp, mb, pixel_center, stripe=None):
     dev = torch.device('cpu')
     sc = _scene_rich(seed, dev)
     sampler = backend.SamplerType.independent if seed % 4 == 3 else backend.SamplerType.sobol      # PCG32 every fourth scene
-    # Fisheye / panorama primary rays go through sin / cos, whose last bit differs between the device's libm and glibc, and the
-    # hierarchical edge pick is chaotic in the shading position: on the GPU those cameras are compared
-    # without the secondary-edge estimator (both backends), like the *_nosec fixtures.
-    sec = not (ON_GPU and sc.camera.camera_type in (2, 3))
+    # Fisheye / panorama primary rays go through sin / cos / atan2 and the hierarchical edge pick is chaotic in the shading
+    # position.  Rounds 1-3 compared those cameras on the GPU without the secondary-edge estimator; the
+    # kernels' transcendental functions are glibc's now (csrc/libm_exact.h), so every camera runs with it.
+    sec = True
     args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=sampler, device=_sdev(backend), backend=backend,
                                           sample_pixel_center=pixel_center, use_secondary_edge_sampling=sec)
     img = RenderFunction.apply(seed, *args)
