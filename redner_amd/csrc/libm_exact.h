@@ -12,8 +12,8 @@
 // tests/test_libm_exact.py holds them to glibc bit for bit on 10^7 ... 10^8 arguments per function on the CPU and runs the same
 // arguments through a kernel on the GPU.
 //
-// Range: |x| < 105414350 for sin / cos (beyond that glibc reduces with a 1200-bit 2/pi table; a renderer's angles never
-// get there: those arguments go to the platform's own routine).
+// Range: every double (sin / cos of |x| >= 105414350 go through branred.c's reduction with 1800 bits of 2 / pi, which
+// glibc builds without FMA: restated without).
 #pragma once
 #include <cmath>
 #include <cstdint>
@@ -143,6 +143,21 @@ RDR_FN const double *sincos_table() {
     return tab;
 }
 
+// 2 / pi in 75 digits of 24 bits -- branred.h: toverp
+RDR_FN const double *two_over_pi_table() {
+    static const double tab[75] = {
+        10680707.0, 7228996.0, 1387004.0, 2578385.0, 16069853.0, 12639074.0, 9804092.0, 4427841.0, 16666979.0, 11263675.0,
+        12935607.0, 2387514.0, 4345298.0, 14681673.0, 3074569.0, 13734428.0, 16653803.0, 1880361.0, 10960616.0, 8533493.0,
+        3062596.0, 8710556.0, 7349940.0, 6258241.0, 3772886.0, 3769171.0, 3798172.0, 8675211.0, 12450088.0, 3874808.0,
+        9961438.0, 366607.0, 15675153.0, 9132554.0, 7151469.0, 3571407.0, 2607881.0, 12013382.0, 4155038.0, 6285869.0,
+        7677882.0, 13102053.0, 15825725.0, 473591.0, 9065106.0, 15363067.0, 6271263.0, 9264392.0, 5636912.0, 4652155.0,
+        7056368.0, 13614112.0, 10155062.0, 1944035.0, 9527646.0, 15080200.0, 6658437.0, 6231200.0, 6832269.0, 16767104.0,
+        5075751.0, 3212806.0, 1398474.0, 7579849.0, 6349435.0, 12618859.0, 4703257.0, 12806093.0, 14477321.0, 2786137.0,
+        12875403.0, 9837734.0, 14528324.0, 13719321.0, 343717.0,
+    };
+    return tab;
+}
+
 namespace detail {
 // s_sin.c: TAYLOR_SIN -- |x| < 0.126
 RDR_FN double taylor_sin(double xx, double x, double dx) {
@@ -206,6 +221,57 @@ RDR_FN double do_sincos(double a, double da, int n) {
     return (n & 2) ? -r : r;
 }
 constexpr double kHp0 = 0x1.921fb54442d18p+0, kHp1 = 0x1.1a62633145c07p-54;
+// branred.c: one half of the argument times 2 / pi -- six 24-bit digits of 2 / pi from the position the half's exponent
+// selects; integer parts beyond two bits dropped digit by digit.  -> fraction (b, bb) of a quarter turn, quarter count in sum
+RDR_FN void branred_half(double xh, double &b, double &bb, double &sum) {
+    const double tm24 = 0x1p-24, big = 0x1.8p+52, big1 = 0x1.8p+54;
+    int k = (int)((hi_word(xh) >> 20) & 2047);
+    k = (k - 450) / 24;
+    if (k < 0) k = 0;
+    double gor = bits2d((uint64_t)(0x63f00000u - (uint32_t)((k * 24) << 20)) << 32);       // 2^(576 - 24 k)
+    const double *tv = two_over_pi_table() + k;
+    double r[6];
+    for (int i = 0; i < 6; ++i) { r[i] = xh * tv[i] * gor; gor *= tm24; }
+    sum = 0;
+    for (int i = 0; i < 3; ++i) { const double s = (r[i] + big) - big; sum += s; r[i] -= s; }
+    double t = 0;
+    for (int i = 0; i < 6; ++i) t += r[5 - i];
+    bb = (((((r[0] - t) + r[1]) + r[2]) + r[3]) + r[4]) + r[5];
+    double s = (t + big) - big;
+    sum += s;
+    t -= s;
+    b = t + bb;
+    bb = (t - b) + bb;
+    s = (sum + big1) - big1;
+    sum -= s;
+}
+// branred.c: __branred -- x = n pi/2 + (a + da) for 105414350 <= |x| < 2^1024
+RDR_FN int branred(double x, double &a, double &da) {
+    const double tm600 = 0x1p-600, split = 134217729.0, mp1 = 0x1.921fb58000000p+0, mp2 = -0x1.dde9740000000p-27;
+    x *= tm600;
+    double t = x * split;
+    const double x1 = t - (t - x);
+    const double x2 = x - x1;
+    double b1, bb1, sum1, b2, bb2, sum2;
+    branred_half(x1, b1, bb1, sum1);
+    branred_half(x2, b2, bb2, sum2);
+    double sum = sum1 + sum2;
+    double b = b1 + b2;
+    double bb = (fabs(b1) > fabs(b2)) ? (b1 - b) + b2 : (b2 - b) + b1;
+    if (b > 0.5) { b -= 1.0; sum += 1.0; }
+    else if (b < -0.5) { b += 1.0; sum -= 1.0; }
+    double s = b + (bb + bb1 + bb2);
+    t = ((b - s) + bb) + (bb1 + bb2);
+    b = s * split;
+    const double t1 = b - (b - s);
+    const double t2 = s - t1;
+    b = s * kHp0;
+    bb = (((t1 * mp1 - b) + t1 * mp2) + t2 * mp1) + (t2 * mp2 + s * kHp1 + t * kHp0);
+    s = b + bb;
+    t = (b - s) + bb;
+    a = s; da = t;
+    return ((int)sum) & 3;
+}
 } // namespace detail
 
 // s_sin.c: __sin
@@ -216,7 +282,8 @@ RDR_FN double sin(double x) {
     if (k < 0x3feb6000u) return do_sin(x, 0.0);               // |x| < 0.855469
     if (k < 0x400368fdu) return copysign(do_cos(kHp0 - fabs(x), kHp1), x);   // |x| < 2.426265
     if (k < 0x419921fbu) { double a, da; int n = reduce_sincos(x, a, da); return do_sincos(a, da, n); }
-    return ::sin(x);
+    if (k < 0x7ff00000u) { double a, da; int n = branred(x, a, da); return do_sincos(a, da, n); }
+    return x / x;                                             // inf, nan
 }
 // s_sin.c: __cos
 RDR_FN double cos(double x) {
@@ -231,7 +298,8 @@ RDR_FN double cos(double x) {
         return do_sin(a, da);
     }
     if (k < 0x419921fbu) { double a, da; int n = reduce_sincos(x, a, da); return do_sincos(a, da, n + 1); }
-    return ::cos(x);
+    if (k < 0x7ff00000u) { double a, da; int n = branred(x, a, da); return do_sincos(a, da, n + 1); }
+    return x / x;
 }
 
 // atan(c) around the 241 points c = u_i ~ (16.25 + i) / 256: {c, atan(c), and the coefficients of the series of atan around c}

@@ -57,6 +57,7 @@ def arguments(name, n, seed=20240925):
     if name in ('sin', 'cos'):
         parts = [(rng.random(n) * 2 - 1) * 7.0, rng.random(n) * 2 - 1, (rng.random(n) * 2 - 1) * 1000.0,
                  (rng.random(n) * 2 - 1) * 1.05e8, _log_uniform(rng, n, -40, 20),
+                 _log_uniform(rng, n // 2, 26, 1024), (rng.random(n // 2) * 2 - 1) * 1e9,     # branred.c: |x| >= 105414350
                  np.arange(0, 110 * 64) / (128.0 * 64),                   # every table interval of do_sin / do_cos
                  (rng.integers(-200, 200, n) + (rng.random(n) - 0.5) * 1e-9) * (np.pi / 2), sp]
         return np.concatenate(parts), None
@@ -137,3 +138,10 @@ def test_libm_exact_gpu(name, gpu_backend):
     of the box's host -- the library the oracle calls there."""
     x, y = arguments(name, 1500000)
     assert_bit_equal(name, x, y, glibc_values(name, x, y), library_values(name, x, y))
+
+
+def test_tables_are_the_c_librarys():
+    """Every coefficient table of the header, entry by entry, inside this machine's libm.so.6; 2 / pi recomputed from scratch."""
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'extract_libm_tables.py')], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -135,7 +135,15 @@ def _channels(rd, kind):
 
 def _compare(img, timg, grads, exact):
     assert img.shape == timg.shape
-    assert np.array_equal(img, timg)            # forward renders are deterministic, on the GPU too
+    if exact:
+        assert np.array_equal(img, timg)        # same inputs, same bits (the sequential harness)
+    else:
+        # On the GPU a render of identical inputs is bit-identical too (tests/test_properties.py), but the two surfaces MAKE
+        # some of their inputs with framework operators -- the environment map's sampling tables are float32 sines and
+        # cumulative sums (render_pytorch.py:113-121, render_tensorflow.py:183-188) -- and where those run and how they
+        # round is the framework's business (the stand-in's tf.range lives on the host, torch.arange on the device: the two
+        # float sines differ in the last bit).  Observed: 2e-7 of a pixel on the environment-lit case, 0 on the other two.
+        assert np.allclose(img, timg, rtol=2e-6, atol=1e-7)
     differentiable = 0
     for n, (ref, got) in grads.items():
         if ref is None:
