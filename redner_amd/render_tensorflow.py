@@ -179,13 +179,16 @@ class EnvironmentMap:
         self.directly_visible = directly_visible
         t = self.values.mipmap[0]
         h, w = int(t.shape[0]), int(t.shape[1])
-        lum = 0.212671 * t[:, :, 0] + 0.715160 * t[:, :, 1] + 0.072169 * t[:, :, 2]
-        cdf_xs_ = tf.cumsum(lum, axis=1)
-        y_weight = tf.sin(math.pi * (tf.cast(tf.range(h), tf.float32) + 0.5) / float(h))
-        cdf_ys_ = tf.cumsum(cdf_xs_[:, -1] * y_weight, axis=0)
-        self.pdf_norm = (h * w) / (float(cdf_ys_[-1]) * (2 * math.pi * math.pi))
-        self.sample_cdf_xs = (cdf_xs_ - cdf_xs_[:, 0:1]) / tf.maximum(cdf_xs_[:, (w - 1):w], 1e-8 * tf.ones([h, 1], dtype=tf.float32))
-        self.sample_cdf_ys = (cdf_ys_ - cdf_ys_[0]) / tf.maximum(cdf_ys_[-1], tf.constant([1e-8]))
+        # on the render device, like the reference (pyredner_tensorflow/envmap.py:37): a float32 sine made on the host differs
+        # from the device's in the last bit, and with it the tables
+        with tf.device(get_device_name()):
+            lum = 0.212671 * t[:, :, 0] + 0.715160 * t[:, :, 1] + 0.072169 * t[:, :, 2]
+            cdf_xs_ = tf.cumsum(lum, axis=1)
+            y_weight = tf.sin(math.pi * (tf.cast(tf.range(h), tf.float32) + 0.5) / float(h))
+            cdf_ys_ = tf.cumsum(cdf_xs_[:, -1] * y_weight, axis=0)
+            self.pdf_norm = (h * w) / (float(cdf_ys_[-1]) * (2 * math.pi * math.pi))
+            self.sample_cdf_xs = (cdf_xs_ - cdf_xs_[:, 0:1]) / tf.maximum(cdf_xs_[:, (w - 1):w], 1e-8 * tf.ones([h, 1], dtype=tf.float32))
+            self.sample_cdf_ys = (cdf_ys_ - cdf_ys_[0]) / tf.maximum(cdf_ys_[-1], tf.constant([1e-8]))
 
 
 class Scene:

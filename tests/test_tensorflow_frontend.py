@@ -138,11 +138,11 @@ def _compare(img, timg, grads, exact):
     if exact:
         assert np.array_equal(img, timg)        # same inputs, same bits (the sequential harness)
     else:
-        # On the GPU a render of identical inputs is bit-identical too (tests/test_properties.py), but the two surfaces MAKE
-        # some of their inputs with framework operators -- the environment map's sampling tables are float32 sines and
-        # cumulative sums (render_pytorch.py:113-121, render_tensorflow.py:183-188) -- and where those run and how they
-        # round is the framework's business (the stand-in's tf.range lives on the host, torch.arange on the device: the two
-        # float sines differ in the last bit).  Observed: 2e-7 of a pixel on the environment-lit case, 0 on the other two.
+        # On the GPU a render of identical inputs is bit-identical too (tests/test_properties.py); the two surfaces MAKE some
+        # of their inputs with framework operators -- the environment map's sampling tables are float32 sines and cumulative
+        # sums (render_pytorch.py:113-121, render_tensorflow.py:183-192), both on the render device like the reference's
+        # (pyredner_tensorflow/envmap.py:37).  [Round 4: the TensorFlow surface made the sine on the host; its last bit, the
+        # tables and a few pixels differed -- found by this test on the GPU.]  A last-bit allowance stays for the operators.
         assert np.allclose(img, timg, rtol=2e-6, atol=1e-7)
     differentiable = 0
     for n, (ref, got) in grads.items():
