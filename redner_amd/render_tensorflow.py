@@ -182,6 +182,7 @@ class EnvironmentMap:
         # on the render device, like the reference (pyredner_tensorflow/envmap.py:37): a float32 sine made on the host differs
         # from the device's in the last bit, and with it the tables
         with tf.device(get_device_name()):
+            t = tf.identity(t)                 # the copy on the render device (a texture handed over as a host tensor stays a host tensor)
             lum = 0.212671 * t[:, :, 0] + 0.715160 * t[:, :, 1] + 0.072169 * t[:, :, 2]
             cdf_xs_ = tf.cumsum(lum, axis=1)
             y_weight = tf.sin(math.pi * (tf.cast(tf.range(h), tf.float32) + 0.5) / float(h))
