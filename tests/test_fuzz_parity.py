@@ -748,7 +748,7 @@ def test_random_scenes_gpu_vs_oracle(gpu_backend, variant):
     assert scenes >= 60
     # Rounds 1-3 allowed two scenes per leg in which a single edge sample landed on another edge (_edge_flip: the device's
     # sin / cos / pow were not glibc's).  They are now (csrc/libm_exact.h): the three legs of the first run with them had none
-    # (profiles/r4_libm_parity_report.jsonl), and none is allowed -- the classifier stays, to say WHAT a failure looks like.
+    # (profiles/r4_parity_report_final.jsonl), and none is allowed -- the classifier stays, to say WHAT a failure looks like.
     assert flips == {}, flips
 
 
