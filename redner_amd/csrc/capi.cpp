@@ -241,7 +241,7 @@ int rdr_debug_libm(int fn, const double *x, const double *y, double *out, int n)
         g_last_error.clear();
         if (fn < 0 || fn > 6 || n < 0) throw std::runtime_error("rdr_debug_libm: bad arguments");
         std::lock_guard<std::recursive_mutex> lk(g_api_lock);
-        exec::select_device(1, -1);
+        exec::select_device(1, exec::current_device());        // the calling thread's device: checked, not changed
         use_caller_stream();
         const size_t bytes = sizeof(double) * (size_t)n;
         double *dx = (double *)exec::dmalloc(bytes), *dy = (double *)exec::dmalloc(bytes), *dout = (double *)exec::dmalloc(bytes);
