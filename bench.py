@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- forward+backward throughput of the differentiable path tracer on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
-torch.distributed.run, one rank per GPU (backend nccl = RCCL).  Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it runs one rank per GPU (backend nccl =
+RCCL) -- launched under torch.distributed.run, or, when started plainly (`python bench.py --gpus 8`), it starts its own
+ranks through torch.distributed.run (self_launch).  Rank 0 prints ONE JSON line.
 
 Workload (BASELINE.json metric "Msamples/s fwd+bwd (1024^2 x spp)", config 4): the bunny_box scene
 (tests/scenes.py, arrays exported from the reference's tests/scenes/bunny_box.xml), 1024 x 1024,
@@ -348,6 +349,22 @@ def inner_run(a):
     torch.cuda.synchronize(dev)
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: become the launcher -- one rank per GPU on
+    this node, rendezvous on 127.0.0.1 at a free port -- with the same arguments.  Rank 0 of the children prints the JSON line."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '1')
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -368,6 +385,8 @@ def main():
     if a.inner:
         return inner_run(a)
 
+    if a.gpus > 1 and 'RANK' not in os.environ:
+        return self_launch(a)          # `python bench.py --gpus N` without a launcher: start the N ranks ourselves
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -375,6 +394,9 @@ def main():
     # RDR_BENCH_SHARE_GPU=1 (rehearsal of the multi-rank path on a box with fewer GPUs than ranks: gloo, ranks share devices;
     # the number it prints is not a measurement)
     share = os.environ.get('RDR_BENCH_SHARE_GPU') == '1'
+    if not share and local_rank >= torch.cuda.device_count():
+        raise SystemExit('bench.py: local rank %d but %d GPU(s) visible (RDR_BENCH_SHARE_GPU=1 rehearses the multi-rank path '
+                         'on fewer GPUs)' % (local_rank, torch.cuda.device_count()))
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda:%d' % dev_index)
@@ -386,7 +408,11 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)
         assert dist.get_world_size() == world
-    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE is %d)' % (a.gpus, world)
+    if world != a.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE is %d: launch `python bench.py --gpus N` (it starts its own ranks) '
+                         'or torch.distributed.run --nproc-per-node N bench.py --gpus N' % (a.gpus, world))
+    if not share and world > torch.cuda.device_count():
+        raise SystemExit('bench.py: %d ranks but %d GPU(s) visible' % (world, torch.cuda.device_count()))
     assert a.spp % world == 0, '--spp must be divisible by the number of GPUs'
     spp_rank = a.spp // world
 

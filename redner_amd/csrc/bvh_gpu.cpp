@@ -494,13 +494,14 @@ void refit_tri_bvh_device(const BvhDev &src, const void *d_shapes, BvhDev &d) { 
     d.area = take<double>(d, 1);
     exec::copy_dev(d.nodes, src.nodes, sizeof(Node) * src.num_nodes);          // links + leaf ranges (the boxes are overwritten)
     exec::copy_dev(d.wide, src.wide, sizeof(Node4) * src.num_wide);
-    hipLaunchKernelGGL(tri_gather_kernel, grid_of(d.num_slots), dim3(256), 0, st, (const ShapeRef *)d_shapes, (const int *)nullptr, (const int *)nullptr,
-                       d.num_slots, d.tris, d.ids);
+    if (d.num_slots > 0)             // (a zero-size grid is a launch error)
+        hipLaunchKernelGGL(tri_gather_kernel, grid_of(d.num_slots), dim3(256), 0, st, (const ShapeRef *)d_shapes, (const int *)nullptr, (const int *)nullptr,
+                           d.num_slots, d.tris, d.ids);
     for (int l = (int)d.level_first.size() - 2; l >= 0; --l) {
         const int first = d.level_first[l], end = d.level_first[l + 1];
         if (end > first) hipLaunchKernelGGL(refit_level_kernel, grid_of(end - first), dim3(256), 0, st, d.nodes, first, end, d.tris, (const float *)nullptr, (const int *)nullptr);
     }
-    hipLaunchKernelGGL(wide_refit_kernel, grid_of(d.num_wide), dim3(256), 0, st, d.nodes, d.wide_src, d.num_wide, d.wide);
+    if (d.num_wide > 0) hipLaunchKernelGGL(wide_refit_kernel, grid_of(d.num_wide), dim3(256), 0, st, d.nodes, d.wide_src, d.num_wide, d.wide);
     hipLaunchKernelGGL(inner_area_kernel, dim3(1), dim3(256), 0, st, d.nodes, d.num_nodes, d.area);
     exec::check(hipGetLastError(), "bvh refit launch");
 }

@@ -244,13 +244,17 @@ int rdr_debug_libm(int fn, const double *x, const double *y, double *out, int n)
         exec::select_device(1, exec::current_device());        // the calling thread's device: checked, not changed
         use_caller_stream();
         const size_t bytes = sizeof(double) * (size_t)n;
-        double *dx = (double *)exec::dmalloc(bytes), *dy = (double *)exec::dmalloc(bytes), *dout = (double *)exec::dmalloc(bytes);
+        struct Held {                      // released on every path out, also when the launch or a copy throws
+            double *p[3] = {nullptr, nullptr, nullptr};
+            ~Held() { exec::device_sync(); for (double *q : p) exec::dfree(q); }
+        } held;
+        for (double *&q : held.p) q = (double *)exec::dmalloc(bytes);
+        double *dx = held.p[0], *dy = held.p[1], *dout = held.p[2];
         exec::upload(dx, x, bytes);
         if (y) exec::upload(dy, y, bytes); else exec::zero(dy, bytes);
         exec::launch(exec::Count(n), LibmProbe{fn, dx, dy, dout});
         exec::download(out, dout, bytes);
         exec::sync();
-        exec::dfree(dx); exec::dfree(dy); exec::dfree(dout);
         return 0;
     } catch (const std::exception &e) {
         set_error(e.what());

@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(256) compact_scatter(const int *in, int n, con
                                                         const int *out_base, int *pos_out) {
     __shared__ int wave_tot[kCompactItems][4];
     if (count) { const int c = *count; n = c < n ? c : n; }
-    if (out_base) out += *out_base;
+    if (out_base) { out += *out_base; if (pos_out) pos_out += *out_base; }      // appended lists: positions line up with the items
     int base = blockIdx.x * kCompactTile;
     int wave = threadIdx.x >> 6;
     int val[kCompactItems]; bool keep[kCompactItems]; int rank[kCompactItems];

@@ -65,8 +65,13 @@ public:
 private:
     Pool() {
         unsigned hw = std::thread::hardware_concurrency();
-        int n = (int)(hw ? hw : 8) - 1;
-        n = n < 1 ? 1 : (n > 31 ? 31 : n);
+        int cores = (int)(hw ? hw : 8);
+        // one process per GPU: the ranks of a node share its cores (torch.distributed.run exports LOCAL_WORLD_SIZE), so a
+        // rank's polling workers take their share of them, at most 15 -- 8 ranks x 31 pollers would occupy a 256-thread host
+        int ranks = 1;
+        if (const char *e = std::getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, std::atoi(e));
+        int n = std::max(2, cores / ranks) - 1;
+        n = std::max(1, std::min(ranks > 1 ? 15 : 31, n));
         if (const char *e = std::getenv("RDR_POOL_THREADS")) n = std::max(1, std::min(63, std::atoi(e)));
         // RDR_POOL_PIN=k: workers restricted to the k-aligned block of k CPUs the creating thread runs on (phases hand their
         // data from thread to thread: cores that share a last-level cache pass it on without leaving the cache)

@@ -502,7 +502,10 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         size_t total = 0;
         for (int i = 0; i < num_shapes; ++i) { refs[2 * i] = s.shapes[i].vertices; refs[2 * i + 1] = s.shapes[i].indices; total += (size_t)s.shapes[i].num_triangles; }
         const void *d_refs = to_device(s, refs.data(), refs.size());
-        bool same = refit_allowed && topo_cache->dev && topo_cache->gpu_index == s.gpu_index && topo_cache->indices.size() == s.h_indices.size();
+        // (a cached EMPTY hierarchy -- no shapes / no triangles -- is never refitted: there is nothing to gather and a zero-size
+        //  launch is an error; the build below returns at once for it)
+        bool same = refit_allowed && total > 0 && topo_cache->dev && topo_cache->dev->num_slots > 0 && topo_cache->gpu_index == s.gpu_index &&
+                    topo_cache->indices.size() == s.h_indices.size();
         for (size_t i = 0; same && i < s.h_indices.size(); ++i) same = topo_cache->indices[i] == s.h_indices[i];
         auto dev = std::make_shared<rt::BvhDev>();
         bool built = false;

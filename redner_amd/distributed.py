@@ -32,18 +32,21 @@ def _ordered_sum(parts):
 
 
 def _all_gather_sum(t, group):
+    """Partial results of all ranks summed in FIXED rank order (bit-identical on every rank and from run to run).  One
+    collective into one flat [world, n] buffer (all_gather_into_tensor: no list of per-rank tensors, no extra copies)."""
     world = dist.get_world_size(group)
     if world == 1:
         return t
-    if t.is_cuda and dist.get_backend(group) == 'gloo':
-        # rehearsals of the multi-rank path on fewer GPUs than ranks (tests, RDR_BENCH_SHARE_GPU): gloo gathers host tensors
-        host = t.detach().cpu().contiguous()
-        parts = [torch.empty_like(host) for _ in range(world)]
-        dist.all_gather(parts, host, group=group)
-        return _ordered_sum([p.to(t.device) for p in parts])
-    parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t.contiguous(), group=group)
-    return _ordered_sum(parts)
+    flat = t.detach().contiguous().reshape(-1)
+    # gloo (CPU tests, rehearsals of the multi-rank path on fewer GPUs than ranks: RDR_BENCH_SHARE_GPU) gathers host tensors
+    src = flat.cpu() if flat.is_cuda and dist.get_backend(group) == 'gloo' else flat
+    every = torch.empty(world * src.numel(), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(every, src, group=group)
+    every = every.view(world, src.numel()).to(t.device)
+    acc = every[0].clone()
+    for r in range(1, world):
+        acc += every[r]
+    return acc.reshape(t.shape)
 
 
 def _all_gather_sum_many(tensors, group):

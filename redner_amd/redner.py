@@ -329,7 +329,7 @@ class Scene:                           # src/redner.cpp:62-73
                  use_primary_edge_sampling, use_secondary_edge_sampling):
         lib = _capi.lib()
         self._lib = lib
-        _use_torch_stream(lib, use_gpu)
+        _use_torch_stream(lib, use_gpu, gpu_index)
         self.camera = camera
         sh = (_capi.ShapeDesc * max(len(shapes), 1))(*[s._desc for s in shapes])
         mt = (_capi.MaterialDesc * max(len(materials), 1))(*[m._to_desc() for m in materials])
@@ -402,7 +402,7 @@ def render(scene, options, rendered_image, d_rendered_image, d_scene, screen_gra
     """redner.render(...)  src/redner.cpp:257 -- forward iff rendered_image != 0, backward iff
     d_rendered_image != 0."""
     od = options._to_desc()
-    _use_torch_stream(scene._lib, scene.use_gpu)
+    _use_torch_stream(scene._lib, scene.use_gpu, scene.gpu_index)
     ds = C.byref(d_scene._desc) if d_scene is not None else None
     rc = scene._lib.rdr_render(scene._handle, C.byref(od), _addr(rendered_image), _addr(d_rendered_image), ds,
                                _addr(screen_gradient_image), _addr(debug_image))
@@ -410,16 +410,18 @@ def render(scene, options, rendered_image, d_rendered_image, d_scene, screen_gra
         raise RuntimeError('redner.render: ' + _capi.last_error())
 
 
-def _use_torch_stream(lib, use_gpu):
-    """The library orders its launches on the calling thread's CURRENT torch stream (rdr_set_stream): tensors produced
-    under `with torch.cuda.stream(s):` are read after their producers without a device-wide synchronisation.  (The
-    reference's kernels run on the null stream, which torch's default stream is.)"""
+def _use_torch_stream(lib, use_gpu, gpu_index=None):
+    """The library orders its launches on the calling thread's CURRENT torch stream OF THE SCENE'S DEVICE (rdr_set_stream):
+    tensors produced under `with torch.cuda.stream(s):` are read after their producers without a device-wide
+    synchronisation.  (The reference's kernels run on the null stream, which torch's default stream is.)"""
     if not use_gpu:
         return
     torch = sys.modules.get('torch')
     stream = 0
     if torch is not None and torch.cuda.is_available():
-        stream = int(torch.cuda.current_stream().cuda_stream)
+        # a Scene may live on another device than torch's current one (pyredner.set_device without torch.cuda.set_device):
+        # a stream handle is only valid on the device it was created on
+        stream = int(torch.cuda.current_stream(gpu_index).cuda_stream)
     lib.rdr_set_stream(stream or None)
 
 

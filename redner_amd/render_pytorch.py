@@ -338,8 +338,12 @@ class RenderFunction(torch.autograd.Function):
                            meta['use_primary_edge_sampling'], meta['use_secondary_edge_sampling'])
         u.options = rd.RenderOptions(seed[0], meta['num_samples'][0], meta['max_bounces'], meta['channels'],
                                      meta['sampler_type'], meta['sample_pixel_center'])
-        for k, v in meta.get('tuning', {}).items():      # rdr_tuning (redner_amd extension; the reference's options have none)
-            if hasattr(u.options, 'tuning'):
+        if meta.get('tuning') and hasattr(u.options, 'tuning'):      # rdr_tuning (redner_amd extension; the reference's options have none)
+            known = {f[0] for f in type(u.options.tuning)._fields_}
+            unknown = sorted(set(meta['tuning']) - known)
+            if unknown:                        # a ctypes.Structure takes any attribute name: a typo would silently render with defaults
+                raise ValueError('unknown rdr_tuning field(s) %s; known: %s' % (unknown, sorted(known)))
+            for k, v in meta['tuning'].items():
                 setattr(u.options.tuning, k, v)
         if 'sample_offset' in meta:             # multi-GPU sample sharding (redner_amd extension)
             u.options.sample_offset = meta['sample_offset'][0]

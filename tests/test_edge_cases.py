@@ -88,6 +88,19 @@ def test_empty_scene_hostsim(hostsim_backend):
 
 
 @pytest.mark.gpu
+def test_empty_scene_twice_gpu(gpu_backend):
+    """Two empty Scenes in a row on the GPU (the second one found the first one's cached, empty hierarchy and
+    tried to refit it with zero-size launches), then a normal Scene, then an empty one again."""
+    dev = torch.device('cuda:0')
+    sc = scenes.two_triangles(dev, resolution=(16, 16))
+    for k in range(4):
+        scene = sc if k == 2 else Scene(sc.camera, [], [], [])
+        args = RenderFunction.serialize_scene(scene, 1, 1, sampler_type=gpu_backend.SamplerType.sobol, device=dev, backend=gpu_backend)
+        img = RenderFunction.apply(1, *args)
+        assert img.shape == (16, 16, 3) and bool(img.cpu().numpy().any()) == (k == 2)
+
+
+@pytest.mark.gpu
 def test_steady_state_render_allocates_nothing_and_reads_no_counts(gpu_backend):
     """After a first forward+backward call has sized the caching allocator, further calls on the same shapes make no
     hipMalloc (the reference allocates its PathBuffer per call, src/pathtracer.cpp:36-152) and the host reads no live-lane

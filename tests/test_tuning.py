@@ -104,3 +104,15 @@ def test_caller_stream_gpu(gpu_backend):
     side.synchronize()
     assert np.array_equal(img.detach().cpu().numpy(), gold['image'])
     assert float(total) == float(torch.from_numpy(gold['image']).to(dev).sum())
+
+
+def test_unknown_tuning_field_is_an_error(hostsim_backend):
+    """A misspelt rdr_tuning field must not silently render with the defaults: ctypes.Structure accepts any name."""
+    import scenes
+    from redner_amd.render_pytorch import RenderFunction
+    dev = torch.device('cpu')
+    sc = scenes.single_triangle(dev, resolution=(8, 8))
+    args = RenderFunction.serialize_scene(sc, 1, 1, sampler_type=hostsim_backend.SamplerType.sobol, device=dev,
+                                          backend=hostsim_backend, tuning={'batch_sample': 1})
+    with pytest.raises(ValueError, match='batch_sample'):
+        RenderFunction.apply(1, *args)
