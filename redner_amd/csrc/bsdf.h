@@ -136,11 +136,11 @@ RDR_FN void adj_tex_fetch(const TexD &tex, V2 uv_, V2 du_, V2 dv_, const double 
 // sp.plain (lean stages): the texture is known to be a constant, so the lookup machinery -- and the registers it
 // would pin -- is compiled out; the values are what tex_fetch's own constant branch returns.
 RDR_FN V3 tex3(const TexD &tex, const Surf &sp) {
-    if (sp.plain) return V3{(double)tex.texels[0][0], (double)tex.texels[0][1], (double)tex.texels[0][2]};
+    if (sp.plain) { const float *t = tex.texels[0]; return V3{(double)load_dev(t), (double)load_dev(t + 1), (double)load_dev(t + 2)}; }
     double o[3]; tex_fetch(tex, sp.uv, sp.du_dxy, sp.dv_dxy, o); return V3{o[0], o[1], o[2]};
 }
 RDR_FN double tex1(const TexD &tex, const Surf &sp) {
-    if (sp.plain) return tex.texels[0][0];
+    if (sp.plain) return load_dev(tex.texels[0]);
     double o; tex_fetch(tex, sp.uv, sp.du_dxy, sp.dv_dxy, &o); return o;
 }
 RDR_FN void adj_tex3(const TexD &tex, const Surf &sp, V3 o_bar, const GTex &g, Surf &sp_bar) {

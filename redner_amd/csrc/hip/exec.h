@@ -97,6 +97,11 @@ __device__ inline double wave_sum(double x) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// fp64 add to an accumulator in DEVICE memory.  The accumulators' addresses reach the stages through tables in memory, so the
+// compiler knows no address space for them and unsafeAtomicAdd() becomes flat_atomic_add_f64 (the flat path tests every lane's
+// address against the LDS / scratch apertures before it goes to the L2); they are hipMalloc'ed blocks, always: global_atomic_add_f64.
+typedef __attribute__((address_space(1))) double *GlobalDouble;
+__device__ inline void global_add_f64(double *p, double v) { (void)__builtin_amdgcn_global_atomic_fadd_f64((GlobalDouble)p, v); }
 __device__ inline void accum_rounds(double *p, double v, int ROUNDS);
 __device__ inline void accum(double *p, double v) { accum_rounds(p, v, kAccumRounds); }
 // Texel gradients: the lanes of a wave (64 neighbouring pixels) fall on a handful of texels of a magnified or coarse level,
@@ -131,10 +136,10 @@ __device__ inline void accum_rounds(double *p, double v, int ROUNDS) {
                 s += __hiloint2double(__builtin_amdgcn_readlane(vhi, k), __builtin_amdgcn_readlane(vlo, k));
             }
         }
-        if (lane == l) unsafeAtomicAdd(p, s);
+        if (lane == l) global_add_f64(p, s);
         if (same) mine = false;
     }
-    if (mine) unsafeAtomicAdd(p, v);
+    if (mine) global_add_f64(p, v);
 }
 __host__ inline void accum(double *p, double v) { *p += v; }   // host instantiation is never executed
 __host__ inline void accum_texel(double *p, double v) { *p += v; }
@@ -143,11 +148,11 @@ __host__ inline void accum_texel(double *p, double v) { *p += v; }
 // bounce adjoint (6 000 of its 13 500 instructions per wave, profiles/r2_pmc_sq2.csv).
 __device__ inline void accum_plain(double *p, double v) {
     p = replica_of(p);
-    unsafeAtomicAdd(p, v);
+    global_add_f64(p, v);
 }
 __host__ inline void accum_plain(double *p, double v) { *p += v; }
 // fp64 atomic add on an ordinary buffer (no replicas: NOT for the gradient accumulators)
-__device__ inline void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
+__device__ inline void atomic_add_f64(double *p, double v) { global_add_f64(p, v); }
 __host__ inline void atomic_add_f64(double *p, double v) { *p += v; }
 __device__ inline int atomic_fetch_add(int *p, int v) { return atomicAdd(p, v); }
 __host__ inline int atomic_fetch_add(int *p, int v) { int o = *p; *p += v; return o; }

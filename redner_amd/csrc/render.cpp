@@ -280,6 +280,14 @@ struct GradStore {
         counting = false; pairs.clear();
         for (Tier &t : tier) t.cursor = 0;
         layout(scene, ds);                                   // pass 2: real pointers
+#ifdef RDR_HOSTSIM
+        // debugging harness only (tests/hostsim/exec.h: F32Shadow): the reference's fp32 accumulators beside the small tier
+        f32_shadow() = F32Shadow();
+        if (std::getenv("RDR_HOSTSIM_REF_ORDER") && tier[0].stride) {
+            f32_shadow().base = tier[0].base; f32_shadow().count = tier[0].stride;
+            f32_shadow().acc.assign(tier[0].stride, 0.f);
+        }
+#endif
     }
     void layout(const Scene &scene, const rdr_dscene_desc &ds) {
         if (ds.num_shapes != (int)scene.shapes.size() || ds.num_materials != (int)scene.materials.size() ||
@@ -337,6 +345,14 @@ struct GradStore {
         }
     }
     void flush() {
+#ifdef RDR_HOSTSIM
+        if (f32_shadow().base == tier[0].base && f32_shadow().base) {       // reference-order mode: the floats, not the fp64 sums
+            for (const Pair &p : pairs)
+                if (p.tier == 0 && p.count <= 16)
+                    for (size_t i = 0; i < p.count; ++i) p.acc[i] = (double)f32_shadow().acc[(size_t)(p.acc - tier[0].base) + i];
+            f32_shadow() = F32Shadow();
+        }
+#endif
         // one launch per tier for all its tensors, unless two mirrors feed overlapping output ranges (a tensor shared by two
         // DScene entries): those must add one after the other
         std::vector<Pair> by_out(pairs);

@@ -43,7 +43,7 @@ struct TriVerts { V3 p0, p1, p2; int i0, i1, i2; };
 RDR_FN TriVerts load_tri(const ShapeD &sh, int tri) {
     TriVerts t;
     if (sh.geom) {
-        const TriGeomD &g = sh.geom[tri];
+        const TriGeomD g = load_dev(sh.geom + tri);
         t.i0 = g.vi[0]; t.i1 = g.vi[1]; t.i2 = g.vi[2];
         t.p0 = v3f(g.p); t.p1 = v3f(g.p + 3); t.p2 = v3f(g.p + 6);
         return t;
@@ -207,7 +207,7 @@ struct TriAttr {     // per-corner attributes resolved through the optional inde
 RDR_FN TriAttr load_attr(const ShapeD &sh, int tri, const TriVerts &tv) {
     TriAttr a;
     if (sh.geom) {
-        const TriGeomD &g = sh.geom[tri];
+        const TriGeomD g = load_dev(sh.geom + tri);
         a.ui0 = g.ui[0]; a.ui1 = g.ui[1]; a.ui2 = g.ui[2];
         a.ni0 = g.ni[0]; a.ni1 = g.ni[1]; a.ni2 = g.ni[2];
         if (sh.uvs) { a.uv0 = v2(g.uv[0], g.uv[1]); a.uv1 = v2(g.uv[2], g.uv[3]); a.uv2 = v2(g.uv[4], g.uv[5]); }
@@ -231,7 +231,7 @@ RDR_FN TriAttr load_attr(const ShapeD &sh, int tri, const TriVerts &tv) {
 // The three shading normals of triangle `tri` (the shape has normals).
 RDR_FN void load_normals(const ShapeD &sh, int tri, const TriAttr &at, V3 &n0, V3 &n1, V3 &n2) {
     if (sh.geom) {
-        const TriGeomD &g = sh.geom[tri];
+        const TriGeomD g = load_dev(sh.geom + tri);
         n0 = v3f(g.n); n1 = v3f(g.n + 3); n2 = v3f(g.n + 6);
         return;
     }

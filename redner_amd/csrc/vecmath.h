@@ -36,6 +36,20 @@ namespace rdr {
 using gm::sin; using gm::cos; using gm::atan2; using gm::atan; using gm::acos; using gm::log; using gm::pow;
 #endif
 
+// One object read from DEVICE memory through a pointer that was itself loaded from memory (mesh records, texels: the tables of
+// a Scene): the compiler knows no address space for such a pointer and emits flat_load, which counts against the vector-memory
+// AND the LDS / scalar-memory counters -- every wait on a scalar load then also waits for it.  These tables are hipMalloc'ed
+// blocks, always: read them as global memory.  (The copy is scalarised: fields that are not used are not loaded.)
+template <class T> RDR_FN T load_dev(const T *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    T v;
+    __builtin_memcpy(&v, (const __attribute__((address_space(1))) void *)p, sizeof(T));
+    return v;
+#else
+    return *p;
+#endif
+}
+
 struct V2 { double x, y; };
 struct V3 { double x, y, z; };
 

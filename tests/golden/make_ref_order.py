@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""The camera gradients of a case under a DEFINED accumulation order (build container; fixtures <case>_ref_order.npz).
+
+Two processes render the same case:
+  oracle1t   the reference's C++ core (oracle/_ref) with ONE visible processor (LD_PRELOAD oracle/_ref/one_core.so): its
+             parallel_for runs on the calling thread, so every fp32 atomic add (src/atomic.h:43-141) happens in a defined order --
+             sample by sample, kernel by kernel, lane by lane;
+  harness    the product's stage bodies on the CPU debugging harness (tests/hostsim), one sample per launch, one host thread,
+             with RDR_HOSTSIM_REF_ORDER=1: beside its fp64 accumulators it keeps the reference's floats (`float += (float)term`)
+             in the order it issues the adds, which for the camera tensors is the same order (one add per lane in
+             d_primary_intersection, then one per slot in compute_primary_edge_derivatives, src/camera.h:255-257,824-826);
+             and once more without the switch: the fp64 sums.
+If the harness' floats equal the one-thread oracle's, the distance between the oracle's value and the fp64 sum is accumulation
+error of the reference's floats and nothing else; the fp64 sum is then the value a GPU result is compared with
+(tests/parity_util.py, tests/test_accumulation_order.py).
+
+  python tests/golden/make_ref_order.py <case> [...]          # writes tests/golden/<case>_ref_order.npz
+  python tests/golden/make_ref_order.py --leg oracle1t|harness32|harness64 <case> <out.npz>   (internal)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+ONE_CORE = os.path.join(ROOT, 'oracle', '_ref', 'one_core.so')
+HOSTSIM = os.path.join(ROOT, 'tests', 'hostsim', '_build', 'libredner_hostsim.so')
+CAM = ('grad_cam_position', 'grad_cam_look_at', 'grad_cam_up')
+
+
+def leg(which, case, out):
+    import torch  # noqa: F401
+    from golden.make_golden import CASES, CONFIG_CASES, render_case
+    spec = list(CASES.get(case) or CONFIG_CASES[case])
+    while len(spec) < 6:
+        spec.append(None)
+    if which == 'oracle1t':
+        import oracle_util
+        backend = oracle_util.load_oracle()
+    else:
+        from redner_amd import _capi
+        _capi.load(HOSTSIM)
+        from redner_amd import redner as backend
+        spec[5] = dict(spec[5] or {}, tuning={'batch_samples': 1, 'workers': 1})
+    res = render_case(backend, *spec)
+    np.savez(out, **{k: v for k, v in res.items() if k.startswith('grad_cam_')})
+
+
+def run_leg(which, case, out):
+    env = dict(os.environ, MALLOC_MMAP_THRESHOLD_='65536', MALLOC_PERTURB_='255')
+    if which == 'oracle1t':
+        env['LD_PRELOAD'] = ONE_CORE
+    if which == 'harness32':
+        env['RDR_HOSTSIM_REF_ORDER'] = '1'
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), '--leg', which, case, out], env=env)
+    return np.load(out)
+
+
+def make(case, tmp='/tmp', out_dir=HERE):
+    res = {w: run_leg(w, case, os.path.join(tmp, 'ref_order_%s_%s.npz' % (case, w))) for w in ('oracle1t', 'harness32', 'harness64')}
+    out = {}
+    for k in res['oracle1t'].files:
+        for w in res:
+            out['%s_%s' % (w, k)] = res[w][k]
+        o, h32, h64 = (res[w][k].astype(np.float64) for w in ('oracle1t', 'harness32', 'harness64'))
+        n = np.linalg.norm(h64)
+        print('%s %-20s harness floats vs one-thread oracle %.3e | oracle vs fp64 sum %.3e | floats vs fp64 sum %.3e'
+              % (case, k, np.linalg.norm(h32 - o) / n, np.linalg.norm(o - h64) / n, np.linalg.norm(h32 - h64) / n), flush=True)
+    np.savez(os.path.join(out_dir, case + '_ref_order.npz'), **out)
+    return out
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == '--leg':
+        leg(*sys.argv[2:5])
+    else:
+        for c in sys.argv[1:]:
+            make(c)

@@ -61,7 +61,7 @@ inline Path record(const rt::BvhD &bvh, const float o[3], const float d[3], floa
 
 constexpr double Ci = 110, Ct = 190, Cr = 150;
 
-struct Tot { double rep[8] = {0}; double bud[12] = {0}; double vw[6] = {0, 0, 0, 0, 0, 0}; double multi_s[3] = {0, 0, 0}, multi_d[3] = {0, 0, 0}; double vote[4] = {0, 0, 0, 0}, vote_sorted[4] = {0, 0, 0, 0}; double useful = 0, ifif = 0, whilewhile = 0, ww_sorted = 0, refill8 = 0, refill24 = 0, refill_sorted = 0; long rays = 0, live = 0; };
+struct Tot { double rep[8] = {0}; double bud[12] = {0}; double vw[6] = {0, 0, 0, 0, 0, 0}; double multi_s[3] = {0, 0, 0}, multi_d[3] = {0, 0, 0}; double vote[4] = {0, 0, 0, 0}, vote_sorted[4] = {0, 0, 0, 0}; double spec[12] = {0}; double useful = 0, ifif = 0, whilewhile = 0, ww_sorted = 0, refill8 = 0, refill24 = 0, refill_sorted = 0; long rays = 0, live = 0; };
 inline Tot &tot(bool any) { static Tot t[2]; return t[any ? 1 : 0]; }
 
 inline double useful_of(const Path &p) { double c = 0; for (const Seg &s : p) c += Ci * s.inner + Ct * s.tris; return c; }
@@ -165,6 +165,61 @@ inline double sim_refill(const std::vector<const Path *> &q, int idle_min) {
             if (++seg[l] >= cur[l]->size()) cur[l] = nullptr;
         }
         if (alive) cost += Ci * max_i + Ct * max_t;
+    }
+    return cost;
+}
+
+// persistent wave with refill (>= idle_min idle lanes), SPECULATIVE leaves: a lane that reaches a leaf puts it in a pocket
+// (`pockets` of them) and goes on with its walk; it waits only when it reaches a leaf with every pocket full or has nothing left
+// to walk.  The pockets of the whole wave are tested together (a loop over the largest pocket content) when >= pend_min lanes
+// hold one, when >= wait_min lanes wait, or when nobody can walk.  `vote`: instructions per iteration for the ballots.
+inline double sim_spec(const std::vector<const Path *> &q, int idle_min, int pockets, int pend_min, int wait_min, double vote) {
+    struct Ev { bool leaf; int tris; };
+    size_t next = 0;
+    std::vector<Ev> ev[64]; size_t at[64]; int pocket[64]; int pocket_n[64]; bool has[64];
+    for (int l = 0; l < 64; ++l) { has[l] = false; pocket[l] = 0; pocket_n[l] = 0; at[l] = 0; }
+    double cost = 0;
+    auto load = [&](int l, const Path *p) {
+        ev[l].clear(); at[l] = 0; pocket[l] = 0; pocket_n[l] = 0;
+        for (const Seg &s : *p) { for (int i = 0; i < s.inner; ++i) ev[l].push_back(Ev{false, 0}); if (s.tris > 0) ev[l].push_back(Ev{true, s.tris}); }
+        has[l] = !ev[l].empty();
+    };
+    for (;;) {
+        int idle = 0;
+        for (int l = 0; l < 64; ++l) if (!has[l]) ++idle;
+        if (idle == 64 && next >= q.size()) break;
+        if ((idle >= idle_min || idle == 64) && next < q.size()) {
+            for (int l = 0; l < 64 && next < q.size(); ++l) if (!has[l]) load(l, q[next++]);
+            cost += Cr;
+        }
+        // who can walk: has events left and (next event is not a leaf or a pocket is free)
+        int walkers = 0, pend = 0, waiting = 0;
+        for (int l = 0; l < 64; ++l) {
+            if (!has[l]) continue;
+            const bool more = at[l] < ev[l].size();
+            const bool can = more && (!ev[l][at[l]].leaf || pocket_n[l] < pockets);
+            if (can) ++walkers; else ++waiting;
+            if (pocket_n[l] > 0) ++pend;
+        }
+        cost += vote;
+        const bool flush = pend > 0 && (pend >= pend_min || waiting >= wait_min || walkers == 0);
+        if (flush) {
+            int max_t = 0;
+            for (int l = 0; l < 64; ++l) if (has[l]) { max_t = std::max(max_t, pocket[l]); pocket[l] = 0; pocket_n[l] = 0; }
+            cost += Ct * max_t;
+            for (int l = 0; l < 64; ++l) if (has[l] && at[l] >= ev[l].size()) has[l] = false;
+            continue;
+        }
+        if (walkers > 0) {
+            cost += Ci;
+            for (int l = 0; l < 64; ++l) {
+                if (!has[l] || at[l] >= ev[l].size()) continue;
+                const Ev &e = ev[l][at[l]];
+                if (e.leaf) { if (pocket_n[l] < pockets) { pocket[l] += e.tris; ++pocket_n[l]; ++at[l]; } }
+                else ++at[l];
+                if (at[l] >= ev[l].size() && pocket_n[l] == 0) has[l] = false;
+            }
+        }
     }
     return cost;
 }
@@ -369,6 +424,9 @@ inline void report() {
           for (int i = 0; i < 12; ++i) line(nm[i], t.bud[i]); }
         { const char *nm[8] = {"repack wg 256 every 8", "repack wg 512 every 8", "repack wg 1024 every 8", "repack wg 1024 every 4", "repack wg 1024 every 16", "repack wg 1024 every 12", "repack wg 2048 every 8", "repack wg 1024 every 8 (free)"};
           for (int i = 0; i < 8; ++i) line(nm[i], t.rep[i]); }
+        { const char *nm[12] = {"spec 1 pocket pend16 wait8", "spec 1 pocket pend24 wait12", "spec 1 pocket pend32 wait16", "spec 2 pockets pend16 wait8", "spec 2 pockets pend24 wait12", "spec 2 pockets pend32 wait16",
+                                "spec 2 pockets pend32 wait24", "spec 2 pockets pend48 wait24", "spec 1 pocket pend8 wait4", "spec 2 pockets pend24 wait12 idle8", "spec 1 pocket pend1 wait1 (=if-if refill)", "spec 3 pockets pend32 wait16"};
+          for (int i = 0; i < 12; ++i) line(nm[i], t.spec[i]); }
         line("refill (>= 8 idle)", t.refill8); line("refill (>= 24 idle)", t.refill24); line("refill (>= 8), sorted", t.refill_sorted);
     }
 }
@@ -399,6 +457,8 @@ inline void launch(const rt::BvhD &bvh, const rt::RayRec *rays, int n, bool any)
     { const int ks[3] = {2, 4, 8};
       for (int i = 0; i < 3; ++i) for (int w = 0; w < n; w += 64 * ks[i]) { int m = std::min(64 * ks[i], n - w); t.multi_s[i] += sim_multi(q.data() + w, m, ks[i], false); t.multi_d[i] += sim_multi(q.data() + w, m, ks[i], true); } }
     t.refill8 += sim_refill(q, 8); t.refill24 += sim_refill(q, 24);
+    { const int pk[12] = {1, 1, 1, 2, 2, 2, 2, 2, 1, 2, 1, 3}, pm[12] = {16, 24, 32, 16, 24, 32, 32, 48, 8, 24, 1, 32}, wm[12] = {8, 12, 16, 8, 12, 16, 24, 24, 4, 12, 1, 16}, im[12] = {24, 24, 24, 24, 24, 24, 24, 24, 24, 8, 24, 24};
+      for (int i = 0; i < 12; ++i) t.spec[i] += sim_spec(q, im[i], pk[i], pm[i], wm[i], 10); }
     { const int parks[4] = {8, 16, 32, 48}; for (int i = 0; i < 4; ++i) t.vote[i] += sim_vote(q, 8, parks[i]); }
     std::vector<int> order(n);
     for (int i = 0; i < n; ++i) order[i] = i;

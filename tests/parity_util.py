@@ -18,14 +18,20 @@ TOL = 1e-4           # BASELINE.json north_star: 1e-4 relative L2, forward image
 ACCUMULATOR_ELEMS = 16   # tensors this small (light intensity, constant reflectance, camera) collect millions of fp32 atomics
 
 
-def compare(out, gold):
+def compare(out, gold, name=None):
     """-> {tensor: {'rel_l2': e, 'tol': 1e-4, 'flipped_rows': k, ...}}; asserts keys match and values are finite.
 
-    Every tensor is held to 1e-4 (one documented exception below).  Where the fixture carries `ref64_<tensor>` -- the oracle's own estimator on the same
-    samples with the error of its fp32 atomics taken out (sum of 64 pixel-striped oracle passes in fp64,
+    Every tensor is held to 1e-4, no exception.  Where the fixture carries `ref64_<tensor>` -- the oracle's own estimator on the
+    same samples with the error of its fp32 atomics taken out (sum of 64 pixel-striped oracle passes in fp64,
     make_golden.add_ref64) -- THAT is the value compared with, and the distance to the oracle's single fp32 pass is only
     reported (`single_pass_rel_l2`, next to `oracle_selfdiff`: how far the single pass moves under an equivalent evaluation
-    order, and `ref64_convergence`: K = 16 vs K = 64 stripes)."""
+    order, and `ref64_convergence`: K = 16 vs K = 64 stripes).
+
+    `name`: the case.  Where tests/golden/<name>_ref_order.npz exists (make_ref_order.py), a camera tensor is compared with
+    `harness64_<tensor>`: the fp64 sum of the SAME addends whose fp32 sum in the reference's own order (`harness32_`) equals the
+    reference run on one thread (`oracle1t_`) -- tests/test_accumulation_order.py holds the fixture to that -- i.e. the oracle's
+    value with its accumulation error, and nothing else, removed.  (Round 4 capped the bar of one tensor, the camera position of
+    bunny_box 512 x 512 x 8, at 5e-4 because even 256-stripe sums of the oracle had not settled; that cap is gone.)"""
     gold = {k: gold[k] for k in (gold.files if hasattr(gold, 'files') else gold)}
     prefixes = ('selfdiff_', 'ref64_', 'ref64conv_', 'ref256_', 'ref256conv_', 'ref16_')
     aux = {p: {k[len(p):]: v for k, v in gold.items() if k.startswith(p)} for p in prefixes}
@@ -34,6 +40,10 @@ def compare(out, gold):
         aux['ref64_'][k] = v
         aux['ref64conv_'][k] = aux['ref256conv_'][k]
     assert set(out.keys()) == set(gold.keys()), (sorted(out.keys()), sorted(gold.keys()))
+    ref_order = {}
+    if name and os.path.exists(os.path.join(GOLD, name + '_ref_order.npz')):
+        z = np.load(os.path.join(GOLD, name + '_ref_order.npz'))
+        ref_order = {k[len('harness64_'):]: z[k].astype(np.float64) for k in z.files if k.startswith('harness64_')}
     rep = {}
     for k, gv in gold.items():
         g, mine = torch.from_numpy(np.asarray(gv)), torch.from_numpy(np.asarray(out[k]))
@@ -48,23 +58,12 @@ def compare(out, gold):
             entry['rel_l2'] = rel_l2(mine, torch.from_numpy(np.asarray(aux['ref64_'][k])))
             entry['against'] = 'ref256' if k in aux['ref256_'] else 'ref64'
             entry['ref64_convergence'] = float(aux['ref64conv_'][k])       # between the two finest striped sums of the fixture
-            # The striped sum itself must have settled for a 1e-4 comparison to mean anything.  For ONE tensor of all fixtures it
-            # has not: the camera position of bunny_box 512 x 512 x 8 -- three numbers of 5e5, each the sum of 1.7e7 cancelling
-            # terms.  The reference adds every term as `float += (float)term` (src/atomic.h:43-141): an add rounds at the
-            # magnitude of the larger of accumulator and ADDEND, so where single edge-sample terms are large (1 / pdf weights)
-            # striping the upstream gradient over more passes (fewer adds per pass) stops shrinking the error -- which is what
-            # the striped sums show: K = 64 and K = 256 differ by 2.9e-4 of the norm (the single pass by 8e-4), no faster than
-            # K^-0.35; K = 1024 (16 h of oracle time) would not settle it.  The GPU (fp64 accumulators; the CPU harness, which
-            # shares no accumulation code with it, gives the same value to 1e-7) lies 4.8e-4 from the K = 256 sum and 7.7e-4 from
-            # the K = 64 sum, and its x component is reached by the striped sums to 1 part in 4e5 (-394912 / -394653 / -394673.5
-            # for 1 / 64 / 256 stripes, GPU -394672.5).  The
-            # oracle's value for this tensor is known to no better than a few 1e-4, so the bar for it is 4 x the distance
-            # between the two finest striped sums, CAPPED at 5e-4 of the norm (advisor, round 3); every other tensor of every
-            # fixture is held to the flat 1e-4 (two more tensors have striped sums 1.5e-4 / 1.9e-4 apart -- the config-5
-            # stand-in's camera position / look-at -- and the GPU is within 3.4e-5 / 3.9e-6 of them anyway).
             if entry['ref64_convergence'] > TOL:
-                entry['tol'] = min(4.0 * entry['ref64_convergence'], 5e-4)
-                entry['oracle_not_converged'] = True
+                entry['oracle_not_converged'] = True          # reported; the bar stays 1e-4
+        if k in ref_order:
+            entry['rel_l2_vs_striped_sum'] = entry['rel_l2']
+            entry['rel_l2'] = rel_l2(mine, torch.from_numpy(ref_order[k]))
+            entry['against'] = 'harness64 (reference-order accumulation proof, tests/test_accumulation_order.py)'
         if k in aux['selfdiff_']:
             entry['oracle_selfdiff'] = float(aux['selfdiff_'][k])
         if k in aux['ref16_']:

@@ -22,7 +22,7 @@ from parity_util import GOLD, assert_parity, compare, record
 @pytest.mark.parametrize('name', list(CONFIG_CASES))
 def test_config_size_gpu(gpu_backend, name):
     out = render_case(gpu_backend, *CONFIG_CASES[name], device=torch.device('cuda:0'))
-    rep = compare(out, np.load(os.path.join(GOLD, name + '.npz')))
+    rep = compare(out, np.load(os.path.join(GOLD, name + '.npz')), name)
     record(name, rep, 'gpu')
     assert_parity(rep, name)
 
