@@ -276,7 +276,18 @@ int rdr_debug_bvh_check(const rdr_scene *scene);
  * text, for the build-order parity test against the reference (tests/test_edge_build.py). */
 int rdr_debug_dump_edges(const rdr_scene *scene, const char *path);
 
-/* Test hook: sin / cos / atan2 / atan / acos / log / pow as the kernels evaluate them (csrc/libm_exact.h: glibc 2.35's
+/* The library is built twice from the same sources (__graft_entry__.build_native):
+ *   libredner_amd.so        the stage kernels call the DEVICE's own sin / cos / atan2 / atan / acos / log / pow (ocml): the
+ *                           default, +1 ... 3 % throughput; every result is an equally valid sample of the same estimator, and
+ *                           sample-for-sample equal to the reference wherever no transcendental feeds a chaotic decision
+ *                           (perspective / orthographic cameras: all BASELINE configs);
+ *   libredner_amd_exact.so  they call restatements of glibc 2.35's routines (csrc/libm_exact.h, see NOTICE), bit for bit what
+ *                           the reference's CPU path computes: fisheye / panorama cameras with secondary edge sampling are then
+ *                           sample-exact too.  The parity tests load this one (REDNER_AMD_LIBM=exact, redner_amd/_capi.py).
+ * rdr_libm_exact(): 1 in the second, 0 in the first. */
+int rdr_libm_exact(void);
+
+/* Test hook: sin / cos / atan2 / atan / acos / log / pow as the EXACT routines evaluate them (in either build) (csrc/libm_exact.h: glibc 2.35's
  * results bit for bit -- the reference's CPU path calls glibc, src/camera.h:142-191, src/material.h, src/envmap.h), one
  * argument per lane; HOST pointers, `y` may be NULL for the one-argument functions.
  * fn: 0 sin(x), 1 cos(x), 2 atan2(x, y), 3 atan(x), 4 acos(x), 5 log(x), 6 pow(x, y). */

@@ -12,6 +12,9 @@ import os
 MAX_MIP = 8
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, 'lib', 'libredner_amd.so')
+# the same library with glibc-exact transcendental functions in its kernels (include/redner_amd.h: rdr_libm_exact):
+# REDNER_AMD_LIBM=exact selects it (the parity tests do, tests/conftest.py)
+EXACT_LIBRARY = os.path.join(_HERE, 'lib', 'libredner_amd_exact.so')
 
 c_float_p = C.POINTER(C.c_float)
 c_int_p = C.POINTER(C.c_int32)
@@ -130,7 +133,7 @@ EXPORTS = ('rdr_scene_create', 'rdr_scene_destroy', 'rdr_scene_max_generic_textu
            'rdr_render', 'rdr_compute_num_channels', 'rdr_last_error',
            'rdr_trace_stats_enable', 'rdr_trace_stats_reset', 'rdr_trace_stats_get', 'rdr_scene_trace',
            'rdr_debug_counters_get', 'rdr_trim_cache', 'rdr_debug_dump_edges', 'rdr_debug_bvh_check',
-           'rdr_set_stream', 'rdr_set_pool_cap_mb', 'rdr_set_build_flags', 'rdr_debug_libm')
+           'rdr_set_stream', 'rdr_set_pool_cap_mb', 'rdr_set_build_flags', 'rdr_debug_libm', 'rdr_libm_exact')
 
 _lib = None
 _lib_path = None
@@ -140,7 +143,8 @@ def load(path=None):
     """Load the C-ABI library (default: the HIP build).  Raises RuntimeError when it is missing."""
     global _lib, _lib_path
     # REDNER_AMD_LIB: another build of the same library (A/B of two builds inside one GPU session, tools/gpu_ab_builds.sh)
-    path = path or os.environ.get('REDNER_AMD_LIB') or DEFAULT_LIBRARY
+    path = path or os.environ.get('REDNER_AMD_LIB') or \
+        (EXACT_LIBRARY if os.environ.get('REDNER_AMD_LIBM', '').lower() == 'exact' else DEFAULT_LIBRARY)
     if not os.path.exists(path):
         raise RuntimeError(
             "redner_amd: native library %s not found. Build it with "
@@ -184,6 +188,8 @@ def load(path=None):
     lib.rdr_trace_stats_get.argtypes = [C.POINTER(TraceStats)]
     lib.rdr_scene_trace.restype = C.c_int
     lib.rdr_scene_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.rdr_libm_exact.restype = C.c_int
+    lib.rdr_libm_exact.argtypes = []
     lib.rdr_debug_libm.restype = C.c_int
     lib.rdr_debug_libm.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _lib, _lib_path = lib, path
@@ -198,6 +204,11 @@ def lib():
 
 def library_path():
     return _lib_path
+
+
+def is_product_library():
+    """The loaded library is one of the two HIP builds (not the CPU debugging harness, not an A/B variant)."""
+    return _lib_path in (DEFAULT_LIBRARY, EXACT_LIBRARY)
 
 
 def last_error():

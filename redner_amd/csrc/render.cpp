@@ -1212,3 +1212,12 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
 } // namespace
 
 } // namespace rdr
+
+// Which transcendental functions this build of the stage kernels calls (include/redner_amd.h: rdr_libm_exact)
+extern "C" int rdr_libm_exact(void) {
+#ifdef RDR_PLATFORM_LIBM
+    return 0;
+#else
+    return 1;
+#endif
+}

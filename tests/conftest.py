@@ -9,6 +9,13 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
 
 
+# The parity tests hold the GPU to the oracle sample for sample, also where a transcendental function feeds a chaotic decision
+# (fisheye / panorama cameras + the hierarchical edge pick): they load the build whose kernels compute sin / cos / ... as glibc
+# does (libredner_amd_exact.so; include/redner_amd.h: rdr_libm_exact).  Subprocesses started by tests inherit the choice.
+# tests/test_default_library_gpu.py covers the default build (the device's own libm), which bench.py and smoke() run.
+os.environ.setdefault('REDNER_AMD_LIBM', 'exact')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run by the driver with -m gpu)')
 
@@ -35,7 +42,8 @@ def gpu_backend():
     import torch
     from redner_amd import _capi
     assert torch.cuda.is_available(), 'gpu tests need a GPU'
-    _capi.load()          # default = redner_amd/lib/libredner_amd.so
-    assert _capi.library_path().endswith('libredner_amd.so')
+    _capi.load()          # redner_amd/lib/libredner_amd_exact.so (REDNER_AMD_LIBM=exact, above)
+    assert _capi.is_product_library(), _capi.library_path()
+    assert _capi.lib().rdr_libm_exact() == (1 if os.environ.get('REDNER_AMD_LIBM') == 'exact' else 0)
     from redner_amd import redner
     return redner

@@ -70,7 +70,7 @@ sys.path[:0] = [%(root)r, %(root)r + '/tests']
 import numpy as np, torch, torch.distributed as dist
 from redner_amd import _capi
 _capi.load()                                     # the product library
-assert _capi.library_path().endswith('libredner_amd.so')
+assert _capi.is_product_library(), _capi.library_path()
 from redner_amd import redner
 from redner_amd.render_pytorch import RenderFunction
 from redner_amd.distributed import render_sharded

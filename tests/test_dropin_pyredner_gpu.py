@@ -29,7 +29,7 @@ if which == 'mine':
     from redner_amd import _capi
     redner_amd.install()                      # `import redner` now resolves to redner_amd.redner
     _capi.load()                              # the PRODUCT library; raises if libredner_amd.so is missing
-    assert _capi.library_path().endswith('libredner_amd.so'), _capi.library_path()
+    assert _capi.is_product_library(), _capi.library_path()
 else:
     import oracle_util
     sys.modules['redner'] = oracle_util.load_oracle()

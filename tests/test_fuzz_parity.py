@@ -135,14 +135,14 @@ def _distance(mine, ref, skip=()):
         return 'keys differ'
     if not np.array_equal(mine['image'], ref['image']):
         return 'image differs'
-    # position / look_at / up gradients are three projections of the same per-pixel addends (d cam_to_world); the reference sums
-    # them with fp32 atomics, whose rounding is relative to the ADDENDS: `up`, whose sum nearly cancels (norm 0.05 beside 1-5 for
-    # the other two), carries that noise at 1e-4 ... 3e-4 of its own norm.  The three are held to 1e-4 of the largest of them.
-    cam_scale = max(np.linalg.norm(ref[k].astype(np.float64)) for k in ref if k.startswith('cam_'))
+    # every tensor to 1e-4 of ITS OWN norm -- also the three camera gradients (position / look_at / up: three projections of the
+    # same per-pixel addends, of which `up` nearly cancels: norm 0.05 beside 1-5; rounds 3-4 held the three to the largest of
+    # them).  The reference sums them with fp32 atomics whose rounding is relative to the ADDENDS, so its single pass carries
+    # 1e-4 ... 3e-4 of noise in such a tensor: a failure here goes to _few_element_check (the oracle's striped fp64 sum).
     for k in ref:
         if k in skip:
             continue
-        n = cam_scale if k.startswith('cam_') else np.linalg.norm(ref[k].astype(np.float64))
+        n = np.linalg.norm(ref[k].astype(np.float64))
         d = np.linalg.norm(mine[k].astype(np.float64) - ref[k].astype(np.float64))
         if not d <= 1e-4 * n + 1e-9:
             if _edge_flip(k, mine[k], ref[k]):
@@ -533,7 +533,7 @@ def _main(lib):
     if lib == 'gpu':
         assert torch.cuda.is_available(), 'the GPU leg needs a GPU'
         _capi.load()
-        assert _capi.library_path().endswith('libredner_amd.so')
+        assert _capi.is_product_library(), _capi.library_path()
         MINE_DEVICE, ON_GPU = torch.device('cuda:0'), True
     else:
         _capi.load(lib)
