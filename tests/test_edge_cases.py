@@ -97,7 +97,7 @@ def test_empty_scene_twice_gpu(gpu_backend):
         scene = sc if k == 2 else Scene(sc.camera, [], [], [])
         args = RenderFunction.serialize_scene(scene, 1, 1, sampler_type=gpu_backend.SamplerType.sobol, device=dev, backend=gpu_backend)
         img = RenderFunction.apply(1, *args)
-        assert img.shape == (16, 16, 3) and bool(img.cpu().numpy().any()) == (k == 2)
+        assert img.shape == (16, 16, 3) and bool(img.detach().cpu().numpy().any()) == (k == 2)
 
 
 @pytest.mark.gpu
