@@ -178,11 +178,58 @@ def cpu_baseline(a, gpu_rd=None, gpu_dev=None):
                                                     'largest_block_sum_difference': blocks_err, 'vertex_gradient_rel_l2': e,
                                                     'ok': bool(same and e < 1e-4)}
     rate, res, spp, reps, dt = best
-    return {'value': rate, 'unit': 'Msamples/s', 'cores': os.cpu_count(), 'kind': 'reference',
+    threads = os.cpu_count()
+    sweep = cpu_thread_sweep(a)
+    for leg in sweep:
+        if leg.get('value', 0.0) > rate:
+            rate, res, spp, reps, dt, threads = leg['value'], 256, 4, 3, min(leg['seconds_per_pass']), leg['threads']
+    return {'value': rate, 'unit': 'Msamples/s', 'cores': threads, 'host_threads': os.cpu_count(), 'kind': 'reference', 'thread_sweep': sweep,
             'sample': '%s %dx%d, %d spp fwd+bwd, max_bounces %d, Sobol, best of %d passes (%.1f s); reference C++ core '
-                      '(oracle/_ref) with the BVH Embree stand-in, all host threads; the better of the two samples in `samples`'
+                      '(oracle/_ref) with the BVH Embree stand-in; the best of: all host threads on the two samples in `samples`, '
+                      'and 16 / 32 / 64 threads on the first (`thread_sweep`); `cores` = the threads of the best run'
                       % (a.workload, res, res, spp, a.max_bounces, reps, dt),
             'samples': lines, 'gpu_vs_reference': check}
+
+
+def cpu_baseline_leg(a):
+    """Body of one leg of the thread sweep (a child process under LD_PRELOAD=oracle/_ref/nprocs_shim.so, ORACLE_NPROCS=n): the
+    256 x 256, 4-spp sample of the workload on the reference's C++ core, best of 3 passes; prints one JSON line."""
+    import oracle_util
+    ref = oracle_util.load_oracle()
+    cpu = torch.device('cpu')
+    res, spp = 256, 4
+    p = Prepared(ref, build_scene(a, cpu, res), spp, spp, 0, a.max_bounces, cpu)
+    times = []
+    for i in range(3):
+        t0 = time.time()
+        p.step(i)
+        times.append(time.time() - t0)
+    print(json.dumps({'threads': int(os.environ.get('ORACLE_NPROCS', '0')), 'value': res * res * spp / min(times) / 1e6,
+                      'seconds_per_pass': times}), flush=True)
+
+
+def cpu_thread_sweep(a, counts=(16, 32, 64)):
+    """The reference starts hardware_concurrency() - 1 workers per call (src/parallel.cpp:228-255); on a 256-thread host that is
+    not its best configuration for a frame this size.  The same sample on 16 / 32 / 64 threads (oracle/nprocs_shim.c), each leg
+    its own process; cpu_baseline reports the best of these and the all-threads run."""
+    shim = os.path.join(ROOT, 'oracle', '_ref', 'nprocs_shim.so')
+    if not os.path.exists(shim):
+        return []
+    out = []
+    for n in counts:
+        if n > (os.cpu_count() or 1):
+            continue
+        env = dict(os.environ, LD_PRELOAD=shim, ORACLE_NPROCS=str(n))
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+            env.pop(k, None)
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--cpu-baseline-leg', '--workload', a.workload,
+                                '--max-bounces', str(a.max_bounces)], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                               text=True, timeout=180)
+            out.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]))
+        except Exception as e:
+            out.append({'threads': n, 'error': repr(e)})
+    return out
 
 
 def sharded_self_check(a, rd, dev):
@@ -379,11 +426,14 @@ def main():
     ap.add_argument('--no-alone-leg', action='store_true', help='skip the extra single-stream step behind roofline.alone')
     ap.add_argument('--no-profile', action='store_true', help='skip the rocprofv3 counter passes behind roofline.kernels')
     ap.add_argument('--inner', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-baseline-leg', action='store_true', help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.max_bounces is None:
         a.max_bounces = 6 if a.workload.startswith('living_room_standin') else 4
     if a.inner:
         return inner_run(a)
+    if a.cpu_baseline_leg:
+        return cpu_baseline_leg(a)
 
     if a.gpus > 1 and 'RANK' not in os.environ:
         return self_launch(a)          # `python bench.py --gpus N` without a launcher: start the N ranks ourselves

@@ -14,10 +14,14 @@
 
 namespace {
 thread_local std::string g_last_error;
-// rdr_render / rdr_scene_create / rdr_scene_trace are serialised process-wide: the reference's render() is not re-entrant
-// either (global thread pool, src/parallel.cpp:10-14) but runs with the GIL held; ctypes releases the GIL, and two
-// concurrent calls would share the replicated-accumulator symbols, the helper threads and the per-thread scratch.
-std::recursive_mutex g_api_lock;
+// rdr_render / rdr_scene_create / rdr_scene_trace are serialised PER DEVICE: the reference's render() is not re-entrant either
+// (global thread pool, src/parallel.cpp:10-14) but runs with the GIL held; ctypes releases the GIL, and two concurrent calls on
+// one device would share its replicated-accumulator symbols, its helper threads and the Scene caches.  Calls on DIFFERENT
+// devices run side by side (one host thread per device in one process): every piece of state they touch is per device (buffer
+// pool free lists, Scene caches, helper threads, streams, compaction scratch) or per host thread (stream, tuning, staging), and
+// what is shared (host thread pool, edge-builder thread, trace statistics) has its own lock.
+std::recursive_mutex g_device_lock[16];
+std::recursive_mutex &device_lock(int gpu_index) { return g_device_lock[(gpu_index < 0 ? 0 : gpu_index) & 15]; }
 void set_error(const char *what) { g_last_error = what ? what : "unknown error"; }
 // rdr_set_stream: the stream the calling thread's launches are ordered on (null = the null stream)
 thread_local void *g_user_stream = nullptr;
@@ -54,7 +58,7 @@ rdr_scene *rdr_scene_create(const rdr_camera_desc *camera, const rdr_shape_desc 
                             int use_primary_edge_sampling, int use_secondary_edge_sampling) {
     try {
         g_last_error.clear();
-        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+        std::lock_guard<std::recursive_mutex> lk(device_lock(gpu_index));
         use_caller_stream();
         return reinterpret_cast<rdr_scene *>(rdr::create_scene(camera, shapes, num_shapes, materials, num_materials,
                                                                area_lights, num_area_lights, envmap, use_gpu, gpu_index,
@@ -78,7 +82,7 @@ int rdr_render(const rdr_scene *scene, const rdr_render_options *options, float 
         g_last_error.clear();
         if (!scene || !options) throw std::runtime_error("rdr_render: scene and options are required");
         const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
-        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+        std::lock_guard<std::recursive_mutex> lk(device_lock(s.gpu_index));
         exec::select_device(1, s.gpu_index);
         use_caller_stream();
         rdr::render(s, *options, rendered_image, d_rendered_image, d_scene, screen_gradient_image, debug_image);
@@ -116,7 +120,8 @@ void rdr_trace_stats_get(rdr_trace_stats *out) {
 }
 
 uint64_t rdr_trim_cache(void) {
-    std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+    std::unique_lock<std::recursive_mutex> all[16];                 // every device, in index order (a call holds one lock only)
+    for (int d = 0; d < 16; ++d) all[d] = std::unique_lock<std::recursive_mutex>(g_device_lock[d]);
     rdr::drop_edge_cache();            // the last Scene's edge structures, kept for the next one (scene.cpp: EdgeCache)
     const uint64_t bytes = exec::pool_cached_bytes();
     exec::pool_trim();
@@ -137,13 +142,13 @@ int rdr_debug_dump_edges(const rdr_scene *scene, const char *path) {
     FILE *f = fopen(path, "w");
     if (!f) return 1;
     {
-        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+        std::lock_guard<std::recursive_mutex> lk(device_lock(s.gpu_index));
         exec::select_device(1, s.gpu_index);
         try { s.edge_data(); } catch (const std::exception &e) { set_error(e.what()); fclose(f); return 1; }
     }
     if (!s.edges) { fprintf(f, "edges 0\n"); fclose(f); return 0; }
     if (s.edges->device_trees) {
-        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+        std::lock_guard<std::recursive_mutex> lk(device_lock(s.gpu_index));
         try { rdr::download_edge_trees(*s.edges); } catch (const std::exception &e) { set_error(e.what()); fclose(f); return 1; }
     }
     const rdr::EdgeData &ed = *s.edges;
@@ -176,7 +181,7 @@ int rdr_debug_bvh_check(const rdr_scene *scene) {
     try {
         const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
         if (!s.bvh_dev || s.bvh_dev->parent) return -1;
-        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+        std::lock_guard<std::recursive_mutex> lk(device_lock(s.gpu_index));
         exec::select_device(1, s.gpu_index);
         use_caller_stream();
         std::vector<rt::MeshView> meshes(s.shapes.size());
@@ -222,7 +227,7 @@ int rdr_scene_trace(const rdr_scene *scene, const float *rays, int32_t *hits, in
     try {
         g_last_error.clear();
         const rdr::Scene &s = *reinterpret_cast<const rdr::Scene *>(scene);
-        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+        std::lock_guard<std::recursive_mutex> lk(device_lock(s.gpu_index));
         exec::select_device(1, s.gpu_index);
         use_caller_stream();
         exec::trace(s.bvh, reinterpret_cast<const rt::RayRec *>(rays), reinterpret_cast<rt::HitRec *>(hits), num_rays, any_hit != 0);
@@ -240,7 +245,7 @@ int rdr_debug_libm(int fn, const double *x, const double *y, double *out, int n)
     try {
         g_last_error.clear();
         if (fn < 0 || fn > 6 || n < 0) throw std::runtime_error("rdr_debug_libm: bad arguments");
-        std::lock_guard<std::recursive_mutex> lk(g_api_lock);
+        std::lock_guard<std::recursive_mutex> lk(device_lock(exec::current_device()));
         exec::select_device(1, exec::current_device());        // the calling thread's device: checked, not changed
         use_caller_stream();
         const size_t bytes = sizeof(double) * (size_t)n;

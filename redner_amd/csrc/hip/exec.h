@@ -233,9 +233,15 @@ struct StreamScope {
 constexpr int kMaxHelpers = 3;
 class SecondThread {
 public:
-    static SecondThread &get(int k = 0) {                                                   // never destroyed
-        static SecondThread *t[kMaxHelpers] = {new SecondThread(), new SecondThread(), new SecondThread()};
-        return *t[k];
+    static SecondThread &get(int k = 0) {                          // helper k OF THE CALLING THREAD'S DEVICE; never destroyed
+        static std::mutex lock;
+        static SecondThread *t[16][kMaxHelpers] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(lock);
+        SecondThread *&p = t[dev & 15][k];
+        if (!p) p = new SecondThread();
+        return *p;
     }
     void start(std::function<void()> job) {
         int dev = 0;

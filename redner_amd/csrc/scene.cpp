@@ -157,14 +157,16 @@ struct EdgeCache {
     std::vector<std::vector<int>> indices;
     std::shared_future<std::shared_ptr<EdgeData>> result;
 };
-static EdgeCache *edge_cache() { static EdgeCache *c = new EdgeCache(); return c; }
+// (one per device: calls on one device are serialised by the API lock of that device, capi.cpp)
+static EdgeCache *edge_cache(int device) { static EdgeCache *c = new EdgeCache[16]; return c + ((device < 0 ? 0 : device) & 15); }
 // The last triangle hierarchy that was BUILT (index buffers + the build): a Scene with the same connectivity refits a copy of it.
 struct TopologyCache { std::vector<std::vector<int>> indices; rt::BvhHost bvh; std::shared_ptr<rt::BvhDev> dev; int gpu_index = -1; };
-static TopologyCache *topology_cache() { static TopologyCache *c = new TopologyCache(); return c; }
+static TopologyCache *topology_cache(int device) { static TopologyCache *c = new TopologyCache[16]; return c + ((device < 0 ? 0 : device) & 15); }
 void drop_edge_cache() {
-    EdgeCache *c = edge_cache();
-    *c = EdgeCache();                // the device structures go when the last Scene that shares them does
-    *topology_cache() = TopologyCache();
+    for (int d = 0; d < 16; ++d) {       // (rdr_trim_cache holds every device's lock)
+        *edge_cache(d) = EdgeCache();    // the device structures go when the last Scene that shares them does
+        *topology_cache(d) = TopologyCache();
+    }
     drop_gather_cache();
 }
 
@@ -368,7 +370,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
     // hierarchy (raytri.h), and it is rebuilt once its inner surface area has grown by more than 30 %.  RDR_BUILD_NO_REFIT: always build.
     // On the GPU build the hierarchy never exists on the host: bvh_gpu.cpp builds it from the caller's device arrays, or --
     // same connectivity as the last build -- refits a copy of that build's records (below, once the shape table is uploaded).
-    TopologyCache *topo_cache = topology_cache();                    // guarded by the API lock (capi.cpp)
+    TopologyCache *topo_cache = topology_cache(gpu_index);           // guarded by the device's API lock (capi.cpp)
     const bool refit_allowed = !(s.build_flags & RDR_BUILD_NO_REFIT);
     rt::BvhHost bvh_built;
     auto bvh_job = hostpool::run([&meshes, &bvh_built, &s, refit_allowed, topo_cache] {      // (joins in its destructor on an early exit)
@@ -461,7 +463,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         const bool sync_edges = (s.build_flags & RDR_BUILD_SYNC_EDGES) != 0;
         // Everything the edge structures are computed from (edges.cpp: compute_edge_data): if it equals what the previous
         // Scene's were computed from, that result -- finished or still in the builder's hands -- is this Scene's too.
-        EdgeCache *cache = edge_cache();                      // guarded by the API lock (capi.cpp)
+        EdgeCache *cache = edge_cache(gpu_index);             // guarded by the device's API lock (capi.cpp)
         const bool cache_allowed = !(s.build_flags & (RDR_BUILD_NO_EDGE_CACHE | RDR_BUILD_NO_REFIT));
         const bool hit = cache_allowed && cache->result.valid() && cache->gpu_index == s.gpu_index &&
                          cache->primary == s.use_primary_edges && cache->secondary == s.use_secondary_edges &&

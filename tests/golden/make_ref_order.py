@@ -2,7 +2,7 @@
 """The camera gradients of a case under a DEFINED accumulation order (build container; fixtures <case>_ref_order.npz).
 
 Two processes render the same case:
-  oracle1t   the reference's C++ core (oracle/_ref) with ONE visible processor (LD_PRELOAD oracle/_ref/one_core.so): its
+  oracle1t   the reference's C++ core (oracle/_ref) with ONE visible processor (LD_PRELOAD oracle/_ref/nprocs_shim.so): its
              parallel_for runs on the calling thread, so every fp32 atomic add (src/atomic.h:43-141) happens in a defined order --
              sample by sample, kernel by kernel, lane by lane;
   harness    the product's stage bodies on the CPU debugging harness (tests/hostsim), one sample per launch, one host thread,
@@ -25,7 +25,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
-ONE_CORE = os.path.join(ROOT, 'oracle', '_ref', 'one_core.so')
+ONE_CORE = os.path.join(ROOT, 'oracle', '_ref', 'nprocs_shim.so')
 HOSTSIM = os.path.join(ROOT, 'tests', 'hostsim', '_build', 'libredner_hostsim.so')
 CAM = ('grad_cam_position', 'grad_cam_look_at', 'grad_cam_up')
 
@@ -52,6 +52,7 @@ def run_leg(which, case, out):
     env = dict(os.environ, MALLOC_MMAP_THRESHOLD_='65536', MALLOC_PERTURB_='255')
     if which == 'oracle1t':
         env['LD_PRELOAD'] = ONE_CORE
+        env['ORACLE_NPROCS'] = '1'
     if which == 'harness32':
         env['RDR_HOSTSIM_REF_ORDER'] = '1'
     subprocess.check_call([sys.executable, os.path.abspath(__file__), '--leg', which, case, out], env=env)

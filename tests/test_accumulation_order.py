@@ -3,7 +3,7 @@ three numbers that collects 1.7e7 cancelling terms -- the camera position of bun
 4e-4 away from the exact sum of its own addends, and no striped re-summation of the oracle settles below 2.9e-4 (round 4 capped
 that one tensor's bar at 5e-4).  This file closes it instead of capping it:
 
-  * the oracle is run with ONE visible processor (oracle/one_core.c), which makes the order of its adds defined;
+  * the oracle is run with ONE visible processor (oracle/nprocs_shim.c), which makes the order of its adds defined;
   * the CPU debugging harness (the product's stage bodies) keeps, beside its fp64 accumulators, floats that take the same
     addends in the same order (RDR_HOSTSIM_REF_ORDER, tests/hostsim/exec.h);
   * those floats equal the one-thread oracle BIT FOR BIT -- so the harness' addends ARE the oracle's addends, and the distance

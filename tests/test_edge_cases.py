@@ -342,3 +342,32 @@ def test_nonfinite_written_through_data_is_caught_hostsim(hostsim_backend):
 @pytest.mark.gpu
 def test_nonfinite_written_through_data_is_caught_gpu(gpu_backend):
     _nonfinite_through_data(gpu_backend, torch.device('cuda:0'))
+
+
+@pytest.mark.gpu
+def test_two_host_threads_on_one_device_gpu(gpu_backend):
+    """ctypes releases the GIL: two Python threads may be inside rdr_render / rdr_scene_create at once.  Calls on ONE device are
+    serialised by that device's lock (csrc/capi.cpp; calls on different devices are not): the results of interleaved calls equal
+    the results of the same calls made one after the other."""
+    import threading
+    from golden.make_golden import render_case
+    dev = torch.device('cuda:0')
+    jobs = [('bunny_box', 48, 4, 4), ('two_triangles', 64, 4, 1)]
+    alone = [render_case(gpu_backend, *j, device=dev) for j in jobs]
+    got = [[], []]
+
+    def work(k):
+        for _ in range(3):
+            got[k].append(render_case(gpu_backend, *jobs[k], device=dev))
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(2):
+        assert len(got[k]) == 3
+        for out in got[k]:
+            assert np.array_equal(out['image'], alone[k]['image'])
+            for key, ref in alone[k].items():
+                n = np.linalg.norm(ref.astype(np.float64))
+                assert np.linalg.norm(out[key].astype(np.float64) - ref) <= 1e-6 * n + 1e-12, (k, key)
