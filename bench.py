@@ -186,7 +186,7 @@ def cpu_baseline(a, gpu_rd=None, gpu_dev=None):
     return {'value': rate, 'unit': 'Msamples/s', 'cores': threads, 'host_threads': os.cpu_count(), 'kind': 'reference', 'thread_sweep': sweep,
             'sample': '%s %dx%d, %d spp fwd+bwd, max_bounces %d, Sobol, best of %d passes (%.1f s); reference C++ core '
                       '(oracle/_ref) with the BVH Embree stand-in; the best of: all host threads on the two samples in `samples`, '
-                      'and 16 / 32 / 64 threads on the first (`thread_sweep`); `cores` = the threads of the best run'
+                      'and 8 / 16 / 32 / 64 threads on the first (`thread_sweep`); `cores` = the threads of the best run'
                       % (a.workload, res, res, spp, a.max_bounces, reps, dt),
             'samples': lines, 'gpu_vs_reference': check}
 
@@ -208,9 +208,9 @@ def cpu_baseline_leg(a):
                       'seconds_per_pass': times}), flush=True)
 
 
-def cpu_thread_sweep(a, counts=(16, 32, 64)):
+def cpu_thread_sweep(a, counts=(8, 16, 32, 64)):
     """The reference starts hardware_concurrency() - 1 workers per call (src/parallel.cpp:228-255); on a 256-thread host that is
-    not its best configuration for a frame this size.  The same sample on 16 / 32 / 64 threads (oracle/nprocs_shim.c), each leg
+    not its best configuration for a frame this size.  The same sample on 8 / 16 / 32 / 64 threads (oracle/nprocs_shim.c), each leg
     its own process; cpu_baseline reports the best of these and the all-threads run."""
     shim = os.path.join(ROOT, 'oracle', '_ref', 'nprocs_shim.so')
     if not os.path.exists(shim):
