@@ -28,10 +28,19 @@ RDR_FN uint64_t hash64shift(uint64_t key) {
 
 RDR_FN uint64_t sobol_scramble(uint64_t seed, int slot) { return hash64shift((seed << 32) | (uint64_t)slot); }
 
+// The XOR over the set bits of the sample index (src/sobol_sampler.cpp:62-76).  The eight direction numbers of the low byte are
+// loaded TOGETHER and unconditionally and masked by their bit -- the same XORs in the same order; the reference-shaped loop (a
+// conditional load per set bit, each waited for before the next) cost a kernel 4 dependent L2 round trips per number and 7
+// numbers per bounce.  Sample indices above 255 take the loop for their remaining bits.
 RDR_FN double sobol_value(const uint64_t *matrices, uint64_t index, uint32_t dim, uint64_t scramble) {
     uint64_t r = scramble & ~-(1ULL << kSobolBits);
-    for (uint32_t i = dim * kSobolBits; index; index >>= 1, ++i)
-        if (index & 1) r ^= matrices[i];
+    const uint64_t *m = matrices + (size_t)dim * kSobolBits;
+    uint64_t w[8];
+    for (int k = 0; k < 8; ++k) w[k] = m[k];
+    for (int k = 0; k < 8; ++k) r ^= w[k] & (0ULL - ((index >> k) & 1ULL));
+    index >>= 8;
+    for (uint32_t i = 8; index; index >>= 1, ++i)
+        if (index & 1) r ^= m[i];
     return r * (1.0 / (1ULL << kSobolBits));
 }
 
@@ -87,8 +96,15 @@ struct SamplerD {
     const int *dyn = nullptr;
     int batch = 0, batch_lanes = 0;
     const int *seg = nullptr;
-    RDR_FN double draw(int slot, int dim) const {
-        if (pcg_state) return pcg_output_double(pcg_advance(pcg_state[slot], pcg_inc(slot), (uint32_t)(dim - pcg_base)));
+    // What a slot's numbers share -- which sample of the batch the slot belongs to, its scramble, the dynamic part of its
+    // dimension counter: resolved ONCE per lane (`lane(slot)`), then every number of the lane is one `draw(lane, dim)`.  (A
+    // stage draws 2 ... 7 numbers per lane; resolving per number repeated an integer division, the 64-bit hash and the segment
+    // search each time.)
+    struct Lane { uint64_t index, scramble; int slot, dyn; };
+    RDR_FN Lane lane(int slot) const {
+        Lane l;
+        l.slot = slot; l.index = 0; l.scramble = 0; l.dyn = 0;
+        if (pcg_state) return l;
         int s = 0;
         if (seg) {
             for (int k = 1; k < batch; ++k) if (slot >= seg[k]) s = k;
@@ -97,8 +113,16 @@ struct SamplerD {
             s = slot / batch_lanes;
             slot -= s * batch_lanes;
         }
-        return sobol_value(matrices, (uint64_t)(sample_id + s), (uint32_t)(dim + (dyn ? dyn[s] : 0)), sobol_scramble(seed, slot));
+        l.index = (uint64_t)(sample_id + s);
+        l.scramble = sobol_scramble(seed, slot);
+        l.dyn = dyn ? dyn[s] : 0;
+        return l;
     }
+    RDR_FN double draw(const Lane &l, int dim) const {
+        if (pcg_state) return pcg_output_double(pcg_advance(pcg_state[l.slot], pcg_inc(l.slot), (uint32_t)(dim - pcg_base)));
+        return sobol_value(matrices, l.index, (uint32_t)(dim + l.dyn), l.scramble);
+    }
+    RDR_FN double draw(int slot, int dim) const { return draw(lane(slot), dim); }
 };
 
 // Host-launched maintenance of the PCG states.

@@ -398,7 +398,8 @@ struct AdjPrimary {
             DRay mr_bar = dray_zero();
             RayDiff mrd_bar = raydiff_zero();
             adj_envmap_eval(*sc.envmap, ray.dir, rd, e_bar, g.envmap, mr_bar.dir, mrd_bar);
-            V2 ms = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
+            V2 ms = v2(0.5, 0.5);
+            if (!sample_center) { const SamplerD::Lane ln = rng.lane(p); ms = v2(rng.draw(ln, 0), rng.draw(ln, 1)); }
             V2 mscr_bar = v2(0, 0);
             RDR_INLINE_CALL adj_primary_ray(sc.cam, pixel_to_screen(sc.cam, p, ms), mr_bar, g.cam, screen_grad != nullptr, mscr_bar);
             if (screen_grad) { screen_grad[2 * p] += (float)mscr_bar.x; screen_grad[2 * p + 1] += (float)mscr_bar.y; }
@@ -417,7 +418,8 @@ struct AdjPrimary {
             adj_surf_at(sc.shapes[shape], v0.tri[p], ray, rd, pt_bar, raydiff_zero(), r_bar, prd_bar, tg, !sc.no_diffs, sc.plain_materials != 0);
             tg_shape = shape; tg_tri = v0.tri[p];
         }
-        V2 s = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
+        V2 s = v2(0.5, 0.5);
+        if (!sample_center) { const SamplerD::Lane ln = rng.lane(p); s = v2(rng.draw(ln, 0), rng.draw(ln, 1)); }
         V2 screen = pixel_to_screen(sc.cam, p, s);
         double delta = 1e-3;
         double sx = 0.5 / sc.cam.width, sy = 0.5 / sc.cam.height;

@@ -156,7 +156,8 @@ struct SamplePrimaryEdges {
             v.shape[l] = -1; v.tri[l] = -1;
             v.mrough[l] = 0;
         }
-        double edge_sel = rng.draw(slot, dim), t = rng.draw(slot, dim + 1);
+        const SamplerD::Lane ln = rng.lane(slot);
+        double edge_sel = rng.draw(ln, dim), t = rng.draw(ln, dim + 1);
         int eid = iclamp(upper_bound_idx(es.primary_cdf, es.num_edges, edge_sel) - 1, 0, es.num_edges - 1);
         const EdgeD &edge = es.edges[eid];
         V3 a = edge_v0(sc.shapes, edge), b = edge_v1(sc.shapes, edge);
@@ -738,8 +739,9 @@ RDR_FN SecPre sec_prepare(const SceneD &sc, const EdgeSceneD &es, const SamplerD
     } else if (sc.envmap != nullptr) {
         s.nee = make_ray(s.c.sp.position, envmap_sample(*sc.envmap, ld.uv));     // tmax = inf (:1381-1385)
     }
-    s.edge_sel = rng_edge.draw(idx, dim_edge); s.resample_sel = rng_edge.draw(idx, dim_edge + 1);
-    s.bsdf_comp = rng_edge.draw(idx, dim_edge + 2); s.t_sel = rng_edge.draw(idx, dim_edge + 3);
+    const SamplerD::Lane eln = rng_edge.lane(idx);
+    s.edge_sel = rng_edge.draw(eln, dim_edge); s.resample_sel = rng_edge.draw(eln, dim_edge + 1);
+    s.bsdf_comp = rng_edge.draw(eln, dim_edge + 2); s.t_sel = rng_edge.draw(eln, dim_edge + 3);
     const MaterialD &mat = *s.c.mat;
     V3 kd = tex3(mat.diffuse, s.c.sp), ks = tex3(mat.specular, s.c.sp);
     double wd = luminance(kd), ws = luminance(ks), wsum = wd + ws;

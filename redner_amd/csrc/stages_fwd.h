@@ -162,9 +162,10 @@ template <class Walk> struct MidWalk {
 };
 
 struct LightDraw { double light_sel, tri_sel; V2 uv; };
-RDR_FN LightDraw draw_light(const SamplerD &rng, int slot, int dim) {
-    return LightDraw{rng.draw(slot, dim), rng.draw(slot, dim + 1), v2(rng.draw(slot, dim + 2), rng.draw(slot, dim + 3))};
+RDR_FN LightDraw draw_light(const SamplerD &rng, const SamplerD::Lane &ln, int dim) {
+    return LightDraw{rng.draw(ln, dim), rng.draw(ln, dim + 1), v2(rng.draw(ln, dim + 2), rng.draw(ln, dim + 3))};
 }
+RDR_FN LightDraw draw_light(const SamplerD &rng, int slot, int dim) { return draw_light(rng, rng.lane(slot), dim); }
 
 // ---- stage: camera rays -------------------------------------------------------------------------
 struct GenPrimary {
@@ -173,7 +174,8 @@ struct GenPrimary {
     RDR_FN void make_lean() { lean_scene(sc); lean_slice(v0); }
     RDR_FN void make_mid() { mid_scene(sc); }
     RDR_FN void operator()(int p) const {
-        V2 s = sample_center ? v2(0.5, 0.5) : v2(rng.draw(p, 0), rng.draw(p, 1));
+        V2 s = v2(0.5, 0.5);
+        if (!sample_center) { const SamplerD::Lane ln = rng.lane(p); s = v2(rng.draw(ln, 0), rng.draw(ln, 1)); }
         RayDiff rd = raydiff_zero();
         Ray r = sc.no_diffs ? primary_ray(sc.cam, pixel_to_screen(sc.cam, p, s))
                             : primary_ray_with_diff(sc.cam, pixel_to_screen(sc.cam, p, s), rd);
@@ -353,8 +355,9 @@ struct BounceSample {
     // the bounce of lane p from its vertex `c`; the two rays go to queue slot idx
     RDR_FN void sample_from(const VertexCtx &c, int p, int idx) const {
         int slot = p >> rng_shift;
+        const SamplerD::Lane ln = rng.lane(slot);            // the lane's seven numbers share this
         // next-event estimation ray
-        LightDraw ld = draw_light(rng, slot, dim);
+        LightDraw ld = draw_light(rng, ln, dim);
         LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
         if (pk.shape_id >= 0) {
             const ShapeD &lsh = sc.shapes[pk.shape_id];
@@ -388,8 +391,8 @@ struct BounceSample {
             put_ray(q_nee, idx, dead, true);
         }
         // BSDF ray
-        V2 buv = v2(rng.draw(slot, dim + 4), rng.draw(slot, dim + 5));
-        double bw = rng.draw(slot, dim + 6);
+        V2 buv = v2(rng.draw(ln, dim + 4), rng.draw(ln, dim + 5));
+        double bw = rng.draw(ln, dim + 6);
         // a sampler that bails out (one-sided surface seen from behind) leaves the differential untouched
         RayDiff wo_rd = vn.erd ? ld_erd(vn, p) : raydiff_zero();
         double next_mr;
