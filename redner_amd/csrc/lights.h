@@ -10,6 +10,13 @@ namespace rdr {
 
 // index of the first element > v  (thrust::upper_bound semantics)
 RDR_FN int upper_bound_idx(const double *a, int n, double v) {
+    if (n <= 4) {
+        // short tables -- a scene's lights, the two triangles of a quad light: every entry is loaded at once and the entries that
+        // are not above v are counted (the table is non-decreasing, so that count IS the index of the first entry above v; a NaN
+        // compares like the search does): no dependent load per halving step
+        const double a0 = n > 0 ? a[0] : 0, a1 = n > 1 ? a[1] : 0, a2 = n > 2 ? a[2] : 0, a3 = n > 3 ? a[3] : 0;
+        return (n > 0 && !(v < a0) ? 1 : 0) + (n > 1 && !(v < a1) ? 1 : 0) + (n > 2 && !(v < a2) ? 1 : 0) + (n > 3 && !(v < a3) ? 1 : 0);
+    }
     int lo = 0, hi = n;
     while (lo < hi) {
         int mid = (lo + hi) >> 1;
