@@ -145,7 +145,7 @@ RDR_FN double tex1(const TexD &tex, const Surf &sp) {
 }
 RDR_FN void adj_tex3(const TexD &tex, const Surf &sp, V3 o_bar, const GTex &g, Surf &sp_bar) {
     if (sp.plain) {
-        if (g.texels[0]) { accum(g.texels[0] + 0, o_bar.x); accum(g.texels[0] + 1, o_bar.y); accum(g.texels[0] + 2, o_bar.z); }
+        if (g.texels[0]) accum3(g.texels[0], o_bar);
         return;
     }
     double ob[3] = {o_bar.x, o_bar.y, o_bar.z};

@@ -211,7 +211,7 @@ RDR_FN void scatter_cam_to_world(const CameraD &cam, const M4 &c2w_bar, const GC
 RDR_FN void accum_outer3(double *g, V3 a, V3 b, int rows) {          // g[r][c] += a[r] * b[c]
     if (!g) return;
     double av[3] = {a.x, a.y, a.z}, bv[3] = {b.x, b.y, b.z};
-    _Pragma("unroll") for (int r = 0; r < 3; ++r) { if (r < rows) { _Pragma("unroll") for (int c = 0; c < 3; ++c) accum(g + 3 * r + c, av[r] * bv[c]); } }
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) { if (r < rows) accum_triple(g + 3 * r, av[r] * bv[0], av[r] * bv[1], av[r] * bv[2]); }      // a row: one search
 }
 // Tail shared by every camera model: undo the lens distortion on the way back to the screen position.
 RDR_FN void adj_screen_tail(const CameraD &cam, V2 screen, V2 distorted_bar, const GCamera &g, bool want, V2 &screen_bar) {

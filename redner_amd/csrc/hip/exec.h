@@ -141,6 +141,45 @@ __device__ inline void accum_rounds(double *p, double v, int ROUNDS) {
     }
     if (mine) global_add_f64(p, v);
 }
+// Three consecutive accumulators (a colour, a position): the lanes that share p also share p + 1 and p + 2, so the search for
+// them is done ONCE for the triple (accum() three times repeated it per component: ~25 instructions per round and component).
+__device__ inline void accum_triple(double *p, double x, double y, double z) {
+    p = replica_of(p);
+    const unsigned long long act = __ballot(1);
+    const unsigned long long addr = (unsigned long long)p;
+    const int lane = threadIdx.x & 63;
+    unsigned long long rem = act;
+    bool mine = true;
+    for (int round = 0; round < kAccumRounds && rem != 0; ++round) {      // wave-uniform trip count
+        const int l = __ffsll((long long)rem) - 1;
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)addr, l);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)(addr >> 32), l);
+        const bool same = addr == (((unsigned long long)hi << 32) | lo);
+        const unsigned long long m = __ballot(same) & rem;
+        rem &= ~m;
+        if (__popcll(m) < 2) continue;        // a lone lane adds for itself below
+        double sx, sy, sz;
+        if (act == ~0ull) {
+            sx = wave_sum(same ? x : 0.0); sy = wave_sum(same ? y : 0.0); sz = wave_sum(same ? z : 0.0);
+        } else {
+            sx = sy = sz = 0;
+            const int xlo = __double2loint(x), xhi = __double2hiint(x), ylo = __double2loint(y), yhi = __double2hiint(y);
+            const int zlo = __double2loint(z), zhi = __double2hiint(z);
+            unsigned long long mm = m;
+            while (mm) {
+                const int k = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                sx += __hiloint2double(__builtin_amdgcn_readlane(xhi, k), __builtin_amdgcn_readlane(xlo, k));
+                sy += __hiloint2double(__builtin_amdgcn_readlane(yhi, k), __builtin_amdgcn_readlane(ylo, k));
+                sz += __hiloint2double(__builtin_amdgcn_readlane(zhi, k), __builtin_amdgcn_readlane(zlo, k));
+            }
+        }
+        if (lane == l) { global_add_f64(p, sx); global_add_f64(p + 1, sy); global_add_f64(p + 2, sz); }
+        if (same) mine = false;
+    }
+    if (mine) { global_add_f64(p, x); global_add_f64(p + 1, y); global_add_f64(p + 2, z); }
+}
+__host__ inline void accum_triple(double *p, double x, double y, double z) { p[0] += x; p[1] += y; p[2] += z; }
 __host__ inline void accum(double *p, double v) { *p += v; }   // host instantiation is never executed
 __host__ inline void accum_texel(double *p, double v) { *p += v; }
 // The same add without the search for lanes that share the address: for per-vertex / per-texel data of large meshes the lanes

@@ -558,21 +558,21 @@ RDR_FN void scatter_trigrad_wave(const ShapeD *shapes, const GShape *gshapes, in
             for (int k = 0; k < 3; ++k) {
                 V3 p = g.p[k];
                 RDR_WSUM(p.x) RDR_WSUM(p.y) RDR_WSUM(p.z)
-                if (lead) accum3(gv + 3 * vi[k], p);
+                if (lead) accum3_plain(gv + 3 * vi[k], p);      // ONE lane is here: nothing to search for (accum3 would)
                 if (any_n) {
                     V3 n = g.n[k];
                     RDR_WSUM(n.x) RDR_WSUM(n.y) RDR_WSUM(n.z)
-                    if (lead && has_n) accum3(gn + 3 * ni[k], n);
+                    if (lead && has_n) accum3_plain(gn + 3 * ni[k], n);
                 }
                 if (any_uv) {
                     V2 t = g.uv[k];
                     RDR_WSUM(t.x) RDR_WSUM(t.y)
-                    if (lead && has_uv) { accum(gu + 2 * ui[k], t.x); accum(gu + 2 * ui[k] + 1, t.y); }
+                    if (lead && has_uv) { accum_plain(gu + 2 * ui[k], t.x); accum_plain(gu + 2 * ui[k] + 1, t.y); }
                 }
                 if (any_c) {
                     V3 c = g.c[k];
                     RDR_WSUM(c.x) RDR_WSUM(c.y) RDR_WSUM(c.z)
-                    if (lead && has_c) accum3(gc + 3 * vi[k], c);
+                    if (lead && has_c) accum3_plain(gc + 3 * vi[k], c);
                 }
             }
 #undef RDR_WSUM
@@ -612,7 +612,7 @@ RDR_FN void scatter_positions_wave(const ShapeD *shapes, const GShape *gshapes, 
             for (int k = 0; k < 3; ++k) {
                 V3 p = in ? pb[k] : V3{0.0, 0.0, 0.0};
                 p.x = wave_sum(p.x); p.y = wave_sum(p.y); p.z = wave_sum(p.z);
-                if (lead) accum3(gv + 3 * vi[k], p);
+                if (lead) accum3_plain(gv + 3 * vi[k], p);
             }
         }
         if (handled) return;

@@ -103,7 +103,7 @@ RDR_FN double dmax(double a, double b) { return a > b ? a : b; }
 RDR_FN double dmin(double a, double b) { return a < b ? a : b; }
 RDR_FN int iclamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 RDR_FN double sq(double x) { return x * x; }
-RDR_FN void accum3(double *p, V3 v) { accum(p, v.x); accum(p + 1, v.y); accum(p + 2, v.z); }
+RDR_FN void accum3(double *p, V3 v) { accum_triple(p, v.x, v.y, v.z); }      // one search for the lanes that share the triple (exec.h)
 RDR_FN void accum3_plain(double *p, V3 v) { accum_plain(p, v.x); accum_plain(p + 1, v.y); accum_plain(p + 2, v.z); }
 
 // normalize(0) == 0 (src/vector.h:448-457)
