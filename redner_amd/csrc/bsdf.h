@@ -83,11 +83,32 @@ RDR_FN void adj_bilerp(const TexD &tex, double *const *gtexels, int li, V2 uv, i
     v_bar += o_bar * (-f00 * (1.f - b.u) + -f10 * b.u + f01 * (1.f - b.u) + f11 * b.u);
 }
 
+// The same for the three channels of an rgb texture at once: the four corner texels are triples, so the lanes of the wave that
+// share a corner are looked for ONCE per corner (accum_texel_triple) instead of once per corner and channel; u_bar / v_bar
+// receive the channels' terms in channel order, like three adj_bilerp calls.
+RDR_FN void adj_bilerp_rgb(const TexD &tex, double *const *gtexels, int li, V2 uv, const double o_bar[3], double &u_bar, double &v_bar) {
+    Bilerp b = bilerp_setup(tex, li, uv);
+    const float *tx = tex.texels[li];
+    double *g = gtexels[li];
+    if (g) {
+        // (the products are formed as adj_bilerp forms them: (o_bar * wu) * wv)
+        accum_texel_triple(g + 3 * b.i00, o_bar[0] * (1.f - b.u) * (1.f - b.v), o_bar[1] * (1.f - b.u) * (1.f - b.v), o_bar[2] * (1.f - b.u) * (1.f - b.v));
+        accum_texel_triple(g + 3 * b.i10, o_bar[0] * b.u * (1.f - b.v), o_bar[1] * b.u * (1.f - b.v), o_bar[2] * b.u * (1.f - b.v));
+        accum_texel_triple(g + 3 * b.i01, o_bar[0] * (1.f - b.u) * b.v, o_bar[1] * (1.f - b.u) * b.v, o_bar[2] * (1.f - b.u) * b.v);
+        accum_texel_triple(g + 3 * b.i11, o_bar[0] * b.u * b.v, o_bar[1] * b.u * b.v, o_bar[2] * b.u * b.v);
+    }
+    for (int c = 0; c < 3; ++c) {
+        double f00 = tx[3 * b.i00 + c], f10 = tx[3 * b.i10 + c], f01 = tx[3 * b.i01 + c], f11 = tx[3 * b.i11 + c];
+        u_bar += o_bar[c] * (-f00 * (1.f - b.v) + f10 * (1.f - b.v) + -f01 * b.v + f11 * b.v);
+        v_bar += o_bar[c] * (-f00 * (1.f - b.u) + -f10 * b.u + f01 * (1.f - b.u) + f11 * b.u);
+    }
+}
+
 RDR_FN void adj_tex_fetch(const TexD &tex, V2 uv_, V2 du_, V2 dv_, const double *o_bar, const GTex &g,
                           V2 &uv_bar_, V2 &du_bar_, V2 &dv_bar_) {
     int ch = tex.channels;
     if (tex.width[0] <= 0 && tex.height[0] <= 0) {
-        if (g.texels[0]) for (int c = 0; c < ch; ++c) accum(g.texels[0] + c, o_bar[c]);
+        if (g.texels[0]) { if (ch == 3) accum_triple(g.texels[0], o_bar[0], o_bar[1], o_bar[2]); else for (int c = 0; c < ch; ++c) accum(g.texels[0] + c, o_bar[c]); }
         return;
     }
     V2 sc = v2(tex.uv_scale[0], tex.uv_scale[1]);
@@ -101,7 +122,8 @@ RDR_FN void adj_tex_fetch(const TexD &tex, V2 uv_, V2 du_, V2 dv_, const double 
     if (level <= 0 || level >= tex.num_levels - 1) {
         int li = level <= 0 ? 0 : tex.num_levels - 1;
         double ub = 0, vb = 0;
-        for (int c = 0; c < ch; ++c) adj_bilerp(tex, g.texels, li, uv, ch, c, o_bar[c], ub, vb);
+        if (ch == 3) adj_bilerp_rgb(tex, g.texels, li, uv, o_bar, ub, vb);
+        else for (int c = 0; c < ch; ++c) adj_bilerp(tex, g.texels, li, uv, ch, c, o_bar[c], ub, vb);
         uv_bar.x += ub * tex.width[li]; uv_bar.y += vb * tex.height[li];
     } else {
         int li = (int)floor(level);
@@ -112,8 +134,15 @@ RDR_FN void adj_tex_fetch(const TexD &tex, V2 uv_, V2 du_, V2 dv_, const double 
             double a0 = bilerp_eval(tex.texels[li], ch, c, b0);
             double a1 = bilerp_eval(tex.texels[li + 1], ch, c, b1);
             level_bar += o_bar[c] * (a1 - a0);
+            if (ch == 3) continue;
             adj_bilerp(tex, g.texels, li, uv, ch, c, o_bar[c] * (1 - ld), u0b, v0b);
             adj_bilerp(tex, g.texels, li + 1, uv, ch, c, o_bar[c] * ld, u1b, v1b);
+        }
+        if (ch == 3) {          // (the two levels have separate accumulators: per level the channels still arrive in order)
+            const double lo_bar[3] = {o_bar[0] * (1 - ld), o_bar[1] * (1 - ld), o_bar[2] * (1 - ld)};
+            const double hi_bar[3] = {o_bar[0] * ld, o_bar[1] * ld, o_bar[2] * ld};
+            adj_bilerp_rgb(tex, g.texels, li, uv, lo_bar, u0b, v0b);
+            adj_bilerp_rgb(tex, g.texels, li + 1, uv, hi_bar, u1b, v1b);
         }
         uv_bar.x += u1b * tex.width[li + 1]; uv_bar.y += v1b * tex.height[li + 1];
         uv_bar.x += u0b * tex.width[li]; uv_bar.y += v0b * tex.height[li];

@@ -143,14 +143,14 @@ __device__ inline void accum_rounds(double *p, double v, int ROUNDS) {
 }
 // Three consecutive accumulators (a colour, a position): the lanes that share p also share p + 1 and p + 2, so the search for
 // them is done ONCE for the triple (accum() three times repeated it per component: ~25 instructions per round and component).
-__device__ inline void accum_triple(double *p, double x, double y, double z) {
+__device__ inline void accum_triple_rounds(double *p, double x, double y, double z, int ROUNDS) {
     p = replica_of(p);
     const unsigned long long act = __ballot(1);
     const unsigned long long addr = (unsigned long long)p;
     const int lane = threadIdx.x & 63;
     unsigned long long rem = act;
     bool mine = true;
-    for (int round = 0; round < kAccumRounds && rem != 0; ++round) {      // wave-uniform trip count
+    for (int round = 0; round < ROUNDS && rem != 0; ++round) {      // wave-uniform trip count
         const int l = __ffsll((long long)rem) - 1;
         const unsigned lo = __builtin_amdgcn_readlane((unsigned)addr, l);
         const unsigned hi = __builtin_amdgcn_readlane((unsigned)(addr >> 32), l);
@@ -179,7 +179,10 @@ __device__ inline void accum_triple(double *p, double x, double y, double z) {
     }
     if (mine) { global_add_f64(p, x); global_add_f64(p + 1, y); global_add_f64(p + 2, z); }
 }
+__device__ inline void accum_triple(double *p, double x, double y, double z) { accum_triple_rounds(p, x, y, z, kAccumRounds); }
+__device__ inline void accum_texel_triple(double *p, double x, double y, double z) { accum_triple_rounds(p, x, y, z, g_texel_rounds); }      // an rgb texel
 __host__ inline void accum_triple(double *p, double x, double y, double z) { p[0] += x; p[1] += y; p[2] += z; }
+__host__ inline void accum_texel_triple(double *p, double x, double y, double z) { p[0] += x; p[1] += y; p[2] += z; }
 __host__ inline void accum(double *p, double v) { *p += v; }   // host instantiation is never executed
 __host__ inline void accum_texel(double *p, double v) { *p += v; }
 // The same add without the search for lanes that share the address: for per-vertex / per-texel data of large meshes the lanes

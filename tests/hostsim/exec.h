@@ -38,6 +38,7 @@ inline void shadow_add(double *p, double v) {
 inline void accum(double *p, double v) { *p += v; shadow_add(p, v); }
 inline void accum_plain(double *p, double v) { *p += v; shadow_add(p, v); }
 inline void accum_triple(double *p, double x, double y, double z) { p[0] += x; shadow_add(p, x); p[1] += y; shadow_add(p + 1, y); p[2] += z; shadow_add(p + 2, z); }
+inline void accum_texel_triple(double *p, double x, double y, double z) { accum_triple(p, x, y, z); }
 inline void accum_texel(double *p, double v) { *p += v; shadow_add(p, v); }
 inline void atomic_add_f64(double *p, double v) { *p += v; }
 inline int atomic_fetch_add(int *p, int v) { int o = *p; *p += v; return o; }
