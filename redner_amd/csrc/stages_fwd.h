@@ -505,14 +505,16 @@ struct BounceContrib {
     // from it without the reload
     RDR_FN bool contrib(int p, int idx, VertexCtx &next) const {
         int slot = p >> rng_shift;
+        // both query results are fetched with the lane's first loads (further down they would wait behind the branches of the
+        // light pick: the compiler does not move a load across a branch)
+        const rt::HitRec hn = h_nee[idx], hb = h_bsdf[idx];
         VertexCtx c = load_vertex(sc, v, p);
         LightDraw ld = draw_light(rng, slot, dim);
         LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
         Surf lp = surf_zero();
         if (pk.shape_id >= 0) lp = sample_tri(sc.shapes[pk.shape_id], pk.tri_id, ld.uv);
-        bool blocked = h_nee[idx].shape >= 0;
+        bool blocked = hn.shape >= 0;
         if (v.occl) v.occl[p] = blocked ? 1 : 0;
-        rt::HitRec hb = h_bsdf[idx];
         vn.shape[p] = hb.shape; vn.tri[p] = hb.shape >= 0 ? hb.prim : -1;
         Surf bp = surf_zero();
         if (hb.shape >= 0) {
