@@ -508,6 +508,7 @@ struct BounceContrib {
         // both query results are fetched with the lane's first loads (further down they would wait behind the branches of the
         // light pick: the compiler does not move a load across a branch)
         const rt::HitRec hn = h_nee[idx], hb = h_bsdf[idx];
+        const V3 thr = ld3(v.thr, v.n, p, 0);
         VertexCtx c = load_vertex(sc, v, p);
         LightDraw ld = draw_light(rng, slot, dim);
         LightPick pk = pick_light(sc, ld.light_sel, ld.tri_sel);
@@ -530,7 +531,6 @@ struct BounceContrib {
             next.wi = -next.ray.dir;
             next.mrough = vn.mrough[p];
         }
-        V3 thr = ld3(v.thr, v.n, p, 0);
         BounceEval e = eval_bounce(sc, c, thr, !blocked, pk, lp, ld.uv, hb.shape, bp, load_ray(vn, p).dir);
         if (e.next_thr_valid) st3(vn.thr, vn.n, p, 0, e.next_thr);
         V3 pc = thr * (e.nee + e.scatter);
