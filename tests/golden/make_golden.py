@@ -82,6 +82,8 @@ EDGE_SAFE_CHANNELS = [c for c in ALL_CHANNELS if c not in ('barycentric_coordina
 CASES = {
     'single_triangle_64x64x4': ('single_triangle', 64, 4, 1),
     'two_triangles_64x64x16': ('two_triangles', 64, 16, 1),
+    # sample indices above 255: the Sobol' XOR takes its loop for the bits beyond the low byte (csrc/sobol.h: sobol_value)
+    'single_triangle_hi_index_12x12x320': ('single_triangle', 12, 320, 1),
     'bunny_box_32x32x4': ('bunny_box', 32, 4, 4),
     # big enough that every scheduling feature of the GPU build is on: side streams, the second sample worker (8 spp),
     # wave-summed gradient scatters
