@@ -561,7 +561,9 @@ struct Backward {
             else passes(std::integral_constant<int, 64>{});
         }
         const int only_overflow = gather ? 1 : 0;
+        const int *walk_needed = gather ? &gshared.book->walk_needed : nullptr;
         auto go = [&](auto walk) {
+            walk.walk_needed = walk_needed;
             if (LEAN == kLean) exec::launch_persistent(nN, LeanWalk<decltype(walk)>{walk});
             else if (LEAN == kMid) exec::launch_persistent(nN, MidWalk<decltype(walk)>{walk});
             else exec::launch_persistent(nN, walk);

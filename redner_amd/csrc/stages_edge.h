@@ -852,6 +852,8 @@ constexpr int kPickOverflow = -2;     // SecPick::eid of a slot the gather hands
 template <int NS> struct SecEdgePickNWalk {
     SecEdgeArgs a; const int *slots; SecPick *picks;
     int only_overflow;          // 1: walk only the slots SecEdgeGatherN marked kPickOverflow, leave the others alone
+    const int *walk_needed = nullptr;      // (with only_overflow) GatherBook::walk_needed: 0 = no slot kept the mark
+    RDR_DEV_FN bool gate_closed() const { return only_overflow && walk_needed && *walk_needed == 0; }
     struct State {
         int idx, sp, selected;
         double edge_w, wsum, resample;
@@ -973,6 +975,7 @@ constexpr int kGatherBudget = 256, kGatherCandsBig = 256, kGatherHeavyCap = 8192
 struct GatherWork { int heavy, entry; };
 struct GatherBook {                 // zeroed before every SecEdgeGatherN launch
     int heavy_count, work_count;
+    int walk_needed;                // some slot keeps its kPickOverflow mark: SecEdgePickNWalk has work (else it returns at once)
     int cand_count[kGatherHeavyCap];
 };
 // heavy_cap / work_cap: how much of the (kGatherHeavyCap / kGatherWorkCap sized) lists may be used -- the full size, or less
@@ -1100,6 +1103,7 @@ template <int NS> struct SecEdgeGatherN {
         auto promote = [&]() {              // this slot continues in the big lists
             heavy = atomic_fetch_add(&sh.book->heavy_count, 1);
             if (heavy < sh.heavy_cap) sh.heavy_slot[heavy] = i;
+            else sh.book->walk_needed = 1;                 // no room in the big lists: the mark stays, the walk takes the slot
             for (int k = 0; k < ncand; ++k) gather_append_big(sh, heavy, mine[k]);
         };
         auto emit = [&](const GatherCand &cd) {
@@ -1118,6 +1122,7 @@ template <int NS> struct SecEdgeGatherN {
                 else lost = true;
             }
             if (lost && heavy < sh.heavy_cap) atomic_fetch_add(&sh.book->cand_count[heavy], kGatherPoison);
+            if (lost) sh.book->walk_needed = 1;
         }
         exec::gather_stats_add(h_nodes, h_edges % 1000000, ncand, (int)(h_edges / 1000000));      // (harness statistics; nothing on the GPU)
         if (heavy >= 0) { picks[idx] = SecPick{kPickOverflow, 0.0, v3(0), v3(0)}; return; }
@@ -1151,7 +1156,7 @@ struct SecEdgeGatherReplay {
         const int n_heavy = sh.book->heavy_count < sh.heavy_cap ? sh.book->heavy_count : sh.heavy_cap;
         if (h >= n_heavy) return;
         const int n = sh.book->cand_count[h];
-        if (n < 0 || n > kGatherCandsBig) return;          // stays kPickOverflow: SecEdgePickNWalk takes it
+        if (n < 0 || n > kGatherCandsBig) { sh.book->walk_needed = 1; return; }          // stays kPickOverflow: SecEdgePickNWalk takes it
         const int idx = slots[sh.heavy_slot[h]];
         SecPre s = sec_prepare(a.sc, a.es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
         picks[idx] = gather_replay(a, idx, sh.cands_big + (size_t)h * kGatherCandsBig, n, s.resample_sel);

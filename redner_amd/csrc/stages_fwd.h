@@ -152,6 +152,7 @@ template <class Walk> struct LeanWalk {
     RDR_DEV_FN bool begin(int i, State &st) const { Walk g = w; g.make_lean(); return g.begin(i, st); }
     RDR_DEV_FN bool step(State &st) const { Walk g = w; g.make_lean(); return g.step(st); }
     RDR_DEV_FN void finish(State &st) const { Walk g = w; g.make_lean(); g.finish(st); }
+    RDR_DEV_FN bool gate_closed() const { return w.gate_closed(); }
 };
 template <class Walk> struct MidWalk {
     Walk w;
@@ -159,6 +160,7 @@ template <class Walk> struct MidWalk {
     RDR_DEV_FN bool begin(int i, State &st) const { Walk g = w; g.make_mid(); return g.begin(i, st); }
     RDR_DEV_FN bool step(State &st) const { Walk g = w; g.make_mid(); return g.step(st); }
     RDR_DEV_FN void finish(State &st) const { Walk g = w; g.make_mid(); g.finish(st); }
+    RDR_DEV_FN bool gate_closed() const { return w.gate_closed(); }
 };
 
 struct LightDraw { double light_sel, tri_sel; V2 uv; };
