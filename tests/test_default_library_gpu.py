@@ -58,3 +58,16 @@ def test_default_build_against_the_fixtures(tmp_path):
         else:
             assert e['image_identical'], (name, e)
         assert not e['failed'] and e['worst'] < 1e-4, (name, e)
+
+
+@pytest.mark.gpu
+def test_both_builds_load_side_by_side():
+    """The default build next to the exact one this process renders with: both are in-tree products of one source
+    (include/redner_amd.h: rdr_libm_exact tells them apart)."""
+    import ctypes
+    from redner_amd import _capi
+    assert os.path.exists(_capi.DEFAULT_LIBRARY) and os.path.exists(_capi.EXACT_LIBRARY)
+    fast, exact = ctypes.CDLL(_capi.DEFAULT_LIBRARY), ctypes.CDLL(_capi.EXACT_LIBRARY)
+    assert fast.rdr_libm_exact() == 0 and exact.rdr_libm_exact() == 1
+    ch = (ctypes.c_int * 2)(0, 3)              # radiance + position
+    assert fast.rdr_compute_num_channels(ch, 2, 0) == exact.rdr_compute_num_channels(ch, 2, 0) == 6
