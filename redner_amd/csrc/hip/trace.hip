@@ -274,6 +274,17 @@ constexpr int kTopNodes = 255;          // root + 127 sibling pairs (pairs start
 typedef const __attribute__((address_space(3))) float *LdsFloats;
 struct FetchStaged {
     const rt::Node *nodes; LdsFloats top; int ntop;
+    // the two children of an inner record: adjacent records that start at an odd index, so both lie in the LDS copy or neither
+    // does -- ONE branch for the pair (two operator() calls cost two, each with both paths compiled in)
+    __device__ void pair(int i, rt::Node &l, rt::Node &r) const {
+        if (i < ntop) {
+            LdsFloats p = top + 8 * i;
+            l.lo[0] = p[0]; l.lo[1] = p[1]; l.lo[2] = p[2]; l.a = __float_as_int(p[3]);
+            l.hi[0] = p[4]; l.hi[1] = p[5]; l.hi[2] = p[6]; l.b = __float_as_int(p[7]);
+            r.lo[0] = p[8]; r.lo[1] = p[9]; r.lo[2] = p[10]; r.a = __float_as_int(p[11]);
+            r.hi[0] = p[12]; r.hi[1] = p[13]; r.hi[2] = p[14]; r.b = __float_as_int(p[15]);
+        } else { l = nodes[i]; r = nodes[i + 1]; }
+    }
     __device__ rt::Node operator()(int i) const {
         rt::Node n;
         if (i < ntop) {
@@ -398,7 +409,8 @@ __device__ inline bool traverse_some(const rt::BvhD &bvh, const float o[3], cons
                 }
             }
         } else {
-            const Node l = fetch(n.a), r = fetch(n.a + 1);
+            Node l, r;
+            fetch.pair(n.a, l, r);
             const float lim = best.shape < 0 ? tfar : best.t * 1.0000004f + 1e-30f;     // closed at best.t: equal-t candidates are still visited
             float tl, tr;
             const bool hl = ray_box_once(o, inv, tnear, lim, l.lo, l.hi, &tl);
