@@ -70,6 +70,7 @@ constexpr int kTraverseStack = 40;
 struct FetchGlobal {
     const Node *nodes;
     RT_HD Node operator()(int i) const { return nodes[i]; }
+    RT_HD void pair(int i, Node &l, Node &r) const { l = nodes[i]; r = nodes[i + 1]; }      // the two children of an inner record
 };
 template <bool ANY, class IDX, class Fetch>
 RT_HD inline Hit traverse_with(const BvhD &bvh, const float o[3], const float d[3], float tnear, float tfar,
@@ -99,7 +100,8 @@ RT_HD inline Hit traverse_with(const BvhD &bvh, const float o[3], const float d[
                 }
             }
         } else {
-            const Node l = RT_NODE_AT(n.a), r = RT_NODE_AT(n.a + 1);
+            Node l, r;
+            fetch.pair(n.a, l, r);         // siblings are adjacent: one decision where they are read from (trace.hip: FetchStaged)
             nn += 2;
             // keep the window closed at best.t so equal-t candidates are still visited (tie-break)
             float lim = best.shape < 0 ? tfar : best.t * 1.0000004f + 1e-30f;
