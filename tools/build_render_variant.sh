@@ -8,7 +8,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd); CSRC=$ROOT/redner_amd/csrc; OBJ=$ROOT/bu
 mkdir -p $ROOT/variants
 FLAGS="--offload-arch=gfx950 -std=c++17 -O3 -fPIC -I$CSRC/hip -I$CSRC -Wno-unused-result -pthread -ffp-contract=off -DRDR_PLATFORM_LIBM $*"
 /opt/rocm/bin/hipcc -x hip $FLAGS -c $CSRC/render.cpp -o $OBJ/render_$NAME.o 2> $OBJ/render_$NAME.log || { tail -20 $OBJ/render_$NAME.log; exit 1; }
-OBJS=$(ls $OBJ/*.o | grep -v "/render" )
+OBJS=$(ls $OBJ/*.o | grep -v "/render\|/tracevar_")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -pthread -o $ROOT/variants/$NAME.so $OBJ/render_$NAME.o $OBJS
 grep -i "warning: .*occupancy\|spill" $OBJ/render_$NAME.log | head -3 || true
 ls -la $ROOT/variants/$NAME.so
