@@ -16,7 +16,9 @@ sum in FIXED rank order, so the result is bit-identical on every rank and from r
 has both in hand (bench.py: forward + backward per step) folds them into a single collective
 (`_all_gather_sum_many([image] + gradients)`).
 `render_blocked` renders the same blocks sequentially on one device with the same summation
-order, which is the bit-exact single-GPU counterpart of an R-rank run.
+order, which is the bit-exact single-GPU counterpart of an R-rank run.  (Against the PLAIN single call --
+all samples in one render, added sample by sample -- an R-rank image agrees to ~1e-7 relative L2, the fp32
+summation order, not bit for bit.)
 """
 import torch
 import torch.distributed as dist
