@@ -468,15 +468,32 @@ def main():
 
     from redner_amd import redner
     prep = Prepared(redner, build_scene(a, dev, a.res), spp_rank, a.spp, rank * spp_rank, a.max_bounces, dev)
+    # REDNER_AMD_FORCE_COLLECTIVE=1 under a launcher with ONE rank: the collective runs all the same (RCCL communicator,
+    # all_gather_into_tensor on the device bucket, fixed-order sum, unpacking) and its result must equal what went in, bit for
+    # bit -- the multi-rank data path executed on a one-GPU box (tests/test_rccl_gpu.py)
+    forced = world == 1 and dist.is_initialized() and os.environ.get('REDNER_AMD_FORCE_COLLECTIVE') == '1'
+    coll = {'calls': 0, 'seconds': 0.0, 'bytes_per_call': 0, 'bit_identical_to_local': None}
+
     def reduce_all():
         # the image and every gradient tensor in ONE bucket, ONE collective per step: all_gather + fixed-order sum
         # (bit-reproducible), see distributed.py
-        if world == 1:
+        if world == 1 and not forced:
             return
         from redner_amd.distributed import _all_gather_sum_many
         both = [prep.img] + list(prep.grads)
-        for t, r in zip(both, _all_gather_sum_many(both, dist.group.WORLD)):
+        before = [t.clone() for t in both] if forced else None
+        t1 = time.time()
+        red = _all_gather_sum_many(both, dist.group.WORLD, force=forced)
+        for t, r in zip(both, red):
             t.copy_(r)
+        if not share:
+            torch.cuda.synchronize(dev)
+        coll['seconds'] += time.time() - t1
+        coll['calls'] += 1
+        coll['bytes_per_call'] = sum(t.numel() * t.element_size() for t in both)
+        if forced:
+            same = all(torch.equal(x, y) for x, y in zip(before, both))
+            coll['bit_identical_to_local'] = same if coll['bit_identical_to_local'] is None else (coll['bit_identical_to_local'] and same)
 
     from redner_amd import _capi
     lib = _capi.lib()
@@ -512,6 +529,44 @@ def main():
         dt = max(float(t[0]) for t in every)
     samples = a.res * a.res * a.spp * a.steps
     value = samples / dt / 1e6
+
+    # untimed, world > 1 (or the forced one-rank collective): the north star's rule "bit-identical sum at 1 vs N GPUs", checked
+    # on the hardware the job ran on -- a short job of one sample per rank, gathered and summed as in the timed steps, against
+    # rank 0 rendering the same `world` sample blocks itself and summing them in rank order (must be equal BIT FOR BIT: image
+    # and every gradient tensor), and against one plain call of `world` samples (fp32 summation order: ~1e-7)
+    sharded_check = None
+    if world > 1 or forced:
+        from redner_amd.distributed import _all_gather_sum_many
+        part = Prepared(redner, build_scene(a, dev, a.res), 1, world, rank, a.max_bounces, dev)
+        part.step(0)
+        both = [part.img] + list(part.grads)
+        red = [r.clone() for r in _all_gather_sum_many(both, dist.group.WORLD, force=forced)]
+        if rank == 0:
+            acc = None
+            for b in range(world):
+                blk = Prepared(redner, build_scene(a, dev, a.res), 1, world, b, a.max_bounces, dev)
+                blk.step(0)
+                torch.cuda.synchronize(dev)
+                mine = [blk.img] + list(blk.grads)
+                if acc is None:
+                    acc = [t.clone() for t in mine]
+                else:
+                    for x, y in zip(acc, mine):
+                        x += y
+                del blk
+            one = Prepared(redner, build_scene(a, dev, a.res), world, world, 0, a.max_bounces, dev)
+            one.step(0)
+            torch.cuda.synchronize(dev)
+            whole = [one.img] + list(one.grads)
+            sharded_check = {
+                'job': '%s %dx%d, %d spp fwd+bwd as %d one-sample blocks, one per rank' % (a.workload, a.res, a.res, world, world),
+                'image_bit_identical_to_blocks_on_one_device': bool(torch.equal(red[0], acc[0])),
+                'gradients_bit_identical_to_blocks_on_one_device': bool(all(torch.equal(x, y) for x, y in zip(red[1:], acc[1:]))),
+                'image_rel_l2_vs_one_call': _rel_l2(red[0], whole[0]),
+                'worst_gradient_rel_l2_vs_one_call': max((_rel_l2(x, y) for x, y in zip(red[1:], whole[1:]) if float(y.abs().sum()) > 0),
+                                                         default=0.0)}
+            del one
+        del part
 
     # everything below is untimed and works on a short job (the counters do not depend on the sample count)
     # (32 spp: enough samples for the library to form the same sample batches as in the timed job, so that launches of the
@@ -576,6 +631,13 @@ def main():
             # Scene incl. its edge structures, synchronised (the library builds those beside the caller: a render loop does not
             # wait here); first Scene of the process / a later one with the same connectivity
             'scene_build_ms': prep.scene_build_s * 1e3, 'scene_build_warm_ms': scene_build_warm_ms,
+            # the one collective per step (image + every gradient tensor in one bucket): which backend carried it, how long a
+            # call took on rank 0 (incl. waiting for the slowest rank); null when no process group exists (plain N = 1 run)
+            'sharded_check': sharded_check,
+            'collective': ({'backend': dist.get_backend(), 'world_size': world, 'forced_at_world_1': forced, 'calls': coll['calls'],
+                            'bytes_per_rank_per_call': coll['bytes_per_call'],
+                            'ms_per_call': coll['seconds'] / max(coll['calls'], 1) * 1e3,
+                            'bit_identical_to_local': coll['bit_identical_to_local']} if dist.is_initialized() else None),
             'roofline': {'kernel': 'closest-hit traversal (trace_kernel / trace_refill_kernel, all closest-hit launches of the timed region)', 'bound': 'hbm', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': tc['hbm_bytes_per_launch'] if tc else None,

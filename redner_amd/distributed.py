@@ -20,10 +20,19 @@ order, which is the bit-exact single-GPU counterpart of an R-rank run.  (Against
 all samples in one render, added sample by sample -- an R-rank image agrees to ~1e-7 relative L2, the fp32
 summation order, not bit for bit.)
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 from .render_pytorch import RenderFunction
+
+
+def _collective_forced():
+    """REDNER_AMD_FORCE_COLLECTIVE=1: run the gather + fixed-order sum also in a ONE-rank group (the sum of one part is the
+    part, bit for bit) -- so that the RCCL path -- communicator set-up, all_gather_into_tensor on device tensors, the unpacking
+    -- executes on a box with a single GPU (tests/test_rccl_gpu.py).  Off by default: a one-rank group has nothing to exchange."""
+    return os.environ.get('REDNER_AMD_FORCE_COLLECTIVE') == '1'
 
 
 def _ordered_sum(parts):
@@ -33,11 +42,11 @@ def _ordered_sum(parts):
     return acc
 
 
-def _all_gather_sum(t, group):
+def _all_gather_sum(t, group, force=False):
     """Partial results of all ranks summed in FIXED rank order (bit-identical on every rank and from run to run).  One
     collective into one flat [world, n] buffer (all_gather_into_tensor: no list of per-rank tensors, no extra copies)."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not (force or _collective_forced()):
         return t
     flat = t.detach().contiguous().reshape(-1)
     # gloo (CPU tests, rehearsals of the multi-rank path on fewer GPUs than ranks: RDR_BENCH_SHARE_GPU) gathers host tensors
@@ -51,19 +60,19 @@ def _all_gather_sum(t, group):
     return acc.reshape(t.shape)
 
 
-def _all_gather_sum_many(tensors, group):
+def _all_gather_sum_many(tensors, group, force=False):
     """The same for a list of tensors in ONE collective: the gradient tensors of a render are many and small (bunny_box:
     ~20 tensors, < 0.1 MB together), and over xGMI a collective this size costs its latency, not its bytes -- so they are
     packed into one flat bucket, gathered once, summed in fixed rank order and unpacked."""
     world = dist.get_world_size(group)
-    if world == 1 or not tensors:
+    if (world == 1 and not (force or _collective_forced())) or not tensors:
         return list(tensors)
     out = [None] * len(tensors)
     by_dtype = {}
     for i, t in enumerate(tensors):                 # one bucket per dtype: torch.cat would promote a mixed list
         by_dtype.setdefault(t.dtype, []).append(i)
     for dtype, idx in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):       # the same order on every rank
-        red = _all_gather_sum(torch.cat([tensors[i].reshape(-1) for i in idx]), group)
+        red = _all_gather_sum(torch.cat([tensors[i].reshape(-1) for i in idx]), group, force)
         at = 0
         for i in idx:
             n = tensors[i].numel()

@@ -339,7 +339,11 @@ FULL_FRAME_CASE = ('bunny_box_1024x1024x1', ('bunny_box', 1024, 1, 4))
 # ... and at 16 spp: 16.8 M lanes = ONE 16-sample batch of the GPU build (2^24 lanes) -- the launch shape bench.py times
 # (15.3 M-ray queues, the refilling traversal kernel, per-sample segment tables of the secondary-edge sampler).  ~10 min of
 # oracle time on 8 cores.
-FULL_FRAME_CASES = dict([FULL_FRAME_CASE, ('bunny_box_1024x1024x16', ('bunny_box', 1024, 16, 4))])
+# ... BASELINE config 3 at its quoted size as a FULL frame (tests/test_bunny_box.py at 512 x 512 x 128 spp: 33.5 M samples, ~20 min
+# of oracle time on 8 cores; round 6), and config 4's frame at 64 of its 256 spp (67 M samples, ~40 min): 8 GPU batches of 8
+FULL_FRAME_CASES = dict([FULL_FRAME_CASE, ('bunny_box_1024x1024x16', ('bunny_box', 1024, 16, 4)),
+                         ('bunny_box_512x512x128', ('bunny_box', 512, 128, 4)),
+                         ('bunny_box_1024x1024x64', ('bunny_box', 1024, 64, 4))])
 
 
 def full_frame_digest(out):
