@@ -155,7 +155,8 @@ enum rdr_tune_flags {
     RDR_TUNE_REFILL_ALL       = 1 << 7,   /* the refilling traversal kernel on every queue                    RDR_TRACE_REFILL_ALL */
     RDR_TUNE_TRACE_BINARY     = 1 << 8,   /* never the 4-wide node records                                    RDR_TRACE_BINARY */
     RDR_TUNE_TRACE_NO_LDS_TOP = 1 << 9,   /* hierarchy top not staged in LDS                                  RDR_TRACE_NO_LDS_TOP */
-    RDR_TUNE_NO_FUSED_BOUNCE  = 1 << 10   /* BounceContrib(d) and BounceSample(d+1) as two launches          RDR_NO_FUSED_BOUNCE */
+    RDR_TUNE_NO_FUSED_BOUNCE  = 1 << 10,  /* BounceContrib(d) and BounceSample(d+1) as two launches          RDR_NO_FUSED_BOUNCE */
+    RDR_TUNE_PICKH_ONE_LAUNCH = 1 << 11   /* hierarchical edge pick: one slot per lane, one launch (r1-r5)   RDR_PICKH_ONE_LAUNCH */
 };
 struct rdr_tuning {
     unsigned flags;                 /* rdr_tune_flags */
@@ -175,12 +176,13 @@ struct rdr_tuning {
  *   ordered on `hip_stream` (a hipStream_t; NULL = the null stream, the default) -- a caller whose tensors are produced on
  *   a non-default stream (torch.cuda.stream(...)) passes that stream and needs no device-wide synchronisation of its own.
  *   The calls still return synchronised (like the reference, src/pathtracer.cpp:947-949).
- * rdr_set_pool_cap_mb: bound of the buffer cache per device (see rdr_trim_cache), default min(a quarter of the device, 16 GiB)
+ * rdr_set_pool_cap_mb: bound of the buffer cache per device (see rdr_trim_cache), default min(a quarter of the device, 8 GiB)
  *   or RDR_POOL_CAP_MB; a dedicated render process may raise it so that the ~48 GB of a 2^24-lane sample batch stay parked
  *   between calls.  Negative = back to the default.
  * rdr_set_build_flags: rdr_build_flags for later rdr_scene_create calls (debugging / tests). */
 void rdr_set_stream(void *hip_stream);
 void rdr_set_pool_cap_mb(int64_t megabytes);
+int64_t rdr_get_pool_cap_mb(void);      /* the bound in effect on the calling thread's current device */
 enum rdr_build_flags {
     RDR_BUILD_NO_REFIT        = 1 << 0,   /* no topology caches: hierarchies built from scratch every Scene   RDR_NO_REFIT */
     RDR_BUILD_NO_EDGE_CACHE   = 1 << 1,   /* edge structures never shared between Scenes                      RDR_NO_EDGE_CACHE */
@@ -243,6 +245,9 @@ typedef struct rdr_trace_stats {
     uint64_t closest_nodes, closest_tris, any_nodes, any_tris;
     /* 128-byte records of the 4-wide form of the hierarchy loaded (the kernels walk one form or the other per launch) */
     uint64_t closest_wide_nodes, any_wide_nodes;
+    /* time during which at least one launch of the kind was in flight (union of the launches' intervals): equals closest_ms /
+     * any_ms when launches of a kind never overlap, less when two sample workers trace side by side */
+    double closest_union_ms, any_union_ms;
 } rdr_trace_stats;
 void rdr_trace_stats_enable(int timing, int counting);
 void rdr_trace_stats_reset(void);

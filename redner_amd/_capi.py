@@ -96,7 +96,7 @@ class Tuning(C.Structure):
 
 # rdr_tune_flags / rdr_build_flags
 TUNE_NO_OVERLAP, TUNE_FORCE_GENERAL, TUNE_PICKN_WALK, TUNE_PICKH_FUSED, TUNE_PICKH_LAZY, TUNE_NO_HOIST, TUNE_REFILL_OFF, \
-    TUNE_REFILL_ALL, TUNE_TRACE_BINARY, TUNE_TRACE_NO_LDS_TOP, TUNE_NO_FUSED_BOUNCE = [1 << k for k in range(11)]
+    TUNE_REFILL_ALL, TUNE_TRACE_BINARY, TUNE_TRACE_NO_LDS_TOP, TUNE_NO_FUSED_BOUNCE, TUNE_PICKH_ONE_LAUNCH = [1 << k for k in range(12)]
 BUILD_NO_REFIT, BUILD_NO_EDGE_CACHE, BUILD_SYNC_EDGES, BUILD_EDGE_HOST_BUILD = [1 << k for k in range(4)]
 
 
@@ -122,7 +122,8 @@ class TraceStats(C.Structure):
                 ('closest_rays', C.c_uint64), ('any_rays', C.c_uint64),
                 ('closest_nodes', C.c_uint64), ('closest_tris', C.c_uint64),
                 ('any_nodes', C.c_uint64), ('any_tris', C.c_uint64),
-                ('closest_wide_nodes', C.c_uint64), ('any_wide_nodes', C.c_uint64)]
+                ('closest_wide_nodes', C.c_uint64), ('any_wide_nodes', C.c_uint64),
+                ('closest_union_ms', C.c_double), ('any_union_ms', C.c_double)]
 
 
 class DebugCounters(C.Structure):
@@ -133,7 +134,7 @@ EXPORTS = ('rdr_scene_create', 'rdr_scene_destroy', 'rdr_scene_max_generic_textu
            'rdr_render', 'rdr_compute_num_channels', 'rdr_last_error',
            'rdr_trace_stats_enable', 'rdr_trace_stats_reset', 'rdr_trace_stats_get', 'rdr_scene_trace',
            'rdr_debug_counters_get', 'rdr_trim_cache', 'rdr_debug_dump_edges', 'rdr_debug_bvh_check',
-           'rdr_set_stream', 'rdr_set_pool_cap_mb', 'rdr_set_build_flags', 'rdr_debug_libm', 'rdr_libm_exact')
+           'rdr_set_stream', 'rdr_set_pool_cap_mb', 'rdr_get_pool_cap_mb', 'rdr_set_build_flags', 'rdr_debug_libm', 'rdr_libm_exact')
 
 _lib = None
 _lib_path = None
@@ -182,6 +183,8 @@ def load(path=None):
     lib.rdr_set_stream.argtypes = [C.c_void_p]
     lib.rdr_set_pool_cap_mb.restype = None
     lib.rdr_set_pool_cap_mb.argtypes = [C.c_int64]
+    lib.rdr_get_pool_cap_mb.restype = C.c_int64
+    lib.rdr_get_pool_cap_mb.argtypes = []
     lib.rdr_set_build_flags.restype = None
     lib.rdr_set_build_flags.argtypes = [C.c_uint]
     lib.rdr_trace_stats_get.restype = None

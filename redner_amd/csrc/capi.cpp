@@ -69,7 +69,14 @@ rdr_scene *rdr_scene_create(const rdr_camera_desc *camera, const rdr_shape_desc 
     }
 }
 
-void rdr_scene_destroy(rdr_scene *scene) { delete reinterpret_cast<rdr::Scene *>(scene); }
+void rdr_scene_destroy(rdr_scene *scene) {
+    if (!scene) return;
+    rdr::Scene *s = reinterpret_cast<rdr::Scene *>(scene);
+    // under the device's lock like every other call that touches its pool / caches (the destructor returns buffers and may join
+    // the Scene's edge build)
+    std::lock_guard<std::recursive_mutex> lk(device_lock(s->gpu_index));
+    delete s;
+}
 
 int rdr_scene_max_generic_texture_dimension(const rdr_scene *scene) {
     return scene ? reinterpret_cast<const rdr::Scene *>(scene)->max_generic_texture_dimension : 0;
@@ -117,6 +124,7 @@ void rdr_trace_stats_get(rdr_trace_stats *out) {
     out->closest_nodes = s.nodes[0]; out->closest_tris = s.tris[0];
     out->any_nodes = s.nodes[1]; out->any_tris = s.tris[1];
     out->closest_wide_nodes = s.wide_nodes[0]; out->any_wide_nodes = s.wide_nodes[1];
+    out->closest_union_ms = s.closest_union_ms; out->any_union_ms = s.any_union_ms;
 }
 
 uint64_t rdr_trim_cache(void) {
@@ -130,6 +138,7 @@ uint64_t rdr_trim_cache(void) {
 
 void rdr_set_stream(void *hip_stream) { g_user_stream = hip_stream; }
 void rdr_set_pool_cap_mb(int64_t megabytes) { exec::pool_set_cap(megabytes < 0 ? -1 : (long long)megabytes << 20); }
+int64_t rdr_get_pool_cap_mb(void) { return (int64_t)(exec::pool_cap_bytes() >> 20); }
 void rdr_set_build_flags(unsigned flags) { rdr::build_flags_ref().store(flags); }
 
 void rdr_debug_counters_get(rdr_debug_counters *out) {

@@ -455,10 +455,11 @@ void delete_edge_data(EdgeData *e) {
 }
 
 EdgeData *compute_edge_data(const Scene &scene) {
-    // one build at a time: the topology caches below are process-wide, and builds of different Scenes may be in flight
-    // together now that they run beside the caller (scene.cpp: create_scene)
-    static std::mutex build_lock;
-    std::lock_guard<std::mutex> build_guard(build_lock);
+    // one build at a time PER DEVICE: the topology caches below are per device (like scene.cpp's edge / topology caches), and
+    // builds of different Scenes may be in flight together now that they run beside the caller (scene.cpp: create_scene)
+    const int dev_slot = (scene.gpu_index < 0 ? 0 : scene.gpu_index) & 15;
+    static std::mutex *build_locks = new std::mutex[16];
+    std::lock_guard<std::mutex> build_guard(build_locks[dev_slot]);
     PhaseTimer timer("edge build");
     std::unique_ptr<EdgeData> ed(new EdgeData());
     const int ns = (int)scene.shapes.size();
@@ -477,7 +478,8 @@ EdgeData *compute_edge_data(const Scene &scene) {
     // buffer only; a shape whose index buffer equals the one seen last at its position reuses it (an optimisation loop moves
     // vertices, not connectivity).  Everything after it depends on positions and is redone.
     struct MergedCache { std::vector<std::vector<int>> indices; std::vector<std::vector<EdgeD>> merged; };
-    static MergedCache *merged_cache = new MergedCache();            // one build at a time (build_lock above; scene.cpp: EdgeBuilder)
+    static MergedCache *merged_caches = new MergedCache[16];         // one build at a time per device (build_locks above; scene.cpp: EdgeBuilder)
+    MergedCache *merged_cache = merged_caches + dev_slot;
     const bool cache_allowed = !(scene.build_flags & RDR_BUILD_NO_REFIT);
     if ((int)merged_cache->indices.size() != ns) { merged_cache->indices.assign(ns, {}); merged_cache->merged.assign(ns, {}); }
     std::vector<EdgeD> &edges = ed->edges;
@@ -631,12 +633,13 @@ EdgeData *compute_edge_data(const Scene &scene) {
         // dropped out.  A canonical edge that is not in the current list keeps its place and its box (it is a real edge of
         // the mesh) but gets a leaf record no query accepts (GatherLeaf with an empty Hough interval).
         struct GatherCache { std::vector<EdgeD> canon; rt::BvhHost bvh; };
-        static GatherCache *gather_cache = new GatherCache();            // one build at a time (build_lock above; scene.cpp: EdgeBuilder)
+        static GatherCache *gather_caches = new GatherCache[16];         // one build at a time per device (build_locks above)
+        GatherCache *gather_cache = gather_caches + dev_slot;
         rt::BvhHost gather_built;
         double &expand_out = ed->edge_bounds_expand;
         const bool gather_on_device = ed->device_trees && exec::kDeviceBvh;
         EdgeData *edp = ed.get();
-        auto gather_job = hostpool::run([&gather_built, &edges, &canon, &can_of, &cs_ids, &ncs_ids, shapes, ne, &expand_out, cache_allowed, gather_on_device, edp] {
+        auto gather_job = hostpool::run([&gather_built, &edges, &canon, &can_of, &cs_ids, &ncs_ids, shapes, ne, &expand_out, cache_allowed, gather_on_device, edp, gather_cache] {
             // mean absolute deviation of the endpoints -> billboard half-width
             std::vector<int> all_ids(cs_ids);
             all_ids.insert(all_ids.end(), ncs_ids.begin(), ncs_ids.end());

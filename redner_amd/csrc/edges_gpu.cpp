@@ -662,15 +662,18 @@ __global__ void __launch_bounds__(256) gather_ids_kernel(const int *canon_ids, c
 }
 namespace {
 struct GatherTreeCache { std::mutex lock; std::vector<EdgeD> canon; std::shared_ptr<rt::BvhDev> tree; int device = -1; };
-GatherTreeCache *gather_tree_cache() { static GatherTreeCache *c = new GatherTreeCache(); return c; }
+// per device, like scene.cpp's edge / topology caches: two devices driven from one process do not evict each other's tree
+GatherTreeCache *gather_tree_cache(int device) { static GatherTreeCache *c = new GatherTreeCache[16]; return c + ((device < 0 ? 0 : device) & 15); }
 }
 void drop_gather_cache() {
-    GatherTreeCache *c = gather_tree_cache();
-    std::lock_guard<std::mutex> lk(c->lock);            // (the edge-builder thread may be in gather_hierarchy_device)
-    c->canon.clear(); c->tree.reset(); c->device = -1;
+    for (int d = 0; d < 16; ++d) {
+        GatherTreeCache *c = gather_tree_cache(d);
+        std::lock_guard<std::mutex> lk(c->lock);        // (the edge-builder thread may be in gather_hierarchy_device)
+        c->canon.clear(); c->tree.reset(); c->device = -1;
+    }
 }
 void gather_hierarchy_device(EdgeData &ed) {
-    GatherTreeCache *cache = gather_tree_cache();      // one build at a time (scene.cpp: EdgeBuilder); rdr_trim_cache() may drop it
+    GatherTreeCache *cache = gather_tree_cache(exec::current_device());      // one build at a time per device (scene.cpp: EdgeBuilder); rdr_trim_cache() may drop it
     std::lock_guard<std::mutex> cache_lock(cache->lock);
     hipStream_t s = exec::ctx().stream;
     const int nc = (int)ed.gather_cur_of.size();

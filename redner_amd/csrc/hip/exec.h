@@ -65,6 +65,8 @@ struct ReplicaLayout {
     unsigned hot_mask, mask;         // replicas - 1 (powers of two)
 };
 static __device__ ReplicaLayout g_rep = {nullptr, 0, 0, 0, 0};
+// (callers that add a GROUP of consecutive accumulators -- accum_triple, accum_block -- call this for the first address only:
+//  a tensor never straddles hot_end, render.cpp: GradStore checks its layout)
 __device__ inline double *replica_of(double *p) {
     const unsigned wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const bool hot = p < g_rep.hot_end;
@@ -430,6 +432,49 @@ __global__ void __launch_bounds__(256) persistent_kernel(W w, int n, const int *
         }
     }
 }
+// The same walk protocol with WAVE-LOCAL refill (the scheme of trace_refill_kernel, trace.hip): a wave owns 64 x K consecutive
+// items and its idle lanes take the next unclaimed ones of that chunk -- a ballot and a popcount, no atomic, no counter to
+// zero; items that are neighbours in the list (neighbouring pixels: walks of similar length and the same tree nodes) stay in
+// one wave.  For walks that are long and uneven but not heavy-tailed (the hierarchical edge pick: 20 ... 300 steps).
+template <class W>
+__global__ void __launch_bounds__(256) chunked_kernel(W w, int n, const int *count, int items_per_lane, int idle_min, int steps) {
+    if (count) { const int c = *count; n = c < n ? c : n; }
+    const int chunk = 64 * items_per_lane;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long first = ((long long)blockIdx.x * 4 + wave) * chunk;
+    if (first >= n) return;
+    const int end = (int)(first + chunk < n ? first + chunk : n);
+    int next = (int)first;                                  // wave-uniform
+    typename W::State st;
+    bool busy = false;
+    for (;;) {
+        const unsigned long long idle = __ballot(!busy);
+        const int nidle = __popcll(idle);
+        if (next < end && (nidle >= idle_min || nidle == 64)) {
+            if (!busy) {
+                const int item = next + __popcll(idle & ((1ull << lane) - 1ull));
+                if (item < end) {
+                    if (w.begin(item, st)) busy = true;
+                    else w.finish(st);
+                }
+            }
+            next += nidle;
+        }
+        if (__ballot(busy) == 0ull) { if (next >= end) break; continue; }
+#pragma unroll 1
+        for (int it = 0; it < steps; ++it) {
+            if (busy && w.step(st)) { w.finish(st); busy = false; }
+        }
+    }
+}
+template <class W>
+inline void launch_chunked(Count n, const W &w, int items_per_lane = 4, int idle_min = 16, int steps = 8) {
+    if (n.upper <= 0) return;
+    const int per_block = 4 * 64 * items_per_lane;
+    const int blocks = (int)(((long long)n.upper + per_block - 1) / per_block);
+    hipLaunchKernelGGL(chunked_kernel<W>, dim3(blocks), dim3(256), 0, ctx().stream, w, n.upper, n.dev, items_per_lane, idle_min, steps);
+    check(hipGetLastError(), "chunked launch");
+}
 int *persistent_counter();          // trace.hip: ring of zeroed ints, one per launch
 template <class W>
 inline void launch_persistent(Count n, const W &w) {
@@ -621,7 +666,8 @@ inline int read_count(Count c) {
 
 // ---- traversal kernels (trace.hip) --------------------------------------------------------------
 struct TraceStats {
-    double closest_ms = 0, any_ms = 0;
+    double closest_ms = 0, any_ms = 0;                 // sum of the launches' durations
+    double closest_union_ms = 0, any_union_ms = 0;     // time with at least one launch of the kind in flight
     uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes[2] = {0, 0}, tris[2] = {0, 0}, wide_nodes[2] = {0, 0};   // node records: 32-byte binary / 128-byte 4-wide
     bool timing = false, counting = false;
 };
@@ -633,7 +679,9 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count 
 inline int sample_workers(int lanes, int samples, bool batches = false) {
     // (rdr_tuning::workers overrides all of this, render.cpp)
     // sample batches (render.cpp): two chains of launches in flight, more do not help (tools/gpu_batch_grid.sh)
-    if (batches) return samples >= 2 && lanes < (1 << 20) ? 2 : 1;
+    // ... also of large batches (round 6): at 1024 x 1024 two workers with 4-sample batches beat one worker with 8-sample
+    // batches in the same memory, 69.3 -> 70.8 Msamples/s (profiles/r5_notes.md "two chains of launches in flight")
+    if (batches) return samples >= 2 ? 2 : 1;
     // measured (bunny_box backward, round 2): 256x256x4 spp 13.8 / 14.6 / 15.2 ms with 2 / 3 / 4 workers, 256x256x16 spp
     // 52.1 / 47.9 / 46.7 / 48.7 ms with 3 / 4 / 6 / 8; 512x512x8 spp 92 -> 83 ms with a second worker; at 1024x1024 the second
     // worker adds 2-4 % and stretches every kernel it shares the GPU with
@@ -645,6 +693,12 @@ void select_device(int use_gpu, int gpu_index);
 } // namespace exec
 
 namespace rdr {
+// What GradStore (render.cpp) tells its accumulator backend: the small tier has been laid out / a small tensor is about to be
+// folded into the caller's floats / the fold is done.  The fp64 replicas need none of it (tests/hostsim/exec.h keeps the
+// reference's fp32 accumulation order beside them through these three).
+inline void accumulators_laid_out(double *, size_t) {}
+inline void accumulator_before_fold(double *, double *, size_t) {}
+inline void accumulators_folded() {}
 __device__ inline void accum_f32(float *p, float v) { atomicAdd(p, v); }
 __host__ inline void accum_f32(float *p, float v) { *p += v; }
 }

@@ -49,17 +49,18 @@ struct Pool {
 Pool &pool() { static Pool *p = new Pool(); return *p; }       // never destroyed: blocks may be returned during exit
 
 // The cache is bounded: a torch process shares the device with torch's own allocator, which cannot reclaim what is parked
-// here.  Default: a quarter of the device's memory but no more than 16 GiB (round 3 parked up to 72 GB -- the 48 GB of a
-// 2^24-lane sample batch -- for +4 % at 1024 x 1024: now a decision of the caller, rdr_set_pool_cap_mb / RDR_POOL_CAP_MB);
+// here.  Default: a quarter of the device's memory but no more than 8 GiB (round 6; 16 GiB in rounds 4-5; round 3 parked up
+// to 72 GB -- the 48 GB of a 2^24-lane sample batch -- for +4 % at 1024 x 1024).  More is a decision of the caller:
+// rdr_set_pool_cap_mb / RDR_POOL_CAP_MB (bench.py owns its GPU, raises the bound and says so in its line);
 // rdr_trim_cache() releases everything.
 size_t pool_cap(const Pool &pl) {
     if (pl.cap_override >= 0) return (size_t)pl.cap_override;
     static const size_t dflt = [] {
         if (const char *e = std::getenv("RDR_POOL_CAP_MB")) return (size_t)std::max(0, std::atoi(e)) << 20;
-        const size_t sixteen = (size_t)16384 << 20;
+        const size_t eight = (size_t)8192 << 20;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return sixteen; }
-        return std::min(total_b / 4, sixteen);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return eight; }
+        return std::min(total_b / 4, eight);
     }();
     return dflt;
 }
@@ -77,6 +78,7 @@ void pool_set_cap(long long bytes) {
 // the calling thread's stream -- a buffer that is read before it is written then fails the same way every time instead of
 // depending on what the pool last kept in it (fresh device memory is zero; the CPU harness gets zero pages from malloc).
 static void *pool_alloc_raw(size_t bytes);
+static void pool_release(int only_dev);
 void *pool_alloc(size_t bytes) {
     void *p = pool_alloc_raw(bytes);
     static const bool poison = std::getenv("RDR_POOL_POISON") != nullptr;
@@ -104,7 +106,7 @@ static void *pool_alloc_raw(size_t bytes) {
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess) {             // out of memory with blocks parked in the cache: release them and retry once
         (void)hipGetLastError();
-        pool_trim();
+        pool_release(dev);             // this device's parked blocks only: the other devices' callers are not disturbed
         check(hipMalloc(&p, want), "hipMalloc");
     }
     std::lock_guard<std::mutex> lk(pl.lock);
@@ -133,22 +135,34 @@ void pool_free(void *p) {
     pl.parked[d] += bytes;
 }
 
-void pool_trim() {                     // hipFree waits for the device before it releases a block
+// Parked blocks of ONE device (-1: of every device) back to the driver.  The blocks are taken off the lists under the pool's
+// lock and released outside it: hipFree waits for the device, and another device's allocations must not wait with it
+// (one process driving several devices from several threads).
+static void pool_release(int only_dev) {
     Pool &pl = pool();
-    std::lock_guard<std::mutex> lk(pl.lock);
+    std::vector<std::pair<int, void *>> gone;
+    {
+        std::lock_guard<std::mutex> lk(pl.lock);
+        for (int d = 0; d < 16; ++d) {
+            if (only_dev >= 0 && d != (only_dev & 15)) continue;
+            auto &fl = pl.free_blocks[d];
+            for (auto &kv : fl) gone.push_back({d, kv.second});
+            fl.clear();
+            pl.from_driver[d] -= pl.parked[d];
+            pl.parked[d] = 0;
+        }
+    }
+    if (gone.empty()) return;
     int dev = 0;
     (void)hipGetDevice(&dev);
-    for (int d = 0; d < 16; ++d) {
-        auto &fl = pl.free_blocks[d];
-        if (fl.empty()) continue;
-        (void)hipSetDevice(d);
-        for (auto &kv : fl) (void)hipFree(kv.second);
-        fl.clear();
-        pl.from_driver[d] -= pl.parked[d];
-        pl.parked[d] = 0;
+    int at = dev;
+    for (auto &g : gone) {
+        if (g.first != at) { (void)hipSetDevice(g.first); at = g.first; }
+        (void)hipFree(g.second);
     }
-    (void)hipSetDevice(dev);
+    if (at != dev) (void)hipSetDevice(dev);
 }
+void pool_trim() { pool_release(-1); }
 
 size_t pool_cached_bytes() {
     Pool &pl = pool();
@@ -268,6 +282,7 @@ CompactScratch &compact_scratch(int nblocks) {
 // STACK: entries of the per-lane LDS stack column.  The kernel waits on node fetches about two thirds of the
 // time (profiles/r1_notes.md), so waves per SIMD matter: 40 entries allow 4, 24 allow 6, 16 allow 8.  The host
 // picks the smallest instantiation that covers the scene's hierarchy depth.
+constexpr int kRefillSortDefault = 0;
 constexpr int kTopNodes = 255;          // root + 127 sibling pairs (pairs start at odd indices, so none straddles): 8 KiB of LDS
 // node record i: from the workgroup's LDS copy of the top levels, else from global memory.  The LDS pointer keeps its address
 // space in its type: with two generic pointers the compiler merges the paths into a select + flat_load.
@@ -431,15 +446,20 @@ __device__ inline bool traverse_some(const rt::BvhD &bvh, const float o[3], cons
     return false;
 }
 
-template <bool ANY, int STACK, class IDX>
-__global__ void __launch_bounds__(256) trace_refill_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays, rt::HitRec *__restrict__ hits,
-                                                           int n, const int *count, int rays_per_lane, int idle_min, int steps) {
+// `sort_mode` (round 6): the wave hands its 256 rays out in the order of a direction key instead of queue
+// order -- 1: octant of the direction (Gray-code order: neighbouring bins differ in one sign), 2: octant x dominant axis
+// (24 bins), dead slots (tmax < 0) last.  A counting sort of the 256 indices by ballots, one byte per index in LDS; nothing
+// else moves: rays are read and hits written by queue slot, every ray takes the same steps, so the hit ids are the same.
+template <bool ANY, int STACK, class IDX, bool SORT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STACK <= 24 ? 7 : 1, 8))) trace_refill_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays, rt::HitRec *__restrict__ hits,
+                                                           int n, const int *count, int rays_per_lane, int idle_min, int steps, int sort_mode) {
     if (count) { const int c = *count; n = c < n ? c : n; }
     const int chunk = 64 * rays_per_lane;
     if ((long long)blockIdx.x * 4 * chunk >= n) return;
     __shared__ IDX stack_tile[STACK * 256];
     IDX *stack = stack_tile + threadIdx.x;
     __shared__ rt::Node top[kTopNodes + 1];
+    __shared__ unsigned char order_tile[SORT ? 4 * 256 : 4];
     const int ntop = bvh.num_nodes < kTopNodes ? bvh.num_nodes : kTopNodes;
     if ((int)threadIdx.x < ntop) top[threadIdx.x] = bvh.nodes[threadIdx.x];
     __syncthreads();
@@ -448,6 +468,46 @@ __global__ void __launch_bounds__(256) trace_refill_kernel(rt::BvhD bvh, const r
     const long long first = ((long long)blockIdx.x * 4 + wave) * chunk;
     if (first >= n) return;
     const int end = (int)(first + chunk < n ? first + chunk : n);
+    unsigned char *order = order_tile + wave * 256;
+    const bool sorted = SORT && sort_mode > 0 && rays_per_lane == 4;
+    if (sorted) {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        unsigned keys = 0;                                  // byte j: key of ray first + 64 j + lane (255: beyond the queue)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long r = first + 64 * j + lane;
+            unsigned key = 255u;
+            if (r < end) {
+                const rt::RayRec ray = rays[r];
+                if (ray.tmax < 0.f) key = 254u;             // dead slot: handed out last (it finishes at once)
+                else {
+                    const unsigned oct = (ray.dx < 0.f ? 1u : 0u) | (ray.dy < 0.f ? 2u : 0u) | (ray.dz < 0.f ? 4u : 0u);
+                    const unsigned gray = oct ^ (oct >> 1);
+                    key = gray;
+                    if (sort_mode >= 2) {
+                        const float ax = fabsf(ray.dx), ay = fabsf(ray.dy), az = fabsf(ray.dz);
+                        const unsigned axis = ax >= ay ? (ax >= az ? 0u : 2u) : (ay >= az ? 1u : 2u);
+                        key = gray * 3u + ((gray & 1u) ? 2u - axis : axis);       // boustrophedon: the axis order turns at every octant
+                    }
+                }
+            }
+            keys |= key << (8 * j);
+        }
+        const int nbins = sort_mode >= 2 ? 24 : 8;
+        int off = 0;
+        for (int b = 0; b <= nbins; ++b) {                  // bin `nbins` = the dead slots
+            const unsigned want = b == nbins ? 254u : (unsigned)b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = ((keys >> (8 * j)) & 255u) == want;
+                const unsigned long long m = __ballot(in);
+                if (in) order[off + __popcll(m & below)] = (unsigned char)(64 * j + lane);
+                off += __popcll(m);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     int next = (int)first;                                  // wave-uniform
     bool live = false;
     int slot = 0, cur = 0, sp = 0;
@@ -458,8 +518,9 @@ __global__ void __launch_bounds__(256) trace_refill_kernel(rt::BvhD bvh, const r
         const int nidle = __popcll(idle);
         if (next < end && (nidle >= idle_min || nidle == 64)) {
             if (!live) {
-                const int r = next + __popcll(idle & ((1ull << lane) - 1ull));
+                int r = next + __popcll(idle & ((1ull << lane) - 1ull));
                 if (r < end) {
+                    if (SORT && sorted) r = (int)first + (int)order[r - (int)first];
                     const rt::RayRec ray = rays[r];
                     slot = r; cur = 0; sp = 0;
                     o[0] = ray.ox; o[1] = ray.oy; o[2] = ray.oz; d[0] = ray.dx; d[1] = ray.dy; d[2] = ray.dz;
@@ -557,12 +618,31 @@ void trace_stats_collect() {           // call between render() calls: every wor
     std::lock_guard<std::mutex> lk(g_stats_lock);
     if (!g_pending.empty()) {
         check(hipDeviceSynchronize(), "stats sync");
+        // Per launch: its duration (event pair on the launch stream).  Per kind: the UNION of the launches' busy intervals --
+        // the time during which at least one launch of the kind was in flight.  With one chain of launches the two agree; with
+        // two sample workers two closest-hit launches share the GPU, each takes longer and the same rays are traced at the same
+        // total rate: bytes over the union is the schedule-invariant rate (bench.py: roofline.frac).  Interval ends are placed
+        // relative to the first launch's start event (same device clock on every stream).
+        std::vector<std::pair<double, double>> iv[2];
+        const hipEvent_t ref = g_pending.front().a;
         for (Pending &p : g_pending) {
-            float ms = 0;
+            float ms = 0, at = 0;
             check(hipEventElapsedTime(&ms, p.a, p.b), "hipEventElapsedTime");
             (p.any ? st.any_ms : st.closest_ms) += ms;
-            g_free_events.push_back(p.a); g_free_events.push_back(p.b);
+            if (p.a != ref && hipEventElapsedTime(&at, ref, p.a) != hipSuccess) { (void)hipGetLastError(); at = 0.f; }
+            iv[p.any ? 1 : 0].push_back({(double)at, (double)at + (double)ms});
         }
+        for (int k = 0; k < 2; ++k) {
+            std::sort(iv[k].begin(), iv[k].end());
+            double busy = 0, lo = 0, hi = -1;
+            for (const auto &x : iv[k]) {
+                if (hi < lo || x.first > hi) { if (hi >= lo) busy += hi - lo; lo = x.first; hi = x.second; }
+                else if (x.second > hi) hi = x.second;
+            }
+            if (hi >= lo) busy += hi - lo;
+            (k ? st.any_union_ms : st.closest_union_ms) += busy;
+        }
+        for (Pending &p : g_pending) { g_free_events.push_back(p.a); g_free_events.push_back(p.b); }
         g_pending.clear();
     }
     if (g_counters) {
@@ -646,11 +726,25 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count 
         const int wg_rays = 4 * 64 * refill_k;
         const int rblocks = (int)(((long long)n + wg_rays - 1) / wg_rays);
         const int k_arg = refill_k;
+        // RDR_REFILL_SORT=0|1|2 (experiments; bit 2 = closest-hit queues only, bit 3 = any-hit queues only)
+        static const int sort_env = [] { const char *e = std::getenv("RDR_REFILL_SORT"); return e ? std::atoi(e) : kRefillSortDefault; }();
+        const int sort_mode = ((sort_env & 4) && any) || ((sort_env & 8) && !any) ? 0 : (sort_env & 3);
         const bool small = bvh.num_nodes < 65536 && bvh.stack_need <= 24;
-        if (any && small) hipLaunchKernelGGL((trace_refill_kernel<true, 24, unsigned short>), dim3(rblocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, k_arg, idle_min, steps);
-        else if (any) hipLaunchKernelGGL((trace_refill_kernel<true, rt::kTraverseStack, int>), dim3(rblocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, k_arg, idle_min, steps);
-        else if (small) hipLaunchKernelGGL((trace_refill_kernel<false, 24, unsigned short>), dim3(rblocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, k_arg, idle_min, steps);
-        else hipLaunchKernelGGL((trace_refill_kernel<false, rt::kTraverseStack, int>), dim3(rblocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, k_arg, idle_min, steps);
+#define RDR_REFILL_LAUNCH(ANY_, STACK_, IDX_, SORT_) \
+        hipLaunchKernelGGL((trace_refill_kernel<ANY_, STACK_, IDX_, SORT_>), dim3(rblocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, k_arg, idle_min, steps, sort_mode)
+        const bool sort_on = sort_mode > 0 && k_arg == 4;
+        if (sort_on) {
+            if (any && small) RDR_REFILL_LAUNCH(true, 24, unsigned short, true);
+            else if (any) RDR_REFILL_LAUNCH(true, rt::kTraverseStack, int, true);
+            else if (small) RDR_REFILL_LAUNCH(false, 24, unsigned short, true);
+            else RDR_REFILL_LAUNCH(false, rt::kTraverseStack, int, true);
+        } else {
+            if (any && small) RDR_REFILL_LAUNCH(true, 24, unsigned short, false);
+            else if (any) RDR_REFILL_LAUNCH(true, rt::kTraverseStack, int, false);
+            else if (small) RDR_REFILL_LAUNCH(false, 24, unsigned short, false);
+            else RDR_REFILL_LAUNCH(false, rt::kTraverseStack, int, false);
+        }
+#undef RDR_REFILL_LAUNCH
         check(hipGetLastError(), "trace launch");
         if (st.timing) check(hipEventRecord(p.b, s), "hipEventRecord");
         std::lock_guard<std::mutex> lk(g_stats_lock);

@@ -280,14 +280,14 @@ struct GradStore {
         counting = false; pairs.clear();
         for (Tier &t : tier) t.cursor = 0;
         layout(scene, ds);                                   // pass 2: real pointers
-#ifdef RDR_HOSTSIM
-        // debugging harness only (tests/hostsim/exec.h: F32Shadow): the reference's fp32 accumulators beside the small tier
-        f32_shadow() = F32Shadow();
-        if (std::getenv("RDR_HOSTSIM_REF_ORDER") && tier[0].stride) {
-            f32_shadow().base = tier[0].base; f32_shadow().count = tier[0].stride;
-            f32_shadow().acc.assign(tier[0].stride, 0.f);
+        // accum_triple / accum_block pick the replica from the FIRST address of a group (exec.h: replica_of) and add the
+        // others at the same offset: a tensor must lie in one tier as a whole (place() puts it there; checked, not assumed)
+        for (const Pair &p : pairs) {
+            const Tier &t = tier[p.tier];
+            if (p.acc < t.base || p.acc + p.count > t.base + t.stride)
+                throw std::runtime_error("render: gradient accumulator straddles a replica tier (GradStore::layout)");
         }
-#endif
+        accumulators_laid_out(tier[0].base, tier[0].stride);           // (a hook of the accumulator backend: nothing on the device)
     }
     void layout(const Scene &scene, const rdr_dscene_desc &ds) {
         if (ds.num_shapes != (int)scene.shapes.size() || ds.num_materials != (int)scene.materials.size() ||
@@ -345,14 +345,9 @@ struct GradStore {
         }
     }
     void flush() {
-#ifdef RDR_HOSTSIM
-        if (f32_shadow().base == tier[0].base && f32_shadow().base) {       // reference-order mode: the floats, not the fp64 sums
-            for (const Pair &p : pairs)
-                if (p.tier == 0 && p.count <= 16)
-                    for (size_t i = 0; i < p.count; ++i) p.acc[i] = (double)f32_shadow().acc[(size_t)(p.acc - tier[0].base) + i];
-            f32_shadow() = F32Shadow();
-        }
-#endif
+        for (const Pair &p : pairs)
+            if (p.tier == 0) accumulator_before_fold(tier[0].base, p.acc, p.count);
+        accumulators_folded();
         // one launch per tier for all its tensors, unless two mirrors feed overlapping output ranges (a tensor shared by two
         // DScene entries): those must add one after the other
         std::vector<Pair> by_out(pairs);
@@ -455,6 +450,7 @@ struct Backward {
             if (tuning().gather_work_cap >= 0) gshared.work_cap = std::min(tuning().gather_work_cap, kGatherWorkCap);
             h_leaves = arena.get<HLeaf>((size_t)kHSamples * P);
             h_spill = arena.get<HLeaf>((size_t)(kHSamples - kHStackLds) * P);
+            h_descent = arena.get<HDescent>((size_t)P);
             edge_contrib = arena.get<double>(L);
             edge_tmin = arena.get<double>(L);
             hit_pos = arena.get<double>((size_t)3 * L);
@@ -496,6 +492,7 @@ struct Backward {
     void erd_view(const int *seg) { ea.erd_seg = eb.erd_seg = seg; ea.erd_S = eb.erd_S = cur_S; ea.erd_P0 = eb.erd_P0 = batch.P0; }
     int *elist[3] = {nullptr, nullptr, nullptr};
     HLeaf *h_leaves = nullptr, *h_spill = nullptr;   // hierarchical pick: recorded leaves / spilled stack entries per list position
+    HDescent *h_descent = nullptr;                   // ... and what the descent hands to the leaf launch (stages_edge.h)
     GatherShared gshared{nullptr, nullptr, nullptr, nullptr, 0, 0};     // heavy slots of the gather: big candidate lists, subtree work items
     GatherCand *gather_cands = nullptr;        // positive leaves found by the NEE-mode gather, kGatherCands per list position
     int *nee_slots = nullptr;                  // slots of the NEE-mode edge pick (its walk runs beside the hierarchical pick)
@@ -632,6 +629,10 @@ struct Backward {
         const int dim0 = opt.sample_pixel_center ? 0 : 2;
         const bool pickh_fused = tuning().has(RDR_TUNE_PICKH_FUSED);     // A/B: the one-loop form
         const bool pickh_lazy = tuning().has(RDR_TUNE_PICKH_LAZY);       // A/B: per-field node loads
+        const bool pickh_one_launch = tuning().has(RDR_TUNE_PICKH_ONE_LAUNCH);       // A/B: one slot per lane from root to last leaf
+        // RDR_PICKH_REFILL=<slots per lane>,<idle lanes before a refill>,<steps between two checks> (experiments)
+        static const struct PickhRefill { int k = 4, idle = 16, steps = 8; PickhRefill() { if (const char *e = std::getenv("RDR_PICKH_REFILL")) std::sscanf(e, "%d,%d,%d", &k, &idle, &steps); } } pickh_refill;
+        const int pickh_k = std::max(1, pickh_refill.k), pickh_idle = std::min(64, std::max(1, pickh_refill.idle)), pickh_steps = std::max(1, pickh_refill.steps);
         // The two edge picks of a secondary pass: slot setup, the per-mode slot lists, the NEE-mode gather and the hierarchical
         // pick.  `early`: everything off the calling stream (setup + lists + gather on side stream 1, hierarchical pick on side
         // stream 0), so that the caller's stream is free for the bounce adjoints; otherwise setup, lists and the hierarchical pick
@@ -659,8 +660,19 @@ struct Backward {
             };
             auto hierarchical = [&] {
                 if (pickh_fused) launch_v(lean, nH, SecEdgePickH{sa, elist[0], sec_picks});
-                else if (pickh_lazy) launch_v(lean, nH, SecEdgePickH2<false>{sa, elist[0], sec_picks, h_leaves, h_spill, nH.upper});
-                else launch_v(lean, nH, SecEdgePickH2<true>{sa, elist[0], sec_picks, h_leaves, h_spill, nH.upper});
+                else if (pickh_one_launch && pickh_lazy) launch_v(lean, nH, SecEdgePickH2<false>{sa, elist[0], sec_picks, h_leaves, h_spill, nH.upper});
+                else if (pickh_one_launch) launch_v(lean, nH, SecEdgePickH2<true>{sa, elist[0], sec_picks, h_leaves, h_spill, nH.upper});
+                else {
+                    // the descent as a walk with wave-local lane refill, then the recorded leaves (stages_edge.h, round 6)
+                    auto descend = [&](auto walk) {
+                        if (lean == kLean) exec::launch_chunked(nH, LeanWalk<decltype(walk)>{walk}, pickh_k, pickh_idle, pickh_steps);
+                        else if (lean == kMid) exec::launch_chunked(nH, MidWalk<decltype(walk)>{walk}, pickh_k, pickh_idle, pickh_steps);
+                        else exec::launch_chunked(nH, walk, pickh_k, pickh_idle, pickh_steps);
+                    };
+                    if (pickh_lazy) descend(SecEdgePickHDescend<false>{sa, elist[0], h_leaves, h_spill, h_descent, nH.upper});
+                    else descend(SecEdgePickHDescend<true>{sa, elist[0], h_leaves, h_spill, h_descent, nH.upper});
+                    launch_v(lean, nH, SecEdgePickHLeaves{sa, elist[0], sec_picks, h_leaves, h_descent, nH.upper});
+                }
             };
             if (early) {
                 picks_begin.after(main_stream);
@@ -1031,7 +1043,7 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
         // allocation failure.
         auto bytes_needed = [&](int S_try) {
             const double lanes = (double)S_try * P;
-            const int wk = !samples_independent ? 1 : (tune.workers > 0 ? tune.workers : (lanes < (double)(1 << 20) ? 2 : 1));
+            const int wk = !samples_independent ? 1 : (tune.workers > 0 ? tune.workers : 2);
             // (measured, bunny_box at max_bounces 4: 2.9 KB per lane with ray differentials, 1.98 KB for the lean kernels, which keep
             //  neither them nor the uv / colour adjoints)
             double per_lane = (lean == kLean ? 260.0 * (B + 1) + 660.0 : 400.0 * (B + 1) + 1200.0) * wk;
@@ -1039,7 +1051,7 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
             if (d_image) per_lane += 4.0 * lay.nd;
             return per_lane * lanes;
         };
-        // Buffers that do not fit the buffer cache (exec::pool_cap_bytes: 16 GiB unless the caller raised it) are allocated and
+        // Buffers that do not fit the buffer cache (exec::pool_cap_bytes: 8 GiB unless the caller raised it) are allocated and
         // released by EVERY call, and device memory that another process has used before is scrubbed when it is handed out:
         // ~25 ms per GB on a box that has been in use (a fresh box allocates 48 GB in no time, which is how this went unnoticed
         // for a round).  The 256-spp benchmark in 16-sample batches (48 GB of buffers) ran at 64.3 Msamples/s on a fresh box and

@@ -846,6 +846,141 @@ template <bool PRELOAD> struct SecEdgePickH2 {        // the hierarchical pick w
         picks[idx] = SecPick{eid, ew, v3(0), v3(0)};
     }
 };
+// ---- the same pick in two launches (round 6): a resumable DESCENT with lane refill, then the leaves ------------------------
+// SecEdgePickH2 runs one slot per lane from its first root to its last leaf: a slot takes 20 ... 300 interior steps, the wave
+// waits for its longest lane (lane utilisation 0.60 at fp64 issue 0.82, profiles/r5_notes.md).  The descent consumes only
+// `sample`, the leaves only `resample` (pick_edge_hierarchical_deferred), so they separate cleanly:
+//   SecEdgePickHDescend  a walk (State / begin / step / finish) for exec::launch_chunked: a wave owns 256 consecutive list
+//                        positions and its idle lanes take the next ones (ballot + popcount, no atomics); a step pops ONE entry
+//                        -- an interior node is split, a leaf is recorded; finish() leaves the slot's hand-over record
+//                        (HDescent: shading position, LTC matrix, the reservoir's random number, number of leaves);
+//   SecEdgePickHLeaves   one lane per slot: importance of the recorded leaves in pop order, reservoir, SecPick.
+// Same operations on the same operands in the same order per slot as pick_edge_hierarchical_deferred: identical picks.
+struct HDescent { double pos[3], m_inv[9], resample; int nleaf, pad; };      // 112 B per list position
+template <bool PRELOAD> struct SecEdgePickHDescend {
+    SecEdgeArgs a; const int *slots; HLeaf *leaves, *spill; HDescent *out; int n;
+    struct State {
+        int i, sp, nleaf;
+        double sample, resample;
+        LtcCtx c;                   // (m is not used by the descent: the compiler drops it)
+        SilQuery q_pos;
+        RDR_WALK_STACK_MEMBER(int, st_ref, kHStackLds)
+        RDR_WALK_STACK_MEMBER(unsigned char, st_num, kHStackLds)
+        RDR_WALK_STACK_MEMBER(double, st_pmf, kHStackLds)
+    };
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void make_mid() { mid_scene(a.sc); }
+    RDR_DEV_FN void push(State &st, int r, int nn, double p) const {
+        auto st_ref = RDR_WALK_STACK(st, int, st_ref, kHStackLds, 11);
+        auto st_num = RDR_WALK_STACK(st, unsigned char, st_num, kHStackLds, 12);
+        auto st_pmf = RDR_WALK_STACK(st, double, st_pmf, kHStackLds, 13);
+        if (st.sp < kHStackLds) { RDR_WALK_AT(st_ref, st.sp) = r; RDR_WALK_AT(st_num, st.sp) = (unsigned char)nn; RDR_WALK_AT(st_pmf, st.sp) = p; }
+        else spill[(size_t)(st.sp - kHStackLds) * (size_t)n + st.i] = HLeaf{r, nn, p};
+        st.sp++;
+    }
+    RDR_DEV_FN bool begin(int i, State &st) const {
+        const EdgeSceneD &es = a.es;
+        const int idx = slots[i];
+        SecPre s = sec_prepare(a.sc, es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
+        st.i = i; st.sp = 0; st.nleaf = 0;
+        st.sample = s.edge_sel; st.resample = s.resample_sel;
+        st.c = s.lc;
+        st.q_pos = sil_query(es, s.lc.pos);
+        double imp_cs = es.cs_root != kNoEdgeTree ? 1.0 : 0.0, imp_ncs = es.ncs_root != kNoEdgeTree ? 1.0 : 0.0;
+        if (imp_cs <= 0 && imp_ncs <= 0) { st.nleaf = -1; return false; }            // no edge tree: the pick returns -1
+        double prob_cs = imp_cs / (imp_cs + imp_ncs), prob_ncs = 1 - prob_cs;
+        double exp_cs = kHSamples * prob_cs, exp_ncs = kHSamples * prob_ncs;
+        int n_cs = int(floor(exp_cs)), n_ncs = int(floor(exp_ncs));
+        if (n_cs + n_ncs < kHSamples) {
+            double prob = exp_cs - n_cs;
+            if (st.sample < prob) { n_cs++; st.sample /= prob; }
+            else { n_ncs++; st.sample = (st.sample - prob) / (1 - prob); }
+        }
+        if (n_cs > 0) push(st, es.cs_root, n_cs, prob_cs);
+        if (n_ncs > 0) push(st, es.ncs_root, n_ncs, prob_ncs);
+        return st.sp > 0;
+    }
+    RDR_DEV_FN bool step(State &st) const {
+        const EdgeSceneD &es = a.es;
+        auto st_ref = RDR_WALK_STACK(st, int, st_ref, kHStackLds, 11);
+        auto st_num = RDR_WALK_STACK(st, unsigned char, st_num, kHStackLds, 12);
+        auto st_pmf = RDR_WALK_STACK(st, double, st_pmf, kHStackLds, 13);
+        --st.sp;
+        HItem it;
+        if (st.sp < kHStackLds) it = HItem{RDR_WALK_AT(st_ref, st.sp), (int)RDR_WALK_AT(st_num, st.sp), RDR_WALK_AT(st_pmf, st.sp)};
+        else { const HLeaf sl = spill[(size_t)(st.sp - kHStackLds) * (size_t)n + st.i]; it = HItem{sl.ref, sl.num, sl.pmf}; }
+        if (it.ref < 0) {
+            leaves[(size_t)st.nleaf * (size_t)n + st.i] = HLeaf{it.ref, it.num, it.pmf};
+            st.nleaf++;
+            return st.sp == 0;
+        }
+        const EdgeNodeP nd_line = PRELOAD ? load_node_line(&edge_node(es, it.ref)) : EdgeNodeP();
+        const EdgeNodeP &nd = PRELOAD ? nd_line : edge_node(es, it.ref);
+        const int tree = it.ref & kEdgeTreeBit;
+        const bool tree3d = tree == 0;
+        int c0 = nd.c_ref[0] < 0 ? nd.c_ref[0] : (nd.c_ref[0] | tree);
+        int c1 = nd.c_ref[1] < 0 ? nd.c_ref[1] : (nd.c_ref[1] | tree);
+        double i0, i1;
+        if (box_contains(v3_of(nd.p_min), v3_of(nd.p_max), st.c.pos)) { i0 = i1 = 1; }
+        else { i0 = node_importance(nd, 0, tree3d, st.c, st.q_pos); i1 = node_importance(nd, 1, tree3d, st.c, st.q_pos); }
+        if (i0 > 0 || i1 > 0) {
+            double p0 = i0 / (i0 + i1), p1 = 1 - p0;
+            double e0 = it.num * p0, e1 = it.num * p1;
+            int s0 = int(floor(e0)), s1 = int(floor(e1));
+            if (s0 + s1 < it.num) {
+                double prob = e0 - s0;
+                if (st.sample < prob) { s0++; st.sample /= prob; }
+                else { s1++; st.sample = (st.sample - prob) / (1 - prob); }
+            }
+            if (s0 > 0 && st.sp + st.nleaf < kHSamples) push(st, c0, s0, it.pmf * p0);
+            if (s1 > 0 && st.sp + st.nleaf < kHSamples) push(st, c1, s1, it.pmf * p1);
+        }
+        return st.sp == 0;
+    }
+    RDR_DEV_FN void finish(State &st) const {
+        HDescent d;
+        d.pos[0] = st.c.pos.x; d.pos[1] = st.c.pos.y; d.pos[2] = st.c.pos.z;
+        for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) d.m_inv[3 * r + k] = st.c.m_inv.m[r][k];
+        d.resample = st.resample; d.nleaf = st.nleaf; d.pad = 0;
+        out[st.i] = d;
+    }
+};
+struct SecEdgePickHLeaves {
+    SecEdgeArgs a; const int *slots; SecPick *picks; const HLeaf *leaves; const HDescent *in; int n;
+    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
+    RDR_FN void make_mid() { mid_scene(a.sc); }
+    RDR_FN void operator()(int i) const {
+        const int idx = slots[i];
+        const HDescent d = in[i];
+        LtcCtx c;
+        c.pos = V3{d.pos[0], d.pos[1], d.pos[2]};
+        for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { c.m_inv.m[r][k] = d.m_inv[3 * r + k]; c.m.m[r][k] = 0; }
+        double resample = d.resample;
+        int selected = -1;
+        double edge_w = 0, wsum = 0;
+        for (int j = 0; j < d.nleaf; ++j) {
+            const HLeaf it = leaves[(size_t)j * (size_t)n + i];
+            const int leaf_edge = ~it.ref;
+            double w = it.num * leaf_importance_h(a.sc, a.es, leaf_edge, c) / it.pmf;
+            if (w > 0) {
+                double prev = wsum;
+                wsum += w;
+                double nw = w / wsum;
+                if (resample <= nw || prev == 0) {
+                    selected = leaf_edge;
+                    edge_w = w * it.pmf;
+                    resample /= nw;
+                } else {
+                    resample = (resample - nw) / (1 - nw);
+                }
+            }
+        }
+        int eid = -1;
+        double ew = 0;
+        if (d.nleaf >= 0 && !(edge_w <= 0 || wsum <= 0)) { ew = 1 / (edge_w * kHSamples / wsum); eid = selected; }
+        picks[idx] = SecPick{eid, ew, v3(0), v3(0)};
+    }
+};
 // The NEE-mode pick as a resumable walk for exec::launch_persistent: same tests in the same order as
 // the reference's sample_edge_l (src/edge.cpp:1239-1364), one popped reference per step.
 constexpr int kPickOverflow = -2;     // SecPick::eid of a slot the gather hands to the reference-order walk

@@ -426,10 +426,15 @@ def _use_torch_stream(lib, use_gpu, gpu_index=None):
 
 
 def set_pool_cap_mb(megabytes):
-    """Not in the reference: bound of the library's buffer cache per device (default min(a quarter of the device, 16 GiB)).
+    """Not in the reference: bound of the library's buffer cache per device (default min(a quarter of the device, 8 GiB)).
     A dedicated render process may raise it (e.g. 65536) so that the buffers of a 2^24-lane sample batch stay parked
     between calls; negative = back to the default."""
     _capi.lib().rdr_set_pool_cap_mb(int(megabytes))
+
+
+def get_pool_cap_mb():
+    """Not in the reference: the bound of the buffer cache in effect (MiB)."""
+    return int(_capi.lib().rdr_get_pool_cap_mb())
 
 
 def set_build_flags(flags):

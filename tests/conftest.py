@@ -9,11 +9,14 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
 
 
-# The parity tests hold the GPU to the oracle sample for sample, also where a transcendental function feeds a chaotic decision
-# (fisheye / panorama cameras + the hierarchical edge pick): they load the build whose kernels compute sin / cos / ... as glibc
-# does (libredner_amd_exact.so; include/redner_amd.h: rdr_libm_exact).  Subprocesses started by tests inherit the choice.
-# tests/test_default_library_gpu.py covers the default build (the device's own libm), which bench.py and smoke() run.
-os.environ.setdefault('REDNER_AMD_LIBM', 'exact')
+# Two builds of the product library exist: libredner_amd.so (the device's own sin / cos / ...: what
+# bench.py, smoke() and users run) and libredner_amd_exact.so (glibc-exact transcendental functions: sample-exact against the
+# oracle also where such a function feeds a chaotic decision).  EVERY test that takes `gpu_backend` runs on BOTH (round 6;
+# "the library that is timed is not the library that is fuzzed"); the fixture sets REDNER_AMD_LIBM for the
+# subprocesses tests start.  parity_util.DEFAULT_BUILD_DRAWS_OTHER_SAMPLES lists, explicitly, the cases in which the default
+# build may legitimately draw other (equally valid) edge samples, and what they are held to instead.
+# RDR_TEST_LIBM=exact|default restricts a run to one build.
+GPU_BUILDS = [b for b in ('exact', 'default') if os.environ.get('RDR_TEST_LIBM', b) == b]
 
 
 def pytest_configure(config):
@@ -36,14 +39,21 @@ def hostsim_backend():
     yield redner
 
 
-@pytest.fixture(scope='session')
-def gpu_backend():
-    """The product: libredner_amd.so on cuda:0.  Fails loudly if it is not what got loaded."""
+@pytest.fixture(scope='session', params=GPU_BUILDS)
+def gpu_backend(request):
+    """The product on cuda:0 -- libredner_amd_exact.so, then libredner_amd.so (session-scoped parameter: pytest groups the tests
+    by build).  Fails loudly if it is not what got loaded."""
     import torch
     from redner_amd import _capi
     assert torch.cuda.is_available(), 'gpu tests need a GPU'
-    _capi.load()          # redner_amd/lib/libredner_amd_exact.so (REDNER_AMD_LIBM=exact, above)
+    os.environ.pop('REDNER_AMD_LIB', None)
+    if request.param == 'exact':
+        os.environ['REDNER_AMD_LIBM'] = 'exact'
+    else:
+        os.environ.pop('REDNER_AMD_LIBM', None)
+    _capi.load()
     assert _capi.is_product_library(), _capi.library_path()
-    assert _capi.lib().rdr_libm_exact() == (1 if os.environ.get('REDNER_AMD_LIBM') == 'exact' else 0)
+    assert _capi.library_path() == (_capi.EXACT_LIBRARY if request.param == 'exact' else _capi.DEFAULT_LIBRARY)
+    assert _capi.lib().rdr_libm_exact() == (1 if request.param == 'exact' else 0)
     from redner_amd import redner
     return redner

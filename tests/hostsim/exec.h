@@ -35,6 +35,20 @@ inline void shadow_add(double *p, double v) {
     F32Shadow &s = f32_shadow();
     if (s.base && p >= s.base && p < s.base + s.count) s.acc[(size_t)(p - s.base)] += (float)v;
 }
+// The three places GradStore (render.cpp) tells its accumulator backend about: the small tier has been laid out; a small
+// tensor is about to be folded into the caller's floats; the fold is done.  (hip/exec.h: empty bodies.)
+inline void accumulators_laid_out(double *small_base, size_t small_stride) {
+    f32_shadow() = F32Shadow();
+    if (std::getenv("RDR_HOSTSIM_REF_ORDER") && small_stride) {
+        f32_shadow().base = small_base; f32_shadow().count = small_stride;
+        f32_shadow().acc.assign(small_stride, 0.f);
+    }
+}
+inline void accumulator_before_fold(double *small_base, double *acc, size_t count) {     // reference-order mode: the floats, not the fp64 sums
+    if (f32_shadow().base && f32_shadow().base == small_base && count <= 16)
+        for (size_t i = 0; i < count; ++i) acc[i] = (double)f32_shadow().acc[(size_t)(acc - small_base) + i];
+}
+inline void accumulators_folded() { f32_shadow() = F32Shadow(); }
 inline void accum(double *p, double v) { *p += v; shadow_add(p, v); }
 inline void accum_plain(double *p, double v) { *p += v; shadow_add(p, v); }
 inline void accum_triple(double *p, double x, double y, double z) { p[0] += x; shadow_add(p, x); p[1] += y; shadow_add(p + 1, y); p[2] += z; shadow_add(p + 2, z); }
@@ -106,6 +120,8 @@ inline void launch_persistent(Count c, const W &w) {          // see hip/exec.h:
         w.finish(st);
     }
 }
+template <class W>
+inline void launch_chunked(Count c, const W &w, int = 4, int = 16, int = 8) { launch_persistent(c, w); }     // (hip/exec.h: wave-local refill)
 } // namespace exec
 
 // ---- host stand-ins for the hand-written kernels (compact.hip / trace.hip) ----------------------
@@ -131,7 +147,7 @@ inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const 
     if (dyn && n_in > 0) *dyn += inc;
     return Count(result, n.upper + (append_at ? append_at->upper : 0));
 }
-struct TraceStats { double closest_ms = 0, any_ms = 0; uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes[2] = {0, 0}, tris[2] = {0, 0}, wide_nodes[2] = {0, 0}; bool timing = false, counting = false; };
+struct TraceStats { double closest_ms = 0, any_ms = 0, closest_union_ms = 0, any_union_ms = 0; uint64_t closest_launches = 0, any_launches = 0, closest_rays = 0, any_rays = 0, nodes[2] = {0, 0}, tris[2] = {0, 0}, wide_nodes[2] = {0, 0}; bool timing = false, counting = false; };
 inline TraceStats &trace_stats() { static TraceStats s; return s; }
 inline void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count cnt_n, bool any, bool = false) {
     const int n = cnt_n.value();

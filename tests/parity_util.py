@@ -15,6 +15,29 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 TOL = 1e-4           # BASELINE.json north_star: 1e-4 relative L2, forward image and every gradient tensor
 
 
+# ---- what the DEFAULT build (libredner_amd.so: the device's own sin / cos / atan2 / acos / pow) is held to -----------------------
+# Every GPU test runs on both builds (tests/conftest.py: gpu_backend).  The default build meets the same bars as the exact one --
+# image bit for bit, every gradient tensor to 1e-4 -- EXCEPT where a transcendental function feeds the chaotic hierarchical edge
+# pick (src/edge.cpp:1160-1230: one random number through ~100 rescalings): ocml and glibc differ in the last bit of a few per
+# cent of results, the pick lands on another edge, and the gradient is another, equally valid, draw of the same estimator.
+# The complete list of what may differ, and what holds instead:
+DEFAULT_BUILD_DRAWS_OTHER_SAMPLES = {
+    # fixture: why -> on the default build the forward image is still held to 1e-6 and the gradients to the statistical test
+    # (tests/test_statistical_parity.py: 24 seeds, paired z < 5 against the oracle's per-seed functionals)
+    'bunny_box_fisheye_32x32x4': 'fisheye primary rays: sin / cos / atan2 decide the first-hit position the secondary-edge pick starts from',
+    'bunny_box_panorama_32x32x4': 'panorama primary rays: sin / cos decide the first-hit position the secondary-edge pick starts from',
+}
+# random scenes against the live oracle (tests/test_fuzz_parity.py): glossy bounces go through pow / sin / cos; scenes per leg
+# (of ~107) in which ONE OR TWO edge samples may land on another edge (<= 4 vertex rows move, everything else agrees: _edge_flip)
+DEFAULT_BUILD_FUZZ_FLIPS_PER_LEG = 2        # the exact build: 0
+
+
+def libm_exact():
+    """Is the loaded library the glibc-exact build?"""
+    from redner_amd import _capi
+    return bool(_capi.lib().rdr_libm_exact())
+
+
 ACCUMULATOR_ELEMS = 16   # tensors this small (light intensity, constant reflectance, camera) collect millions of fp32 atomics
 
 

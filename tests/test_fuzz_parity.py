@@ -747,9 +747,12 @@ def test_random_scenes_gpu_vs_oracle(gpu_backend, variant):
     assert json.loads(grab('FUZZ')) == {}, (grab('FUZZ')[:3000], 'oracle not reproducible: %s' % unstable, 'flips: %s' % flips)
     assert scenes >= 60
     # Rounds 1-3 allowed two scenes per leg in which a single edge sample landed on another edge (_edge_flip: the device's
-    # sin / cos / pow were not glibc's).  They are now (csrc/libm_exact.h): the three legs of the first run with them had none
-    # (profiles/r4_parity_report_final.jsonl), and none is allowed -- the classifier stays, to say WHAT a failure looks like.
-    assert flips == {}, flips
+    # sin / cos / pow were not glibc's).  In the exact build they are (csrc/libm_exact.h) and none is allowed; the default build
+    # -- the device's own libm -- gets the old budget, stated in parity_util.DEFAULT_BUILD_FUZZ_FLIPS_PER_LEG (first full run of
+    # the three legs on it, round 6: one scene in one leg, `mesh 118`, two rows each in two shapes).
+    from parity_util import DEFAULT_BUILD_FUZZ_FLIPS_PER_LEG, libm_exact
+    allowed = 0 if libm_exact() else DEFAULT_BUILD_FUZZ_FLIPS_PER_LEG
+    assert len(flips) <= allowed, flips
 
 
 if __name__ == '__main__':

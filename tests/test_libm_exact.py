@@ -136,6 +136,9 @@ def test_libm_exact_cpu_harness(name, hostsim_backend):
 def test_libm_exact_gpu(name, gpu_backend):
     """The routines as the kernels run them on gfx950 (one argument per lane through rdr_debug_libm): bit-equal to the glibc
     of the box's host -- the library the oracle calls there."""
+    from redner_amd import _capi
+    if not _capi.lib().rdr_libm_exact():
+        pytest.skip("the default build computes these with the device's own libm (ocml): nothing to hold to glibc")
     x, y = arguments(name, 1500000)
     assert_bit_equal(name, x, y, glibc_values(name, x, y), library_values(name, x, y))
 

@@ -55,7 +55,7 @@ def _json_line(stdout):
 
 
 @pytest.mark.gpu
-def test_bench_one_rank_under_launcher_runs_the_collective_over_rccl(gpu_backend):
+def test_bench_one_rank_under_launcher_runs_the_collective_over_rccl():
     env = _clean_env(REDNER_AMD_FORCE_COLLECTIVE='1', NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,COLL')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--spp', '32', '--steps', '1',
@@ -146,7 +146,7 @@ def test_render_sharded_in_a_one_rank_nccl_group_equals_the_plain_render(gpu_bac
 
 
 @pytest.mark.gpu
-def test_eight_rank_rehearsal_on_one_gpu(gpu_backend):
+def test_eight_rank_rehearsal_on_one_gpu():
     """The driver's 8-GPU command line at the real world size, ranks sharing the one GPU (gloo): 8 x 2 spp of the 1024 x 1024
     frame.  Not a measurement -- a rehearsal of everything around the kernels: self-launch, rendezvous, rank -> sample block,
     per-rank pool and host-thread caps, the gathered sum against the same blocks on one device."""

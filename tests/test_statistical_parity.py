@@ -63,6 +63,9 @@ def test_stat_functionals_gpu(gpu_backend, name):
                                 'z_unpaired_max': float(z_unpaired.max()), 'share_identical': share_equal}) + '\n')
     assert z_paired.max() < 5.0, z_paired
     assert z_unpaired.max() < 4.0, z_unpaired
+    from parity_util import libm_exact
+    if not libm_exact():
+        return            # the default build draws other, equally valid edge samples here: the z-scores above are its bar
     # sample for sample, like the CPU harness: the kernels' sin / cos / atan2 are glibc's (tests/test_libm_exact.py)
     scale = np.abs(gold).max(0)
     assert np.all(np.abs(mine - gold) <= 1e-4 * scale), (np.abs(mine - gold) / scale).max(0)

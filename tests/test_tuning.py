@@ -23,6 +23,8 @@ SCHEDULES = {
     'pickn_walk': {'flags': K.TUNE_PICKN_WALK},
     'pickh_fused': {'flags': K.TUNE_PICKH_FUSED},
     'pickh_lazy': {'flags': K.TUNE_PICKH_LAZY},
+    'pickh_one_launch': {'flags': K.TUNE_PICKH_ONE_LAUNCH},
+    'pickh_one_launch_lazy': {'flags': K.TUNE_PICKH_ONE_LAUNCH | K.TUNE_PICKH_LAZY},
     'gather_hand_over': {'gather_budget': 2, 'gather_heavy_cap_plus1': 4, 'gather_work_cap_plus1': 6},
     'gather_no_lists': {'gather_budget': 1, 'gather_heavy_cap_plus1': 1, 'gather_work_cap_plus1': 1},
     'little_memory': {'mem_available_mb': 8},
