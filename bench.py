@@ -154,8 +154,22 @@ def cpu_baseline(a, gpu_rd=None, gpu_dev=None):
             check = {'job': '%s %dx%d, %d spp fwd+bwd' % (a.workload, res, res, spp), 'image_rel_l2': _rel_l2(g.img, p.img),
                      'worst_per_vertex_gradient_rel_l2': max(big, default=0.0),
                      'worst_few_element_gradient_rel_l2': max(few, default=0.0), 'tensors': len(errs),
-                     'note': 'single reference pass: its few-element tensors (light, reflectances, camera) carry the fp32-atomics '
-                             'error the ref64 fixtures take out (tests/golden/make_golden.py)'}
+                     'few_element_reference': 'the single reference pass of this run: its few-element tensors (light, reflectances, '
+                                              'camera) carry the error of its fp32 atomics'}
+            # ... which a committed fixture takes out for exactly this job (tests/golden/make_ref_order.py --bench-job): the fp64
+            # sum of the reference's own addends (its floats in reference order equal the one-thread reference bit for bit)
+            fix = os.path.join(ROOT, 'tests', 'golden', 'bench_job_bunny_box_1024x1024x1_ref_order.npz')
+            if (a.workload, res, spp, a.max_bounces) == ('bunny_box', 1024, 1, 4) and os.path.exists(fix):
+                import numpy as np
+                z = np.load(fix)
+                vs64 = [_rel_l2(gt, torch.from_numpy(z['harness64_g%d' % i])) for i, gt in enumerate(g.grads)
+                        if 'harness64_g%d' % i in z.files and float(np.abs(z['harness64_g%d' % i]).sum()) > 0]
+                if vs64:
+                    check['worst_few_element_gradient_rel_l2_vs_single_reference_pass'] = check['worst_few_element_gradient_rel_l2']
+                    check['worst_few_element_gradient_rel_l2'] = max(vs64)
+                    check['few_element_reference'] = ('fp64 sum of the reference\'s addends for this job (committed fixture, '
+                                                      'tests/golden/make_ref_order.py --bench-job; %d tensors)' % len(vs64))
+                    check['ok'] = bool(check['image_rel_l2'] == 0.0 and check['worst_per_vertex_gradient_rel_l2'] < 1e-4 and max(vs64) < 1e-4)
             del g
         # at least `min_reps` passes, each timed on its own, while the sample stays within its budget of CPU seconds
         while len(times) < min_reps and sum(times) + min(times) < budget:
@@ -256,6 +270,59 @@ def sharded_self_check(a, rd, dev):
     e_grad = max((_rel_l2(x, y) for x, y in zip(acc, grads) if float(y.abs().sum()) > 0), default=0.0)
     return {'job': '%s %dx%d, %d spp in %d sample blocks vs one call' % (a.workload, a.res, a.res, spp, blocks),
             'image_rel_l2': e_img, 'worst_gradient_rel_l2': e_grad, 'ok': bool(e_img < 2e-6 and e_grad < 1e-4)}
+
+
+def large_hierarchy_leg(levels=4, spp=8, res=1024, max_bounces=4):
+    """Untimed: the closest-hit kernel on a hierarchy that does NOT fit the L2 -- bunny_box with the bunny tessellated to 3.7 M
+    triangles (tests/scenes.py: bunny_box_subdivided; ~250 MB of node + triangle records against 4 MiB of L2 per XCD), forward
+    render of the same frame (camera rays + four bounces of cosine-distributed rays: the queue kinds of the benchmark).  Same
+    accounting as `roofline`: records per ray from the instrumented kernel, launch durations from HIP events."""
+    import scenes
+    from redner_amd import _capi, redner
+    from redner_amd.render_pytorch import RenderFunction
+    lib = _capi.lib()
+    dev = torch.device('cuda:0')
+    t0 = time.time()
+    sc = scenes.bunny_box_subdivided(dev, resolution=(res, res), levels=levels)
+    torch.cuda.synchronize(dev)
+    t_mesh = time.time() - t0
+    tris = sum(int(s.indices.shape[0]) for s in sc.shapes)
+    args = RenderFunction.serialize_scene(sc, spp, max_bounces, sampler_type=redner.SamplerType.sobol, device=dev, backend=redner,
+                                          use_primary_edge_sampling=False, use_secondary_edge_sampling=False)
+    t0 = time.time()
+    u = RenderFunction.unpack_args((1, 2), args[0], args[1:])
+    torch.cuda.synchronize(dev)
+    t_scene = time.time() - t0
+    img = torch.zeros(res, res, 3, device=dev)
+
+    def forward():
+        img.zero_()
+        redner.render(u.scene, u.options, redner.float_ptr(img.data_ptr()), redner.float_ptr(0), None, redner.float_ptr(0), redner.float_ptr(0))
+        torch.cuda.synchronize(dev)
+    forward()                                   # warm-up (buffers)
+    lib.rdr_trace_stats_enable(1, 0)
+    trace_stats(reset=True)
+    t0 = time.time()
+    forward()
+    t_fwd = time.time() - t0
+    st = trace_stats()
+    lib.rdr_trace_stats_enable(0, 1)
+    trace_stats(reset=True)
+    forward()
+    cnt = trace_stats()
+    lib.rdr_trace_stats_enable(0, 0)
+    rays = cnt.closest_rays
+    alg = rays * (RAY_BYTES + HIT_BYTES) + cnt.closest_nodes * NODE_BYTES + cnt.closest_wide_nodes * WIDE_NODE_BYTES + cnt.closest_tris * TRI_BYTES
+    busy = st.closest_union_ms if st.closest_union_ms > 0 else st.closest_ms
+    achieved = alg / (busy * 1e-3) / 1e9 if busy > 0 else 0.0
+    return {'workload': 'bunny_box_subdivided (levels %d): %d triangles, %dx%d, %d spp forward, max_bounces %d' % (levels, tris, res, res, spp, max_bounces),
+            'triangles': tris, 'hierarchy_bytes_estimate': tris * TRI_BYTES + 2 * (tris // 2) * NODE_BYTES,
+            'mesh_s': t_mesh, 'scene_build_ms': t_scene * 1e3, 'forward_ms': t_fwd * 1e3, 'image_mean': float(img.mean()),
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'closest_launches': st.closest_launches, 'busy_ms': busy, 'mean_launch_ms': st.closest_ms / max(st.closest_launches, 1),
+            'rays': rays, 'rays_per_s': rays / (busy * 1e-3) if busy > 0 else None,
+            'nodes_per_ray': cnt.closest_nodes / max(rays, 1), 'wide_nodes_per_ray': cnt.closest_wide_nodes / max(rays, 1),
+            'tris_per_ray': cnt.closest_tris / max(rays, 1), 'algorithmic_bytes': alg}
 
 
 def alone_leg(st, alg_bytes_launch):

@@ -432,50 +432,61 @@ __global__ void __launch_bounds__(256) persistent_kernel(W w, int n, const int *
         }
     }
 }
-// The same walk protocol with WAVE-LOCAL refill (the scheme of trace_refill_kernel, trace.hip): a wave owns 64 x K consecutive
-// items and its idle lanes take the next unclaimed ones of that chunk -- a ballot and a popcount, no atomic, no counter to
-// zero; items that are neighbours in the list (neighbouring pixels: walks of similar length and the same tree nodes) stay in
-// one wave.  For walks that are long and uneven but not heavy-tailed (the hierarchical edge pick: 20 ... 300 steps).
+// The same walk protocol with WAVE-LOCAL refill (the scheme of trace_refill_kernel, trace.hip) over chunks that the waves take
+// off a global counter: a wave owns 64 x K consecutive items at a time and its idle lanes take the next unclaimed ones of that
+// chunk -- a ballot and a popcount; when the chunk is handed out the wave takes the next chunk (ONE atomic per 64 K items:
+// 16 k per 4 M items, where persistent_kernel above issues one per refill) while its busy lanes go on, so no lane waits for the
+// longest walk of a chunk, only for the longest walk of the launch.  Items that are neighbours in the list (neighbouring pixels:
+// walks of similar length through the same tree nodes) stay in one wave.  For walks that are long and uneven (the hierarchical
+// edge pick: 20 ... 300 steps).
 template <class W>
-__global__ void __launch_bounds__(256) chunked_kernel(W w, int n, const int *count, int items_per_lane, int idle_min, int steps) {
+__global__ void __launch_bounds__(256) chunked_kernel(W w, int n, const int *count, int items_per_lane, int idle_min, int steps, int *next_chunk) {
     if (count) { const int c = *count; n = c < n ? c : n; }
     const int chunk = 64 * items_per_lane;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long first = ((long long)blockIdx.x * 4 + wave) * chunk;
-    if (first >= n) return;
-    const int end = (int)(first + chunk < n ? first + chunk : n);
-    int next = (int)first;                                  // wave-uniform
+    const int lane = threadIdx.x & 63;
+    int next = 0, end = 0;                                  // wave-uniform: the part of the current chunk not handed out yet
+    bool more = true;                                       // chunks may be left on the counter
     typename W::State st;
     bool busy = false;
     for (;;) {
         const unsigned long long idle = __ballot(!busy);
         const int nidle = __popcll(idle);
-        if (next < end && (nidle >= idle_min || nidle == 64)) {
-            if (!busy) {
-                const int item = next + __popcll(idle & ((1ull << lane) - 1ull));
-                if (item < end) {
-                    if (w.begin(item, st)) busy = true;
-                    else w.finish(st);
-                }
+        if (nidle >= idle_min || nidle == 64) {
+            if (next >= end && more) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(next_chunk, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) more = false;
+                else { next = base; end = base + chunk < n ? base + chunk : n; }
             }
-            next += nidle;
+            if (next < end) {
+                if (!busy) {
+                    const int item = next + __popcll(idle & ((1ull << lane) - 1ull));
+                    if (item < end) {
+                        if (w.begin(item, st)) busy = true;
+                        else w.finish(st);
+                    }
+                }
+                next += nidle;
+            }
         }
-        if (__ballot(busy) == 0ull) { if (next >= end) break; continue; }
+        if (__ballot(busy) == 0ull) { if (next >= end && !more) break; continue; }
 #pragma unroll 1
         for (int it = 0; it < steps; ++it) {
             if (busy && w.step(st)) { w.finish(st); busy = false; }
         }
     }
 }
+int *persistent_counter();          // trace.hip: ring of zeroed ints, one per launch
 template <class W>
 inline void launch_chunked(Count n, const W &w, int items_per_lane = 4, int idle_min = 16, int steps = 8) {
     if (n.upper <= 0) return;
     const int per_block = 4 * 64 * items_per_lane;
-    const int blocks = (int)(((long long)n.upper + per_block - 1) / per_block);
-    hipLaunchKernelGGL(chunked_kernel<W>, dim3(blocks), dim3(256), 0, ctx().stream, w, n.upper, n.dev, items_per_lane, idle_min, steps);
+    // as many workgroups as there are chunks of four, but no more than a few per CU: later ones would find the counter exhausted
+    const int blocks = (int)std::min<long long>(((long long)n.upper + per_block - 1) / per_block, 256 * 6);
+    hipLaunchKernelGGL(chunked_kernel<W>, dim3(blocks), dim3(256), 0, ctx().stream, w, n.upper, n.dev, items_per_lane, idle_min, steps, persistent_counter());
     check(hipGetLastError(), "chunked launch");
 }
-int *persistent_counter();          // trace.hip: ring of zeroed ints, one per launch
 template <class W>
 inline void launch_persistent(Count n, const W &w) {
     if (n.upper <= 0) return;

@@ -648,7 +648,7 @@ struct Backward {
             const int need = es.max_stack;
             exec::Count nH(0), nN(0);
             auto lists = [&] {
-                launch_v(lean, nA, SecEdgeSetup{sa, sec_mode, sec_recs, sec_picks, ea, edge_tmin});
+                launch_v(lean, nA, SecEdgeSetup{sa, sec_mode, sec_recs, sec_picks, ea, edge_tmin, (pickh_fused || pickh_one_launch) ? nullptr : h_descent});
                 nH = exec::compact_dev((const int *)nullptr, nA, elist[0], KeepMode{sec_mode, 1});
                 const exec::Count nN2 = exec::compact_dev((const int *)nullptr, nA, nee_slots, KeepMode{sec_mode, 2});
                 nN = exec::compact_dev((const int *)nullptr, nA, nee_slots, KeepMode{sec_mode, 3}, &nN2);   // dense-shape slots after the others
@@ -669,8 +669,15 @@ struct Backward {
                         else if (lean == kMid) exec::launch_chunked(nH, MidWalk<decltype(walk)>{walk}, pickh_k, pickh_idle, pickh_steps);
                         else exec::launch_chunked(nH, walk, pickh_k, pickh_idle, pickh_steps);
                     };
-                    if (pickh_lazy) descend(SecEdgePickHDescend<false>{sa, elist[0], h_leaves, h_spill, h_descent, nH.upper});
-                    else descend(SecEdgePickHDescend<true>{sa, elist[0], h_leaves, h_spill, h_descent, nH.upper});
+                    if (pickh_lazy) descend(SecEdgePickHDescend<false>{sa.es, elist[0], h_leaves, h_spill, h_descent, nH.upper});
+                    else descend(SecEdgePickHDescend<true>{sa.es, elist[0], h_leaves, h_spill, h_descent, nH.upper});
+                    static const bool leaves_walk = std::getenv("RDR_PICKH_LEAVES_WALK") != nullptr;       // (experiments)
+                    if (leaves_walk) {
+                        const SecEdgePickHLeavesWalk lw{sa.sc, sa.es, elist[0], sec_picks, h_leaves, h_descent, nH.upper};
+                        if (lean == kLean) exec::launch_chunked(nH, LeanWalk<SecEdgePickHLeavesWalk>{lw}, pickh_k, pickh_idle, 2);
+                        else if (lean == kMid) exec::launch_chunked(nH, MidWalk<SecEdgePickHLeavesWalk>{lw}, pickh_k, pickh_idle, 2);
+                        else exec::launch_chunked(nH, lw, pickh_k, pickh_idle, 2);
+                    } else
                     launch_v(lean, nH, SecEdgePickHLeaves{sa, elist[0], sec_picks, h_leaves, h_descent, nH.upper});
                 }
             };

@@ -788,8 +788,12 @@ struct SecEdgeArgs {          // what every stage of the sampler needs
 // mode[slot]: 0 = no sample, 1 = hierarchical pick, 2 / 3 = NEE-billboard pick (3: the vertex lies on a shape with at least
 // kDenseShapeTriangles triangles).  Also resets the slot's outputs.
 constexpr int kDenseShapeTriangles = 512;
+// What the slot set-up hands to the hierarchical pick (SecEdgePickHDescend / SecEdgePickHLeaves below): shading position, LTC
+// matrix and the two random numbers of the pick -- sec_prepare's results, computed once here instead of again in the pick.
+struct HDescent { double pos[3], m_inv[9], sample, resample; int nleaf, pad; };      // 120 B per slot
 struct SecEdgeSetup {
     SecEdgeArgs a; unsigned char *mode; SecondaryEdgeRec *recs; SecPick *picks; VSlice ev; double *edge_tmin;
+    HDescent *hd = nullptr;         // null: the one-launch forms of the pick (they call sec_prepare themselves)
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(ev); }
     RDR_FN void make_mid() { mid_scene(a.sc); }
     RDR_FN void operator()(int idx) const {
@@ -815,6 +819,13 @@ struct SecEdgeSetup {
         // the gather holds slots of one kind (its lanes otherwise idle through the longest walk of their wave)
         const bool dense = s.live && s.c.shape->num_triangles >= kDenseShapeTriangles;
         mode[idx] = !s.live ? 0 : (s.use_nee ? (dense ? 3 : 2) : 1);
+        if (hd && s.live && !s.use_nee) {
+            HDescent d;
+            d.pos[0] = s.lc.pos.x; d.pos[1] = s.lc.pos.y; d.pos[2] = s.lc.pos.z;
+            for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) d.m_inv[3 * r + k] = s.lc.m_inv.m[r][k];
+            d.sample = s.edge_sel; d.resample = s.resample_sel; d.nleaf = 0; d.pad = 0;
+            hd[idx] = d;
+        }
     }
 };
 struct KeepMode {
@@ -852,24 +863,24 @@ template <bool PRELOAD> struct SecEdgePickH2 {        // the hierarchical pick w
 // `sample`, the leaves only `resample` (pick_edge_hierarchical_deferred), so they separate cleanly:
 //   SecEdgePickHDescend  a walk (State / begin / step / finish) for exec::launch_chunked: a wave owns 256 consecutive list
 //                        positions and its idle lanes take the next ones (ballot + popcount, no atomics); a step pops ONE entry
-//                        -- an interior node is split, a leaf is recorded; finish() leaves the slot's hand-over record
-//                        (HDescent: shading position, LTC matrix, the reservoir's random number, number of leaves);
+//                        -- an interior node is split, a leaf is recorded; begin() reads the slot's HDescent record (what
+//                        SecEdgeSetup's sec_prepare found: shading position, LTC matrix, the two random numbers of the pick
+//                        -- the one-launch form computed sec_prepare a second time), finish() adds the number of leaves;
 //   SecEdgePickHLeaves   one lane per slot: importance of the recorded leaves in pop order, reservoir, SecPick.
 // Same operations on the same operands in the same order per slot as pick_edge_hierarchical_deferred: identical picks.
-struct HDescent { double pos[3], m_inv[9], resample; int nleaf, pad; };      // 112 B per list position
 template <bool PRELOAD> struct SecEdgePickHDescend {
-    SecEdgeArgs a; const int *slots; HLeaf *leaves, *spill; HDescent *out; int n;
+    EdgeSceneD es; const int *slots; HLeaf *leaves, *spill; HDescent *hd; int n;
     struct State {
-        int i, sp, nleaf;
-        double sample, resample;
-        LtcCtx c;                   // (m is not used by the descent: the compiler drops it)
+        int i, idx, sp, nleaf;
+        double sample;
+        LtcCtx c;
         SilQuery q_pos;
         RDR_WALK_STACK_MEMBER(int, st_ref, kHStackLds)
         RDR_WALK_STACK_MEMBER(unsigned char, st_num, kHStackLds)
         RDR_WALK_STACK_MEMBER(double, st_pmf, kHStackLds)
     };
-    RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); }
-    RDR_FN void make_mid() { mid_scene(a.sc); }
+    RDR_FN void make_lean() {}
+    RDR_FN void make_mid() {}
     RDR_DEV_FN void push(State &st, int r, int nn, double p) const {
         auto st_ref = RDR_WALK_STACK(st, int, st_ref, kHStackLds, 11);
         auto st_num = RDR_WALK_STACK(st, unsigned char, st_num, kHStackLds, 12);
@@ -879,13 +890,13 @@ template <bool PRELOAD> struct SecEdgePickHDescend {
         st.sp++;
     }
     RDR_DEV_FN bool begin(int i, State &st) const {
-        const EdgeSceneD &es = a.es;
-        const int idx = slots[i];
-        SecPre s = sec_prepare(a.sc, es, a.rng_main, a.dim_main, a.rng_edge, a.dim_edge, a.v, a.active[idx], idx);
-        st.i = i; st.sp = 0; st.nleaf = 0;
-        st.sample = s.edge_sel; st.resample = s.resample_sel;
-        st.c = s.lc;
-        st.q_pos = sil_query(es, s.lc.pos);
+        st.i = i; st.idx = slots[i]; st.sp = 0; st.nleaf = 0;
+        const HDescent d = hd[st.idx];
+        st.sample = d.sample;
+        st.c.pos = V3{d.pos[0], d.pos[1], d.pos[2]};
+        for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) st.c.m_inv.m[r][k] = d.m_inv[3 * r + k];
+        st.c.m = m3_inverse(st.c.m_inv);              // as sec_prepare does (ltc_bound needs both; the leaves only m_inv)
+        st.q_pos = sil_query(es, st.c.pos);
         double imp_cs = es.cs_root != kNoEdgeTree ? 1.0 : 0.0, imp_ncs = es.ncs_root != kNoEdgeTree ? 1.0 : 0.0;
         if (imp_cs <= 0 && imp_ncs <= 0) { st.nleaf = -1; return false; }            // no edge tree: the pick returns -1
         double prob_cs = imp_cs / (imp_cs + imp_ncs), prob_ncs = 1 - prob_cs;
@@ -901,7 +912,6 @@ template <bool PRELOAD> struct SecEdgePickHDescend {
         return st.sp > 0;
     }
     RDR_DEV_FN bool step(State &st) const {
-        const EdgeSceneD &es = a.es;
         auto st_ref = RDR_WALK_STACK(st, int, st_ref, kHStackLds, 11);
         auto st_num = RDR_WALK_STACK(st, unsigned char, st_num, kHStackLds, 12);
         auto st_pmf = RDR_WALK_STACK(st, double, st_pmf, kHStackLds, 13);
@@ -937,13 +947,7 @@ template <bool PRELOAD> struct SecEdgePickHDescend {
         }
         return st.sp == 0;
     }
-    RDR_DEV_FN void finish(State &st) const {
-        HDescent d;
-        d.pos[0] = st.c.pos.x; d.pos[1] = st.c.pos.y; d.pos[2] = st.c.pos.z;
-        for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) d.m_inv[3 * r + k] = st.c.m_inv.m[r][k];
-        d.resample = st.resample; d.nleaf = st.nleaf; d.pad = 0;
-        out[st.i] = d;
-    }
+    RDR_DEV_FN void finish(State &st) const { hd[st.idx].nleaf = st.nleaf; }
 };
 struct SecEdgePickHLeaves {
     SecEdgeArgs a; const int *slots; SecPick *picks; const HLeaf *leaves; const HDescent *in; int n;
@@ -951,7 +955,7 @@ struct SecEdgePickHLeaves {
     RDR_FN void make_mid() { mid_scene(a.sc); }
     RDR_FN void operator()(int i) const {
         const int idx = slots[i];
-        const HDescent d = in[i];
+        const HDescent d = in[idx];
         LtcCtx c;
         c.pos = V3{d.pos[0], d.pos[1], d.pos[2]};
         for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { c.m_inv.m[r][k] = d.m_inv[3 * r + k]; c.m.m[r][k] = 0; }
@@ -979,6 +983,45 @@ struct SecEdgePickHLeaves {
         double ew = 0;
         if (d.nleaf >= 0 && !(edge_w <= 0 || wsum <= 0)) { ew = 1 / (edge_w * kHSamples / wsum); eid = selected; }
         picks[idx] = SecPick{eid, ew, v3(0), v3(0)};
+    }
+};
+// SecEdgePickHLeaves as a walk (one recorded leaf per step) for exec::launch_chunked: slots record 1 ... 16 leaves.
+struct SecEdgePickHLeavesWalk {
+    SceneD sc; EdgeSceneD es; const int *slots; SecPick *picks; const HLeaf *leaves; const HDescent *in; int n;
+    struct State { int i, idx, j, nleaf, selected; double resample, edge_w, wsum; LtcCtx c; };
+    RDR_FN void make_lean() { lean_scene(sc); }
+    RDR_FN void make_mid() { mid_scene(sc); }
+    RDR_DEV_FN bool begin(int i, State &st) const {
+        st.i = i; st.idx = slots[i]; st.j = 0; st.selected = -1; st.edge_w = 0; st.wsum = 0;
+        const HDescent d = in[st.idx];
+        st.nleaf = d.nleaf; st.resample = d.resample;
+        st.c.pos = V3{d.pos[0], d.pos[1], d.pos[2]};
+        for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) { st.c.m_inv.m[r][k] = d.m_inv[3 * r + k]; st.c.m.m[r][k] = 0; }
+        return st.nleaf > 0;
+    }
+    RDR_DEV_FN bool step(State &st) const {
+        const HLeaf it = leaves[(size_t)st.j * (size_t)n + st.i];
+        const int leaf_edge = ~it.ref;
+        double w = it.num * leaf_importance_h(sc, es, leaf_edge, st.c) / it.pmf;
+        if (w > 0) {
+            double prev = st.wsum;
+            st.wsum += w;
+            double nw = w / st.wsum;
+            if (st.resample <= nw || prev == 0) {
+                st.selected = leaf_edge;
+                st.edge_w = w * it.pmf;
+                st.resample /= nw;
+            } else {
+                st.resample = (st.resample - nw) / (1 - nw);
+            }
+        }
+        return ++st.j >= st.nleaf;
+    }
+    RDR_DEV_FN void finish(State &st) const {
+        int eid = -1;
+        double ew = 0;
+        if (st.nleaf >= 0 && !(st.edge_w <= 0 || st.wsum <= 0)) { ew = 1 / (st.edge_w * kHSamples / st.wsum); eid = st.selected; }
+        picks[st.idx] = SecPick{eid, ew, v3(0), v3(0)};
     }
 };
 // The NEE-mode pick as a resumable walk for exec::launch_persistent: same tests in the same order as

@@ -110,6 +110,11 @@ def assert_parity(rep, name=''):
             assert e['rel_l2'] < 1e-12, (name, k, e)
         else:
             assert e['rel_l2'] < e['tol'], (name, k, e)
+            # a tensor judged against the harness' fp64 sum (a value this project generated, pinned to the oracle by
+            # tests/test_accumulation_order.py) must ALSO stay near the oracle's own striped sum -- looser (that sum has not
+            # settled: 4.8e-4 at K = 256), but a bar that does not rest on self-generated data
+            if 'rel_l2_vs_striped_sum' in e:
+                assert e['rel_l2_vs_striped_sum'] < 1e-3, (name, k, e)
 
 
 def summary(rep):

@@ -159,6 +159,37 @@ def bunny_box(device, resolution=(512, 512), vertex_grad=True):
     return Scene(cam, shapes, mats, lights)
 
 
+def _subdivide(v, f):
+    """One level of midpoint subdivision with shared vertices: every triangle -> 4 (v [N, 3] float32, f [T, 3] int64)."""
+    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    uniq, inv = torch.unique(torch.sort(e, dim=1).values, dim=0, return_inverse=True)
+    mid = 0.5 * (v[uniq[:, 0]] + v[uniq[:, 1]])
+    m = inv.reshape(3, -1).t() + v.shape[0]
+    a, b, c, ab, bc, ca = f[:, 0], f[:, 1], f[:, 2], m[:, 0], m[:, 1], m[:, 2]
+    f2 = torch.cat([torch.stack([a, ab, ca], 1), torch.stack([ab, b, bc], 1), torch.stack([ca, bc, c], 1), torch.stack([ab, bc, ca], 1)], 0)
+    return torch.cat([v, mid], 0), f2
+
+
+def bunny_box_subdivided(device, resolution=(1024, 1024), levels=4):
+    """bunny_box with the bunny tessellated `levels` times further (x 4 per level: 3.7 M triangles at 4) and its surface rippled
+    by a few 1e-4 so that the small triangles are not coplanar: same picture, a triangle hierarchy of ~250 MB instead of 1 MB --
+    far beyond the 4 MiB of L2 per XCD.  The workload of bench.py's `roofline_large`; not a BASELINE
+    configuration and not a parity case (no oracle fixture: the oracle's scalar builder would need hours)."""
+    sc = bunny_box(device, resolution, vertex_grad=False)
+    z = np.load(os.path.join(GOLDEN, 'bunny_box_scene.npz'))
+    sh = sc.shapes[int(z['bunny_shape_id'])]
+    v, f = sh.vertices.detach(), sh.indices.long()          # (on `device`: seconds on the GPU, half a minute on the host)
+    for _ in range(levels):
+        v, f = _subdivide(v, f)
+    if levels > 0:
+        v = v + 2e-4 * torch.sin(900.0 * v[:, [1, 2, 0]]) * torch.cos(700.0 * v[:, [2, 0, 1]])
+    sh.vertices = v.contiguous().to(device)
+    sh.indices = f.to(torch.int32).contiguous().to(device)
+    sh.uvs = None
+    sh.normals = None
+    return sc
+
+
 def bunny_box_tile(device, resolution=(512, 512)):
     """BASELINE config 3 at full resolution and full spp, restricted by the camera viewport to the 128 x 128 tile
     (rows 256..384, columns 128..256) that holds the bunny's ears, head and back against the back wall
