@@ -59,7 +59,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 VALU_LANE_OPS_PEAK = 256 * 4 * 16 * 2.4e9     # CUs x SIMDs x lanes/clk x clock = 39.3 T lane-operations/s (79 TFLOP/s fp64 FMA)
 RAY_BYTES, HIT_BYTES, NODE_BYTES, WIDE_NODE_BYTES, TRI_BYTES = 32, 8, 32, 128, 36
-BENCH_POOL_CAP_MB = 16384      # buffer-cache bound this benchmark asks for (the library's default is 8192)
+BENCH_POOL_CAP_MB = 32768      # buffer-cache bound this benchmark asks for (the library default is 8192): two workers x 8-sample batches
 INNER_SPP = 32                 # samples of the job the rocprofv3 passes run (forms the same sample batches as the timed job at 1024 x 1024)
 
 
@@ -325,6 +325,49 @@ def large_hierarchy_leg(levels=4, spp=8, res=1024, max_bounces=4):
             'tris_per_ray': cnt.closest_tris / max(rays, 1), 'algorithmic_bytes': alg}
 
 
+LARGE_LEVELS, LARGE_SPP = 4, 8
+
+
+def large_hierarchy_counters(a):
+    """Three rocprofv3 passes (FETCH_SIZE / WRITE_SIZE / SQ counters, separate passes as MI355X_MICROARCH.md prescribes; gfx950
+    FETCH_SIZE counts 64 B per 128-B request: x 2) over the large-hierarchy leg: what the refilling closest-hit kernel really
+    moves to and from HBM per launch there, its lane utilisation, the share of wave cycles spent waiting."""
+    base = tempfile.mkdtemp(prefix='rdr_prof_large_', dir='/tmp')
+    try:
+        dirs = [_rocprof(['--pmc'] + c, a, os.path.join(base, tag), inner='--large-inner')
+                for tag, c in (('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']), ('sq', SQ_COUNTERS))]
+        if not all(dirs):
+            return None
+        out = {}
+        for d in dirs:
+            fs = glob.glob(os.path.join(d, '*', '*_counter_collection.csv'))
+            if not fs:
+                return None
+            agg, launches = collections.defaultdict(float), set()
+            for r in csv.DictReader(open(fs[0])):
+                if 'trace_refill_kernel<false' in r['Kernel_Name']:
+                    agg[r['Counter_Name']] += float(r['Counter_Value'])
+                    launches.add(r['Dispatch_Id'])
+            for k, v in agg.items():
+                out[k] = v / max(len(launches), 1)
+            out['launches_counted'] = len(launches)
+        ds = glob.glob(os.path.join(dirs[2], '*', '*_kernel_trace.csv'))
+        tot, n = 0.0, 0
+        for r in (csv.DictReader(open(ds[0])) if ds else []):
+            if 'trace_refill_kernel<false' in r['Kernel_Name']:
+                tot += (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-6
+                n += 1
+        ms = tot / n if n else None
+        hbm = (out.get('FETCH_SIZE', 0.0) * 2.0 + out.get('WRITE_SIZE', 0.0)) * 1024.0
+        return {'kernel': 'trace_refill_kernel<closest-hit> launches of the leg', 'launches_counted': out.get('launches_counted'),
+                'mean_launch_ms_under_counters': ms, 'hbm_bytes_per_launch': hbm,
+                'hbm_GBs': hbm / (ms * 1e-3) / 1e9 if ms else None, 'hbm_frac_measured': hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None,
+                'valu_lane_util': out['SQ_THREAD_CYCLES_VALU'] / (64.0 * out['SQ_ACTIVE_INST_VALU']) if out.get('SQ_ACTIVE_INST_VALU') else None,
+                'wave_cycles_waiting_frac': out['SQ_WAIT_ANY'] / out['SQ_WAVE_CYCLES'] if out.get('SQ_WAVE_CYCLES') else None}
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
 def alone_leg(st, alg_bytes_launch):
     """The same kernel in an extra untimed step on one stream (RDR_NO_OVERLAP=1): informative, not the headline."""
     ms = st.closest_ms / max(st.closest_launches, 1)
@@ -338,19 +381,21 @@ PROFILE_KERNELS = collections.OrderedDict([       # short name -> substring of t
     ('trace_closest', 'trace_kernel<false, false'), ('trace_any', 'trace_kernel<true, false'),
     ('trace_closest_wide', 'trace_wide_kernel<false, false'), ('trace_any_wide', 'trace_wide_kernel<true, false'),
     ('trace_closest_refill', 'trace_refill_kernel<false'), ('trace_any_refill', 'trace_refill_kernel<true'),
-    ('SecEdgePickH', 'SecEdgePickH'), ('SecEdgeGatherN', 'SecEdgeGatherN'), ('AdjBounceScatter', 'AdjBounceScatter'),
+    ('SecEdgePickHDescend', 'SecEdgePickHDescend'), ('SecEdgePickHLeaves', 'SecEdgePickHLeaves'), ('SecEdgePickH', 'SecEdgePickH'),
+    ('SecEdgeSetup', 'SecEdgeSetup'), ('SecEdgeGatherN', 'SecEdgeGatherN'), ('AdjBounceScatter', 'AdjBounceScatter'),
     ('AdjBounceNee', 'AdjBounceNee'), ('BounceContrib', 'BounceContrib'), ('BounceSample', 'BounceSample'),
     ('AdjPrimary', 'AdjPrimary')])
 SQ_COUNTERS = ['SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_INSTS_VALU', 'SQ_THREAD_CYCLES_VALU']
 
 
-def _rocprof(extra, a, out_dir, env=None):
-    """One rocprofv3 pass over `bench.py --inner` (2 spp, one forward+backward).  Returns the output directory or None."""
+def _rocprof(extra, a, out_dir, env=None, inner='--inner'):
+    """One rocprofv3 pass over `bench.py --inner` (32 spp, one forward+backward) or `--large-inner` (the large-hierarchy leg).
+    Returns the output directory or None."""
     exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(exe):
         return None
     cmd = [exe] + extra + ['--kernel-trace', '--output-format', 'csv', '-d', out_dir, '--', sys.executable,
-                           os.path.join(ROOT, 'bench.py'), '--inner', '--res', str(a.res), '--max-bounces', str(a.max_bounces),
+                           os.path.join(ROOT, 'bench.py'), inner, '--res', str(a.res), '--max-bounces', str(a.max_bounces),
                            '--workload', a.workload]
     e = dict(os.environ)
     e.update(env or {})
@@ -496,12 +541,18 @@ def main():
     ap.add_argument('--no-alone-leg', action='store_true', help='skip the extra single-stream step behind roofline.alone')
     ap.add_argument('--no-profile', action='store_true', help='skip the rocprofv3 counter passes behind roofline.kernels')
     ap.add_argument('--inner', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--large-inner', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--no-large-leg', action='store_true', help='skip the untimed large-hierarchy traversal leg behind roofline_large')
     ap.add_argument('--cpu-baseline-leg', action='store_true', help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.max_bounces is None:
         a.max_bounces = 6 if a.workload.startswith('living_room_standin') else 4
     if a.inner:
         return inner_run(a)
+    if a.large_inner:
+        torch.cuda.set_device(0)
+        large_hierarchy_leg(LARGE_LEVELS, LARGE_SPP)
+        return None
     if a.cpu_baseline_leg:
         return cpu_baseline_leg(a)
 
@@ -539,7 +590,8 @@ def main():
     from redner_amd import redner
     # The library parks at most 8 GiB of buffers between calls by default (it may share the device with torch's allocator).  This
     # process owns its GPU: it raises the bound -- stated in the line (`config.pool_cap_mb`) -- so that two sample workers keep
-    # 4-sample batches of the 1024 x 1024 frame resident (16 GiB of the 288; RDR_POOL_CAP_MB overrides).
+    # 8-sample batches of the 1024 x 1024 frame resident (32 GiB of the 288; RDR_POOL_CAP_MB overrides.  Measured on the final
+    # tree, profiles/r6_notes.md: 8 GiB 72.4, 16 GiB 74.1, 32 GiB 75.5, 64 GiB 75.7 Msamples/s).
     if 'RDR_POOL_CAP_MB' not in os.environ:
         redner.set_pool_cap_mb(BENCH_POOL_CAP_MB)
     pool_cap_mb = redner.get_pool_cap_mb()
@@ -744,6 +796,22 @@ def main():
                                  'so this is an L2-served rate; hbm_frac_measured is what reaches HBM (counters), and the '
                                  'kernels are bound by vector-ALU issue at valu_lane_util (DESIGN.md section 3)'},
         }
+        # the same closest-hit kernel on a hierarchy that does NOT fit the L2 (bunny tessellated to 3.7 M triangles, ~250 MB of records):
+        # what the design does when traversal really goes to the MALL / HBM
+        if world == 1 and not a.no_large_leg and a.workload == 'bunny_box':
+            try:
+                big = large_hierarchy_leg(LARGE_LEVELS, LARGE_SPP)
+                if not a.no_profile and not under_profiler():
+                    big['counters'] = large_hierarchy_counters(a)
+                    if big['counters'] and big['counters'].get('launches_counted'):
+                        big['traffic'] = big['counters']['hbm_bytes_per_launch']
+                        big['hbm_frac_measured'] = big['counters']['hbm_frac_measured']
+                big['note'] = ('latency-bound: dependent node fetches miss the L2, three (40-entry stack) or four (32-entry) waves per '
+                               'SIMD hide little of it; the HBM traffic the counters see is well under the algorithmic bytes '
+                               '(DESIGN.md section 3)')
+                out['roofline_large'] = big
+            except Exception as e:
+                out['roofline_large'] = {'error': repr(e)}
         if world == 1 and not a.no_self_check:
             try:
                 out['self_check'] = sharded_self_check(a, redner, dev)

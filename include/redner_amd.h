@@ -169,6 +169,9 @@ struct rdr_tuning {
     int gather_budget;              /* pops per lane of SecEdgeGatherN before it hands over (256)                          RDR_GATHER_BUDGET */
     int gather_heavy_cap_plus1, gather_work_cap_plus1;   /* list capacities of the gather's hand-over paths, + 1 (tests: 1 = capacity 0)   RDR_GATHER_CAPS */
     int mem_available_mb;           /* size the batches as if this much device memory were free (tests)                    RDR_MEM_AVAILABLE_MB */
+    int refill_order;               /* order in which trace_refill_kernel hands a wave's 256 rays out: 1 = queue order (rounds
+                                     * 3-5), 2 = by direction octant (default), 3 = octant x dominant axis               RDR_REFILL_SORT=0|1|2 */
+    int pickh_slots_per_lane, pickh_idle_lanes, pickh_steps;     /* the hierarchical pick's descent walk (1, 8, 8)           RDR_PICKH_REFILL=k,idle,steps */
 };
 
 /* Library-wide settings (no reference counterpart).

@@ -91,7 +91,8 @@ class Tuning(C.Structure):
     _fields_ = [('flags', C.c_uint), ('batch_samples', C.c_int), ('batch_lanes', C.c_int64), ('workers', C.c_int),
                 ('refill_rays_per_lane', C.c_int), ('refill_idle_lanes', C.c_int), ('refill_steps', C.c_int),
                 ('wide_max_rays', C.c_int), ('gather_budget', C.c_int),
-                ('gather_heavy_cap_plus1', C.c_int), ('gather_work_cap_plus1', C.c_int), ('mem_available_mb', C.c_int)]
+                ('gather_heavy_cap_plus1', C.c_int), ('gather_work_cap_plus1', C.c_int), ('mem_available_mb', C.c_int),
+                ('refill_order', C.c_int), ('pickh_slots_per_lane', C.c_int), ('pickh_idle_lanes', C.c_int), ('pickh_steps', C.c_int)]
 
 
 # rdr_tune_flags / rdr_build_flags

@@ -608,7 +608,7 @@ __global__ void __launch_bounds__(256) compact_scatter(const int *in, int n, con
 // it, so reading it back costs one stream synchronisation and no copy launch (a pageable 4-byte
 // hipMemcpy measured ~195 us per call in the rocprofv3 trace, profiles/r1_notes.md).
 struct CompactScratch { int *block_counts = nullptr; int *total = nullptr; volatile int *total_host = nullptr; int capacity = 0; int ticket = 0; };
-CompactScratch &compact_scratch(int nblocks);
+CompactScratch &compact_scratch(int nblocks, int which = 0);      // `which`: compactions that may be in flight together (two streams of one host thread) use different scratch
 
 // `out` must not alias `in`: a workgroup may scatter into a tile that an earlier-numbered workgroup has not read yet.
 // compact_dev: nothing comes back to the host.  The kept items go to out[*append_at ...] (append_at null: out[0 ...]) and
@@ -617,12 +617,12 @@ int *new_count();                    // trace.hip: a device int from a per-threa
 // `pos_out` (optional): pos_out[k] = position in the input list of the k-th kept item.
 template <class P>
 inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const Count *append_at = nullptr, int *dyn = nullptr, int inc = 0,
-                         int *pos_out = nullptr) {
+                         int *pos_out = nullptr, int scratch = 0) {
     const int base_upper = append_at ? append_at->upper : 0;
     if (n.upper <= 0) return append_at ? *append_at : Count(0);
     int nblocks = (n.upper + kCompactTile - 1) / kCompactTile;
     if (nblocks > 256 * 4096) throw std::runtime_error("compact: input too large");
-    CompactScratch &sc = compact_scratch(nblocks);
+    CompactScratch &sc = compact_scratch(nblocks, scratch);
     hipStream_t st = ctx().stream;
     int *result = new_count();
     const int *base = append_at ? append_at->dev : nullptr;

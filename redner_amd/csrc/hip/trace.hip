@@ -258,11 +258,11 @@ const void *device_constant(const void *host, size_t bytes) {
     return p;
 }
 
-CompactScratch &compact_scratch(int nblocks) {
-    static thread_local CompactScratch per_device[16];
+CompactScratch &compact_scratch(int nblocks, int which) {
+    static thread_local CompactScratch per_device[16][2];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    CompactScratch &s = per_device[dev & 15];
+    CompactScratch &s = per_device[dev & 15][which & 1];
     if (s.capacity < nblocks) {
         if (s.block_counts) (void)hipFree(s.block_counts);
         if (!s.total) {
@@ -282,7 +282,6 @@ CompactScratch &compact_scratch(int nblocks) {
 // STACK: entries of the per-lane LDS stack column.  The kernel waits on node fetches about two thirds of the
 // time (profiles/r1_notes.md), so waves per SIMD matter: 40 entries allow 4, 24 allow 6, 16 allow 8.  The host
 // picks the smallest instantiation that covers the scene's hierarchy depth.
-constexpr int kRefillSortDefault = 0;
 constexpr int kTopNodes = 255;          // root + 127 sibling pairs (pairs start at odd indices, so none straddles): 8 KiB of LDS
 // node record i: from the workgroup's LDS copy of the top levels, else from global memory.  The LDS pointer keeps its address
 // space in its type: with two generic pointers the compiler merges the paths into a select + flat_load.
@@ -451,16 +450,18 @@ __device__ inline bool traverse_some(const rt::BvhD &bvh, const float o[3], cons
 // (24 bins), dead slots (tmax < 0) last.  A counting sort of the 256 indices by ballots, one byte per index in LDS; nothing
 // else moves: rays are read and hits written by queue slot, every ray takes the same steps, so the hit ids are the same.
 template <bool ANY, int STACK, class IDX, bool SORT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STACK <= 24 ? 7 : 1, 8))) trace_refill_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays, rt::HitRec *__restrict__ hits,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STACK <= 24 ? 7 : (STACK <= 32 ? 4 : 1), 8))) trace_refill_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays, rt::HitRec *__restrict__ hits,
                                                            int n, const int *count, int rays_per_lane, int idle_min, int steps, int sort_mode) {
     if (count) { const int c = *count; n = c < n ? c : n; }
     const int chunk = 64 * rays_per_lane;
     if ((long long)blockIdx.x * 4 * chunk >= n) return;
     __shared__ IDX stack_tile[STACK * 256];
     IDX *stack = stack_tile + threadIdx.x;
-    __shared__ rt::Node top[kTopNodes + 1];
+    // (32-entry int stacks + the order bytes: 31 fewer pairs of the top staged, so that four workgroups still fit a CU's LDS)
+    constexpr int kTop = (SORT && STACK == 32) ? 191 : kTopNodes;
+    __shared__ rt::Node top[kTop + 1];
     __shared__ unsigned char order_tile[SORT ? 4 * 256 : 4];
-    const int ntop = bvh.num_nodes < kTopNodes ? bvh.num_nodes : kTopNodes;
+    const int ntop = bvh.num_nodes < kTop ? bvh.num_nodes : kTop;
     if ((int)threadIdx.x < ntop) top[threadIdx.x] = bvh.nodes[threadIdx.x];
     __syncthreads();
     const FetchStaged fetch{bvh.nodes, (LdsFloats)(const float *)top, ntop};
@@ -581,7 +582,11 @@ int *new_count() {
 }
 
 int *persistent_counter() {
-    // per host thread (its launches are ordered on its own streams) and per device
+    // per host thread and per device; the slot is zeroed ON THE STREAM OF THE LAUNCH that is about to use it.  (Rounds 3-5 zeroed
+    // the whole ring once per lap on whatever stream was current then: a kernel launched on ANOTHER stream right after the
+    // ring's allocation could read its counter before that fill had run -- harmless while the only user was the gated overflow
+    // walk, a wrong pick once in a while as soon as the hierarchical pick's descent took its chunks off such a counter; found as
+    // an intermittent failure of the first test after a library load, round 6.)
     static thread_local int *rings[16] = {};
     static thread_local int slots[16] = {};
     constexpr int kRing = 4096;
@@ -590,9 +595,9 @@ int *persistent_counter() {
     int *&ring = rings[dev & 15];
     int &slot = slots[dev & 15];
     if (!ring) ring = (int *)dmalloc(sizeof(int) * kRing);
-    if (slot == 0) zero(ring, sizeof(int) * kRing);        // stream-ordered: re-zeroed once per lap
     int *p = ring + slot;
     slot = (slot + 1) % kRing;
+    check(hipMemsetAsync(p, 0, sizeof(int), ctx().stream), "persistent_counter");
     return p;
 }
 
@@ -726,22 +731,27 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count 
         const int wg_rays = 4 * 64 * refill_k;
         const int rblocks = (int)(((long long)n + wg_rays - 1) / wg_rays);
         const int k_arg = refill_k;
-        // RDR_REFILL_SORT=0|1|2 (experiments; bit 2 = closest-hit queues only, bit 3 = any-hit queues only)
-        static const int sort_env = [] { const char *e = std::getenv("RDR_REFILL_SORT"); return e ? std::atoi(e) : kRefillSortDefault; }();
-        const int sort_mode = ((sort_env & 4) && any) || ((sort_env & 8) && !any) ? 0 : (sort_env & 3);
+        const int sort_mode = tune.refill_sort;        // rdr_tuning::refill_order: 0 queue order, 1 octant (default), 2 octant x axis
         const bool small = bvh.num_nodes < 65536 && bvh.stack_need <= 24;
+        // big hierarchies (int entries): 32 entries where that covers the tree -- 40 KiB of LDS per workgroup instead of 49: four
+        // workgroups per CU instead of three (a hierarchy beyond the L2 is latency-bound: more waves, profiles/r6_notes.md)
+        const bool mid32 = !small && bvh.stack_need <= 32;
 #define RDR_REFILL_LAUNCH(ANY_, STACK_, IDX_, SORT_) \
         hipLaunchKernelGGL((trace_refill_kernel<ANY_, STACK_, IDX_, SORT_>), dim3(rblocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, k_arg, idle_min, steps, sort_mode)
         const bool sort_on = sort_mode > 0 && k_arg == 4;
         if (sort_on) {
             if (any && small) RDR_REFILL_LAUNCH(true, 24, unsigned short, true);
+            else if (any && mid32) RDR_REFILL_LAUNCH(true, 32, int, true);
             else if (any) RDR_REFILL_LAUNCH(true, rt::kTraverseStack, int, true);
             else if (small) RDR_REFILL_LAUNCH(false, 24, unsigned short, true);
+            else if (mid32) RDR_REFILL_LAUNCH(false, 32, int, true);
             else RDR_REFILL_LAUNCH(false, rt::kTraverseStack, int, true);
         } else {
             if (any && small) RDR_REFILL_LAUNCH(true, 24, unsigned short, false);
+            else if (any && mid32) RDR_REFILL_LAUNCH(true, 32, int, false);
             else if (any) RDR_REFILL_LAUNCH(true, rt::kTraverseStack, int, false);
             else if (small) RDR_REFILL_LAUNCH(false, 24, unsigned short, false);
+            else if (mid32) RDR_REFILL_LAUNCH(false, 32, int, false);
             else RDR_REFILL_LAUNCH(false, rt::kTraverseStack, int, false);
         }
 #undef RDR_REFILL_LAUNCH

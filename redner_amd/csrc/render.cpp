@@ -412,6 +412,7 @@ struct Backward {
         // (the lean stages keep no uv / uv-derivative / colour adjoints: 15 of the 24 components, stages_bwd.h: AdjState::plain)
         adj_point_doubles = lean == kLean ? 15 : kAdjPointDoubles;
         adj.point = arena.get<double>((size_t)adj_point_doubles * P);
+        nee_act = arena.get<int>((size_t)P);
         const bool edges_on = scene.edges && scene.edges->d.num_edges > 0 &&
                               (scene.use_primary_edges || scene.use_secondary_edges);
         if (edges_on) {
@@ -492,6 +493,7 @@ struct Backward {
     void erd_view(const int *seg) { ea.erd_seg = eb.erd_seg = seg; ea.erd_S = eb.erd_S = cur_S; ea.erd_P0 = eb.erd_P0 = batch.P0; }
     int *elist[3] = {nullptr, nullptr, nullptr};
     HLeaf *h_leaves = nullptr, *h_spill = nullptr;   // hierarchical pick: recorded leaves / spilled stack entries per list position
+    int *nee_act = nullptr;                          // lanes of a depth whose next-event estimate has something to differentiate
     HDescent *h_descent = nullptr;                   // ... and what the descent hands to the leaf launch (stages_edge.h)
     GatherShared gshared{nullptr, nullptr, nullptr, nullptr, 0, 0};     // heavy slots of the gather: big candidate lists, subtree work items
     GatherCand *gather_cands = nullptr;        // positive leaves found by the NEE-mode gather, kGatherCands per list position
@@ -630,9 +632,7 @@ struct Backward {
         const bool pickh_fused = tuning().has(RDR_TUNE_PICKH_FUSED);     // A/B: the one-loop form
         const bool pickh_lazy = tuning().has(RDR_TUNE_PICKH_LAZY);       // A/B: per-field node loads
         const bool pickh_one_launch = tuning().has(RDR_TUNE_PICKH_ONE_LAUNCH);       // A/B: one slot per lane from root to last leaf
-        // RDR_PICKH_REFILL=<slots per lane>,<idle lanes before a refill>,<steps between two checks> (experiments)
-        static const struct PickhRefill { int k = 4, idle = 16, steps = 8; PickhRefill() { if (const char *e = std::getenv("RDR_PICKH_REFILL")) std::sscanf(e, "%d,%d,%d", &k, &idle, &steps); } } pickh_refill;
-        const int pickh_k = std::max(1, pickh_refill.k), pickh_idle = std::min(64, std::max(1, pickh_refill.idle)), pickh_steps = std::max(1, pickh_refill.steps);
+        const int pickh_k = tuning().pickh_k, pickh_idle = tuning().pickh_idle, pickh_steps = tuning().pickh_steps;      // rdr_tuning::pickh_*
         // The two edge picks of a secondary pass: slot setup, the per-mode slot lists, the NEE-mode gather and the hierarchical
         // pick.  `early`: everything off the calling stream (setup + lists + gather on side stream 1, hierarchical pick on side
         // stream 0), so that the caller's stream is free for the bounce adjoints; otherwise setup, lists and the hierarchical pick
@@ -758,6 +758,18 @@ struct Backward {
             early_sa = start_picks(0, 0, hoist_dyn, true, true);
             hoisted = true;
         }
+        // The next-event half of a bounce adjoint has nothing to do for a lane whose shadow ray was blocked or whose light sample
+        // lies below a horizon (the forward pass left both in the slice's occlusion byte): it runs over the compacted list of the
+        // others -- full waves (lane utilisation 0.61 over the whole list).  Order-preserving: the adds keep their order.
+        // (its own scratch: the pick phase's compactions may be in flight on another stream of this thread)
+        static const bool nee_compact = std::getenv("RDR_NO_NEE_COMPACT") == nullptr;
+        auto adj_nee = [&](const AdjBounceArgs &ba, exec::Count nA, int d) {
+            if (!nee_compact || !vs[d].occl) { launch_v(lean, nA, AdjBounceNee{ba}); return; }
+            AdjBounceArgs lit = ba;
+            const exec::Count nLit = exec::compact_dev(ba.active, nA, nee_act, KeepNeeLive{vs[d].occl}, nullptr, nullptr, 0, nullptr, 1);
+            lit.active = nee_act;
+            launch_v(lean, nLit, AdjBounceNee{lit});
+        };
         for (int d = B - 1; d >= 0 && has_lights; --d) {
             const exec::Count nA = num_active[d];
             if (nA.upper <= 0) continue;
@@ -782,11 +794,11 @@ struct Backward {
                 exec::StreamScope on(exec::side_stream(side_index(0, P)));
                 depth_begin.gate(exec::ctx().stream);
                 launch_v(lean, nA, AdjBounceScatter{ba});
-                launch_v(lean, nA, AdjBounceNee{ba});
+                adj_nee(ba, nA, d);
                 adjoint_done.after(exec::ctx().stream);
             } else {
                 launch_v(lean, nA, AdjBounceScatter{ba});
-                launch_v(lean, nA, AdjBounceNee{ba});
+                adj_nee(ba, nA, d);
             }
             if (with_edges) {
                 // ---- secondary (shadow / inter-reflection) edges at this vertex, :500-706 ----

@@ -260,15 +260,10 @@ struct AdjBounceNee {
         double d2 = len_sq(dir);
         V3 wo = dir / sqrt(d2);
         const LightD &l = sc.lights[lsh.light_id];
-        if (!(l.two_sided || dot(-wo, lp.frame.n) > 0)) return;
-        {   // bsdf_eval's geometric early-outs: value and every adjoint below are exactly zero then
-            ShadeCtx sx = shade_ctx(*c.mat, c.sp);
-            double gwi = dot(sx.gn, c.wi), gwo = dot(sx.gn, wo);
-            double swi = fabs(dot(sx.fr.n, c.wi)), swo = fabs(dot(sx.fr.n, wo));
-            if (gwi * gwo < 0) return;
-            if (!c.mat->two_sided && gwi < 0 && gwo < 0) return;
-            if (swi == 0 || swo <= 1e-3f || fabs(gwo) <= 1e-3f) return;
-        }
+        // light facing away / bsdf_eval's geometric early-outs: value and every adjoint below are exactly zero then.  (The
+        // forward pass has folded the same test into the occlusion byte and the list this stage runs over holds only lanes
+        // whose byte is clear: kept for callers that hand over the full list.)
+        if (nee_is_geometrically_zero(sc, c, pk, lp)) return;
         const GMaterial &gm = g.materials[c.shape->material_id];
         V3 thr = ld3(v.thr, v.n, p, 0);
         V3 pc_bar = a.weight * image_grad(a.d_image, a.nd, a.radiance_dim, p);
@@ -463,6 +458,11 @@ struct AdjPrimaryLive {
 
 // fp64 accumulators -> the caller's fp32 gradient tensors (+=), all tensors in one launch: lane i owns element i of the
 // replicated block, sums its replicas in fixed order and finds the tensor it belongs to in the sorted segment table.
+struct KeepNeeLive {    // lanes whose next-event estimate has something to differentiate (the slice's occlusion byte is clear)
+    const unsigned char *occl;
+    RDR_FN bool operator()(int p) const { return occl[p] == 0; }
+};
+
 struct FlushSegment { size_t begin, count; float *out; };      // elements [begin, begin + count) of the block
 struct FlushGrad {
     const double *block; size_t stride; int replicas;

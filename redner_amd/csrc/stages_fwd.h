@@ -488,6 +488,29 @@ RDR_FN BounceEval eval_bounce(const SceneD &sc, const VertexCtx &c, V3 thr,
     return r;
 }
 
+// Next-event estimation towards an area light: is this vertex / light-sample pair one of the cases in which the estimator AND
+// every adjoint of it are exactly zero for geometric reasons -- the light faces away, the sample lies below the horizon of the
+// shading or the geometric normal (bsdf_eval's early-outs)?  ONE definition, used by BounceContrib (it folds the answer into
+// the slice's occlusion byte) and by AdjBounceNee (src/path_contribution.cpp:206-294 evaluates these as it goes): the adjoint
+// stage then runs over the compacted list of lanes whose byte is clear (render.cpp) -- full waves instead of 0.6 of a wave.
+RDR_FN bool nee_is_geometrically_zero(const SceneD &sc, const VertexCtx &c, const LightPick &pk, const Surf &lp) {
+    if (pk.shape_id < 0) return sc.envmap == nullptr;          // environment light: never decided here
+    const ShapeD &lsh = sc.shapes[pk.shape_id];
+    if (lsh.light_id < 0) return true;
+    const V3 dir = lp.position - c.sp.position;
+    const double d2 = len_sq(dir);
+    const V3 wo = dir / sqrt(d2);
+    const LightD &l = sc.lights[lsh.light_id];
+    if (!(l.two_sided || dot(-wo, lp.frame.n) > 0)) return true;
+    const ShadeCtx sx = shade_ctx(*c.mat, c.sp);
+    const double gwi = dot(sx.gn, c.wi), gwo = dot(sx.gn, wo);
+    const double swi = fabs(dot(sx.fr.n, c.wi)), swo = fabs(dot(sx.fr.n, wo));
+    if (gwi * gwo < 0) return true;
+    if (!c.mat->two_sided && gwi < 0 && gwo < 0) return true;
+    if (swi == 0 || swo <= 1e-3f || fabs(gwo) <= 1e-3f) return true;
+    return false;
+}
+
 // ---- stage: gather both query results, accumulate the bounce, advance the throughput ------------
 struct BounceContrib {
     static constexpr int kMidBlocksPerCU = 3;
@@ -517,7 +540,8 @@ struct BounceContrib {
         Surf lp = surf_zero();
         if (pk.shape_id >= 0) lp = sample_tri(sc.shapes[pk.shape_id], pk.tri_id, ld.uv);
         bool blocked = hn.shape >= 0;
-        if (v.occl) v.occl[p] = blocked ? 1 : 0;
+        // the byte AdjBounceNee skips a lane by: shadow ray blocked, or nothing to differentiate for geometric reasons
+        if (v.occl) v.occl[p] = (blocked || nee_is_geometrically_zero(sc, c, pk, lp)) ? 1 : 0;
         vn.shape[p] = hb.shape; vn.tri[p] = hb.shape >= 0 ? hb.prim : -1;
         Surf bp = surf_zero();
         if (hb.shape >= 0) {

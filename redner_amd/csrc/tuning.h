@@ -23,6 +23,8 @@ struct Tuning {
     int gather_budget = 256;
     int gather_heavy_cap = -1, gather_work_cap = -1;      // -1 = the buffers' full capacity
     double mem_available_mb = -1.0;     // < 0: ask the driver
+    int refill_sort = 1;                // 0 queue order, 1 octant, 2 octant x axis (trace.hip)
+    int pickh_k = 1, pickh_idle = 8, pickh_steps = 8;
     bool has(unsigned f) const { return (flags & f) != 0; }
 };
 
@@ -35,6 +37,7 @@ struct EnvDefaults {
     int batch_samples = 0; long long batch_lanes = 0; int workers = 0;
     int refill_k = 0, refill_idle = 0, refill_steps = 0, wide_max = 0, gather_budget = 0, heavy_cap = -1, work_cap = -1;
     double mem_mb = -1.0;
+    int refill_order = 0, pickh_k = 0, pickh_idle = 0, pickh_steps = 0;
     EnvDefaults() {
         if (env_set("RDR_NO_OVERLAP") || env_set("RDR_DEBUG_DUMP")) flags |= RDR_TUNE_NO_OVERLAP;
         if (env_set("RDR_FORCE_GENERAL")) flags |= RDR_TUNE_FORCE_GENERAL;
@@ -62,6 +65,14 @@ struct EnvDefaults {
         if (const char *e = env("RDR_GATHER_BUDGET")) gather_budget = std::atoi(e);
         if (const char *e = env("RDR_GATHER_CAPS")) { int h = 0, w = 0; if (std::sscanf(e, "%d,%d", &h, &w) == 2) { heavy_cap = h; work_cap = w; } }
         if (const char *e = env("RDR_MEM_AVAILABLE_MB")) mem_mb = std::atof(e);
+        if (const char *e = env("RDR_REFILL_SORT")) refill_order = std::atoi(e) + 1;
+        if (const char *e = env("RDR_PICKH_REFILL")) {
+            int k = 0, idle = 0, steps = 0;
+            const int got = std::sscanf(e, "%d,%d,%d", &k, &idle, &steps);
+            if (got >= 1 && k > 0) pickh_k = k;
+            if (got >= 2 && idle > 0) pickh_idle = idle;
+            if (got >= 3 && steps > 0) pickh_steps = steps;
+        }
     }
 };
 inline const EnvDefaults &env_defaults() { static const EnvDefaults d; return d; }
@@ -87,6 +98,10 @@ inline Tuning resolve_tuning(const rdr_tuning *t) {
     r.gather_heavy_cap = u.gather_heavy_cap_plus1 > 0 ? u.gather_heavy_cap_plus1 - 1 : e.heavy_cap;
     r.gather_work_cap = u.gather_work_cap_plus1 > 0 ? u.gather_work_cap_plus1 - 1 : e.work_cap;
     r.mem_available_mb = u.mem_available_mb > 0 ? (double)u.mem_available_mb : e.mem_mb;
+    r.refill_sort = detail::clampi(pick(u.refill_order, e.refill_order, 2), 1, 3) - 1;
+    r.pickh_k = detail::clampi(pick(u.pickh_slots_per_lane, e.pickh_k, 1), 1, 64);
+    r.pickh_idle = detail::clampi(pick(u.pickh_idle_lanes, e.pickh_idle, 8), 1, 64);
+    r.pickh_steps = detail::clampi(pick(u.pickh_steps, e.pickh_steps, 8), 1, 1024);
     return r;
 }
 

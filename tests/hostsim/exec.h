@@ -138,7 +138,7 @@ inline int compact(const int *in, int n, int *out, const P &pred) {
 }
 template <class P>
 inline Count compact_dev(const int *in, Count n, int *out, const P &pred, const Count *append_at = nullptr, int *dyn = nullptr, int inc = 0,
-                         int *pos_out = nullptr) {
+                         int *pos_out = nullptr, int /*scratch*/ = 0) {
     const int n_in = n.value();
     const int base = append_at ? append_at->value() : 0;
     int *result = new_count();

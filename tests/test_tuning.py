@@ -24,6 +24,7 @@ SCHEDULES = {
     'pickh_fused': {'flags': K.TUNE_PICKH_FUSED},
     'pickh_lazy': {'flags': K.TUNE_PICKH_LAZY},
     'pickh_one_launch': {'flags': K.TUNE_PICKH_ONE_LAUNCH},
+    'pickh_walk_params': {'pickh_slots_per_lane': 4, 'pickh_idle_lanes': 32, 'pickh_steps': 3},
     'pickh_one_launch_lazy': {'flags': K.TUNE_PICKH_ONE_LAUNCH | K.TUNE_PICKH_LAZY},
     'gather_hand_over': {'gather_budget': 2, 'gather_heavy_cap_plus1': 4, 'gather_work_cap_plus1': 6},
     'gather_no_lists': {'gather_budget': 1, 'gather_heavy_cap_plus1': 1, 'gather_work_cap_plus1': 1},
@@ -33,6 +34,8 @@ SCHEDULES = {
 GPU_ONLY = {
     'refill_everywhere': {'flags': K.TUNE_REFILL_ALL},
     'refill_params': {'flags': K.TUNE_REFILL_ALL, 'refill_rays_per_lane': 2, 'refill_idle_lanes': 8, 'refill_steps': 1},
+    'refill_queue_order': {'flags': K.TUNE_REFILL_ALL, 'refill_order': 1},
+    'refill_octant_axis_order': {'flags': K.TUNE_REFILL_ALL, 'refill_order': 3},
     'binary_records': {'flags': K.TUNE_TRACE_BINARY | K.TUNE_TRACE_NO_LDS_TOP},
     'wide_records_everywhere': {'wide_max_rays': 1 << 30},
     'one_worker': {'workers': 1},
