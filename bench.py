@@ -318,6 +318,7 @@ def large_hierarchy_leg(levels=4, spp=8, res=1024, max_bounces=4):
     return {'workload': 'bunny_box_subdivided (levels %d): %d triangles, %dx%d, %d spp forward, max_bounces %d' % (levels, tris, res, res, spp, max_bounces),
             'triangles': tris, 'hierarchy_bytes_estimate': tris * TRI_BYTES + 2 * (tris // 2) * NODE_BYTES,
             'mesh_s': t_mesh, 'scene_build_ms': t_scene * 1e3, 'forward_ms': t_fwd * 1e3, 'image_mean': float(img.mean()),
+            'image_sha256': __import__('hashlib').sha256(img.cpu().numpy().tobytes()).hexdigest()[:16],
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'closest_launches': st.closest_launches, 'busy_ms': busy, 'mean_launch_ms': st.closest_ms / max(st.closest_launches, 1),
             'rays': rays, 'rays_per_s': rays / (busy * 1e-3) if busy > 0 else None,
@@ -455,18 +456,22 @@ def under_profiler():
     return any(k.startswith(('ROCPROF', 'ROCP_TOOL', 'ROCPROFILER_')) for k in env)
 
 
-def profile_kernels(a):
+def profile_kernels(a, batch=0):
     """Four rocprofv3 passes on a 2-spp forward+backward of the same workload: kernel durations (stages overlapped as in
     the benchmark, and each kernel on its own with RDR_NO_OVERLAP=1), SQ counters, FETCH_SIZE, WRITE_SIZE (separate passes,
     MI355X_MICROARCH.md "HBM": gfx950 FETCH_SIZE counts 64 B per 128-B request, hence x2).  Returns {kernel: {...}}."""
     base = tempfile.mkdtemp(prefix='rdr_prof_', dir='/tmp')
     out = {}
     try:
+        # "alone": one stream of ONE sample worker (a second worker's chain would run beside it), the timed job's samples per launch
+        one = {'RDR_NO_OVERLAP': '1', 'RDR_WORKERS': '1'}
+        if batch > 0:
+            one['RDR_BATCH'] = str(batch)
         d_over = _rocprof([], a, os.path.join(base, 'over'))
-        d_alone = _rocprof([], a, os.path.join(base, 'alone'), {'RDR_NO_OVERLAP': '1'})
-        d_sq = _rocprof(['--pmc'] + SQ_COUNTERS, a, os.path.join(base, 'sq'), {'RDR_NO_OVERLAP': '1'})
-        d_f = _rocprof(['--pmc', 'FETCH_SIZE'], a, os.path.join(base, 'fetch'), {'RDR_NO_OVERLAP': '1'})
-        d_w = _rocprof(['--pmc', 'WRITE_SIZE'], a, os.path.join(base, 'write'), {'RDR_NO_OVERLAP': '1'})
+        d_alone = _rocprof([], a, os.path.join(base, 'alone'), one)
+        d_sq = _rocprof(['--pmc'] + SQ_COUNTERS, a, os.path.join(base, 'sq'), one)
+        d_f = _rocprof(['--pmc', 'FETCH_SIZE'], a, os.path.join(base, 'fetch'), one)
+        d_w = _rocprof(['--pmc', 'WRITE_SIZE'], a, os.path.join(base, 'write'), one)
         if not (d_over and d_alone and d_sq and d_f and d_w):
             return None
         dur_over, dur_alone = _read_durations(d_over), _read_durations(d_alone)
@@ -551,6 +556,9 @@ def main():
         return inner_run(a)
     if a.large_inner:
         torch.cuda.set_device(0)
+        if 'RDR_POOL_CAP_MB' not in os.environ:
+            from redner_amd import redner as _rd
+            _rd.set_pool_cap_mb(BENCH_POOL_CAP_MB)
         large_hierarchy_leg(LARGE_LEVELS, LARGE_SPP)
         return None
     if a.cpu_baseline_leg:
@@ -657,6 +665,9 @@ def main():
         dt = max(float(t[0]) for t in every)
     samples = a.res * a.res * a.spp * a.steps
     value = samples / dt / 1e6
+    dbg = _capi.DebugCounters()
+    lib.rdr_debug_counters_get(ctypes.byref(dbg))
+    timed_batch, timed_workers = int(dbg.last_batch_samples), int(dbg.last_workers)      # how the library scheduled the timed steps
 
     # untimed, world > 1 (or the forced one-rank collective): the north star's rule "bit-identical sum at 1 vs N GPUs", checked
     # on the hardware the job ran on -- a short job of one sample per rank, gathered and summed as in the timed steps, against
@@ -713,7 +724,9 @@ def main():
     # shadow-ray launch of the same bounce runs beside every closest-hit launch)
     alone = None
     if not a.no_alone_leg:
-        short.u.options.tuning.flags |= _capi.TUNE_NO_OVERLAP          # rdr_tuning: every stage on the calling stream
+        short.u.options.tuning.flags |= _capi.TUNE_NO_OVERLAP          # rdr_tuning: every stage on the calling stream ...
+        short.u.options.tuning.workers = 1                              # ... of ONE host thread, the timed job's samples per launch
+        short.u.options.tuning.batch_samples = max(timed_batch, 1)
         lib.rdr_trace_stats_enable(1, 0)
         trace_stats(reset=True)
         short.step(a.warmup)
@@ -739,7 +752,7 @@ def main():
         prof = None
         if world == 1 and not a.no_profile and not under_profiler():
             try:
-                prof = profile_kernels(a)
+                prof = profile_kernels(a, timed_batch)
             except Exception as e:      # the counters must never take the throughput number down with them
                 prof = {'error': repr(e)}
         # counters of the closest-hit kernel that does most of the work: the refilling form on the large incoherent queues of the
@@ -758,6 +771,7 @@ def main():
                                       'camera-pose' if a.workload.startswith('living_room_standin') else 'vertex', world, spp_rank),
                        'resolution': [a.res, a.res], 'spp': a.spp, 'spp_per_gpu': spp_rank, 'max_bounces': a.max_bounces,
                        'parallelism': 'sample-sharded x%d' % world, 'world_size': world, 'pool_cap_mb': pool_cap_mb,
+                       'samples_per_launch': timed_batch, 'sample_workers': timed_workers,
                        'schedule': os.environ.get('RDR_BENCH_SCHEDULE_NOTE', 'library default: two sample workers, batches as large as the buffer cache holds')},
             # per rank: wall time per step, and the part of it spent inside render() (the rest: the one collective + waiting
             # for the slowest rank) -- so that a scaling curve explains itself

@@ -272,7 +272,10 @@ uint64_t rdr_trim_cache(void);
  * and how often the host has read a live-lane count back from the device, since the library was loaded.  A steady-state
  * rdr_render() adds nothing to either (the reference allocates its PathBuffer per call, src/pathtracer.cpp:36-152, and
  * reads a count after every stage, :292,590,833). */
-typedef struct rdr_debug_counters { uint64_t device_mallocs, host_count_reads; } rdr_debug_counters;
+typedef struct rdr_debug_counters {
+    uint64_t device_mallocs, host_count_reads;
+    uint64_t last_batch_samples, last_workers;      /* how the last gradient render of this process was scheduled: samples per launch set, host threads */
+} rdr_debug_counters;
 void rdr_debug_counters_get(rdr_debug_counters *out);
 
 /* Test hook: the triangle hierarchy the kernels of this Scene built (bvh_gpu.cpp) against the host builder's on the same

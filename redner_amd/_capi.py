@@ -128,7 +128,8 @@ class TraceStats(C.Structure):
 
 
 class DebugCounters(C.Structure):
-    _fields_ = [('device_mallocs', C.c_uint64), ('host_count_reads', C.c_uint64)]
+    _fields_ = [('device_mallocs', C.c_uint64), ('host_count_reads', C.c_uint64),
+                ('last_batch_samples', C.c_uint64), ('last_workers', C.c_uint64)]
 
 
 EXPORTS = ('rdr_scene_create', 'rdr_scene_destroy', 'rdr_scene_max_generic_texture_dimension',

@@ -144,6 +144,8 @@ void rdr_set_build_flags(unsigned flags) { rdr::build_flags_ref().store(flags); 
 void rdr_debug_counters_get(rdr_debug_counters *out) {
     out->device_mallocs = exec::pool_device_mallocs();
     out->host_count_reads = exec::host_count_reads();
+    out->last_batch_samples = (uint64_t)rdr::last_schedule()[0].load();
+    out->last_workers = (uint64_t)rdr::last_schedule()[1].load();
 }
 
 int rdr_debug_dump_edges(const rdr_scene *scene, const char *path) {

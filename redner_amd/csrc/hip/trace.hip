@@ -405,9 +405,13 @@ __global__ void __launch_bounds__(256) trace_wide_kernel(rt::BvhD bvh, const rt:
 // vector-ALU lane utilisation of these launches 0.19 -> 0.28.  (A vote per step on top -- lanes on leaves park, a step of the
 // wave is either the box body or the triangle body -- was measured as well: 8-10 % slower than refilling alone, whatever the
 // number of parked lanes it waits for.)
-template <bool ANY, class IDX, class Fetch>
+// LDSN > 0 (hybrid stack, big hierarchies): the first LDSN entries of a lane's stack are its LDS column, deeper ones go to a
+// private array (scratch) -- the walk is at depth < 16 nearly always, and 16 int entries instead of 32 / 40 let six workgroups
+// share a CU's LDS where four / three did: a hierarchy beyond the L2 is latency-bound and wants the waves (profiles/r6_notes.md).
+constexpr int kHybridLds = 16, kHybridSpill = rt::kTraverseStack - kHybridLds;
+template <bool ANY, class IDX, int LDSN, class Fetch>
 __device__ inline bool traverse_some(const rt::BvhD &bvh, const float o[3], const float d[3], const float inv[3], float tnear, float tfar,
-                                     IDX *stack, rt::Hit &best, int &cur, int &sp, int budget, const Fetch &fetch) {
+                                     IDX *stack, int (&spill)[LDSN > 0 ? kHybridSpill : 1], rt::Hit &best, int &cur, int &sp, int budget, const Fetch &fetch) {
     using namespace rt;
     for (int it = 0; it < budget; ++it) {
         const Node n = fetch(cur);
@@ -432,7 +436,8 @@ __device__ inline bool traverse_some(const rt::BvhD &bvh, const float o[3], cons
             if (hl && hr) {
                 int near = n.a, far = n.a + 1;
                 if (tr < tl) { near = n.a + 1; far = n.a; }
-                stack[sp * 256] = (IDX)far; ++sp;
+                if (LDSN == 0 || sp < LDSN) stack[sp * 256] = (IDX)far; else spill[sp - LDSN] = far;
+                ++sp;
                 cur = near;
                 continue;
             } else if (hl) { cur = n.a; continue; }
@@ -440,7 +445,7 @@ __device__ inline bool traverse_some(const rt::BvhD &bvh, const float o[3], cons
         }
         if (sp == 0) return true;
         --sp;
-        cur = (int)stack[sp * 256];
+        cur = (LDSN == 0 || sp < LDSN) ? (int)stack[sp * 256] : spill[sp - LDSN];
     }
     return false;
 }
@@ -450,7 +455,7 @@ __device__ inline bool traverse_some(const rt::BvhD &bvh, const float o[3], cons
 // (24 bins), dead slots (tmax < 0) last.  A counting sort of the 256 indices by ballots, one byte per index in LDS; nothing
 // else moves: rays are read and hits written by queue slot, every ray takes the same steps, so the hit ids are the same.
 template <bool ANY, int STACK, class IDX, bool SORT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STACK <= 24 ? 7 : (STACK <= 32 ? 4 : 1), 8))) trace_refill_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays, rt::HitRec *__restrict__ hits,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STACK <= 16 ? 6 : (STACK <= 24 ? 7 : (STACK <= 32 ? 4 : 1)), 8))) trace_refill_kernel(rt::BvhD bvh, const rt::RayRec *__restrict__ rays, rt::HitRec *__restrict__ hits,
                                                            int n, const int *count, int rays_per_lane, int idle_min, int steps, int sort_mode) {
     if (count) { const int c = *count; n = c < n ? c : n; }
     const int chunk = 64 * rays_per_lane;
@@ -514,6 +519,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STACK 
     int slot = 0, cur = 0, sp = 0;
     rt::Hit best{0.f, -1, -1};
     float o[3] = {0, 0, 0}, d[3] = {1, 1, 1}, inv[3] = {1, 1, 1}, tmin = 0, tmax = -1;
+    constexpr int kLdsN = (STACK == kHybridLds && sizeof(IDX) == 4) ? kHybridLds : 0;       // 16 int entries: the hybrid stack
+    int spill[kLdsN > 0 ? kHybridSpill : 1];
     for (;;) {
         const unsigned long long idle = __ballot(!live);
         const int nidle = __popcll(idle);
@@ -537,7 +544,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STACK 
         }
         if (__ballot(live) == 0ull) { if (next >= end) break; continue; }
         if (live) {
-            if (traverse_some<ANY, IDX>(bvh, o, d, inv, tmin, tmax, stack, best, cur, sp, steps, fetch)) {
+            if (traverse_some<ANY, IDX, kLdsN>(bvh, o, d, inv, tmin, tmax, stack, spill, best, cur, sp, steps, fetch)) {
                 hits[slot] = rt::HitRec{best.shape, best.shape >= 0 ? best.prim : -1};
                 live = false;
             }
@@ -736,21 +743,29 @@ void trace(const rt::BvhD &bvh, const rt::RayRec *rays, rt::HitRec *hits, Count 
         // big hierarchies (int entries): 32 entries where that covers the tree -- 40 KiB of LDS per workgroup instead of 49: four
         // workgroups per CU instead of three (a hierarchy beyond the L2 is latency-bound: more waves, profiles/r6_notes.md)
         const bool mid32 = !small && bvh.stack_need <= 32;
+        // ... and the hybrid stack (16 LDS entries + scratch: six workgroups per CU) for every hierarchy too big for the 16-bit
+        // column: 0.92 M triangles 2.39 -> 2.73, 3.7 M 2.02 -> 2.33 G rays/s against the 32-entry tier.  RDR_TRACE_HYBRID=0: the tiers.
+        static const bool hybrid_on = [] { const char *e = std::getenv("RDR_TRACE_HYBRID"); return !(e && e[0] == '0'); }();
+        const bool hybrid = !small && hybrid_on;
 #define RDR_REFILL_LAUNCH(ANY_, STACK_, IDX_, SORT_) \
         hipLaunchKernelGGL((trace_refill_kernel<ANY_, STACK_, IDX_, SORT_>), dim3(rblocks), dim3(256), 0, s, bvh, rays, hits, n, n_dev, k_arg, idle_min, steps, sort_mode)
         const bool sort_on = sort_mode > 0 && k_arg == 4;
         if (sort_on) {
             if (any && small) RDR_REFILL_LAUNCH(true, 24, unsigned short, true);
+            else if (any && hybrid) RDR_REFILL_LAUNCH(true, 16, int, true);
             else if (any && mid32) RDR_REFILL_LAUNCH(true, 32, int, true);
             else if (any) RDR_REFILL_LAUNCH(true, rt::kTraverseStack, int, true);
             else if (small) RDR_REFILL_LAUNCH(false, 24, unsigned short, true);
+            else if (hybrid) RDR_REFILL_LAUNCH(false, 16, int, true);
             else if (mid32) RDR_REFILL_LAUNCH(false, 32, int, true);
             else RDR_REFILL_LAUNCH(false, rt::kTraverseStack, int, true);
         } else {
             if (any && small) RDR_REFILL_LAUNCH(true, 24, unsigned short, false);
+            else if (any && hybrid) RDR_REFILL_LAUNCH(true, 16, int, false);
             else if (any && mid32) RDR_REFILL_LAUNCH(true, 32, int, false);
             else if (any) RDR_REFILL_LAUNCH(true, rt::kTraverseStack, int, false);
             else if (small) RDR_REFILL_LAUNCH(false, 24, unsigned short, false);
+            else if (hybrid) RDR_REFILL_LAUNCH(false, 16, int, false);
             else if (mid32) RDR_REFILL_LAUNCH(false, 32, int, false);
             else RDR_REFILL_LAUNCH(false, rt::kTraverseStack, int, false);
         }

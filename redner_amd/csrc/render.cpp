@@ -1120,6 +1120,7 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
     int workers = 1;
     if (samples_independent) workers = std::max(1, std::min(tune.workers > 0 ? tune.workers : exec::sample_workers(PL, num_batches, batch.on), num_batches));
     if (chain) workers = 1;            // (also one sample per launch: the scratch chain runs through the samples in order)
+    if (d_image != nullptr) { last_schedule()[0].store(S); last_schedule()[1].store(workers); }
 
     // Everything one sample (or sample batch) needs between its camera rays and its last gradient add.
     struct Worker {

@@ -105,6 +105,9 @@ inline Tuning resolve_tuning(const rdr_tuning *t) {
     return r;
 }
 
+// how the last gradient render was scheduled {samples per launch set, workers} (rdr_debug_counters: bench.py's single-chain legs repeat the batch size)
+inline std::atomic<int> *last_schedule() { static std::atomic<int> s[2]; return s; }
+
 // the calling thread's current tuning (default-constructed = resolve_tuning(nullptr) on first use)
 inline Tuning &tuning() {
     static thread_local Tuning t = resolve_tuning(nullptr);

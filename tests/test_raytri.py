@@ -185,6 +185,65 @@ def test_gpu_traversal_kernel_forms(gpu_backend, env):
     assert ' passed' in r.stdout and 'failed' not in r.stdout, r.stdout[-500:]
 
 
+BIG_WORKER = r"""
+import os, sys
+sys.path[:0] = [%(root)r, %(root)r + '/tests']
+import numpy as np, torch
+from redner_amd import _capi, redner
+from redner_amd.render_pytorch import RenderFunction
+import scenes
+dev = torch.device('cuda:0')
+sc = scenes.bunny_box_subdivided(dev, resolution=(16, 16), levels=2)          # 230 k triangles: > 65 535 node records
+args = RenderFunction.serialize_scene(sc, 1, 1, sampler_type=redner.SamplerType.sobol, device=dev,
+                                      use_primary_edge_sampling=False, use_secondary_edge_sampling=False)
+u = RenderFunction.unpack_args((1, 2), args[0], args[1:])
+g = torch.Generator().manual_seed(5)
+n = 300000
+o = (torch.rand(n, 3, generator=g) - 0.5) * 1.6
+d = torch.randn(n, 3, generator=g); d = d / d.norm(dim=1, keepdim=True)
+rays = torch.zeros(n, 8); rays[:, 0:3] = o; rays[:, 3] = 1e-3; rays[:, 4:7] = d; rays[:, 7] = float('inf')
+rays[::7, 7] = -1.0                                # dead slots
+rays = rays.to(dev).contiguous()
+out = {}
+for any_hit in (0, 1):
+    hits = torch.zeros(n, 2, dtype=torch.int32, device=dev)
+    assert _capi.lib().rdr_scene_trace(u.scene._handle, rays.data_ptr(), hits.data_ptr(), n, any_hit) == 0
+    h = hits.cpu().numpy()
+    out['h%%d' %% any_hit] = h if not any_hit else (h[:, 0] >= 0)
+np.savez(%(out)r, **out)
+"""
+
+
+@pytest.mark.gpu
+def test_big_hierarchy_kernel_forms_agree(gpu_backend, tmp_path):
+    """Hierarchies with more than 65 535 node records take the int-entry forms of the kernels: the 4-wide records (default for a
+    queue this size), the plain binary kernel, the refilling kernel with the hybrid LDS + scratch stack and with the 32 / 40-entry
+    LDS tiers, each with and without the octant order -- all must return the same hit ids (closest) / the same verdict (any)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    forms = [('wide', {}), ('binary', {'RDR_TRACE_BINARY': '1'}),
+             ('refill_hybrid', {'RDR_TRACE_BINARY': '1', 'RDR_TRACE_REFILL_ALL': '1'}),
+             ('refill_hybrid_queue_order', {'RDR_TRACE_BINARY': '1', 'RDR_TRACE_REFILL_ALL': '1', 'RDR_REFILL_SORT': '0'}),
+             ('refill_tiers', {'RDR_TRACE_BINARY': '1', 'RDR_TRACE_REFILL_ALL': '1', 'RDR_TRACE_HYBRID': '0'}),
+             ('refill_tiers_axis_order', {'RDR_TRACE_BINARY': '1', 'RDR_TRACE_REFILL_ALL': '1', 'RDR_TRACE_HYBRID': '0', 'RDR_REFILL_SORT': '2'})]
+    first = None
+    for name, env in forms:
+        out = str(tmp_path / (name + '.npz'))
+        script = tmp_path / (name + '.py')
+        script.write_text(BIG_WORKER % {'root': root, 'out': out})
+        r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        z = np.load(out)
+        if first is None:
+            first = {k: z[k] for k in z.files}
+            assert (first['h0'][:, 0] >= 0).sum() > 100000 and (first['h0'][::7, 0] == -1).all()
+        else:
+            assert np.array_equal(z['h0'], first['h0']), name
+            assert np.array_equal(z['h1'], first['h1']), name
+
+
 # ---- the hierarchy the kernels build (bvh_gpu.cpp) ----------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize('builder', ['single_triangle', 'two_triangles', 'bunny_box', 'living_room_standin', 'triangle_soup_large'])
