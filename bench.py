@@ -369,12 +369,13 @@ def large_hierarchy_counters(a):
         shutil.rmtree(base, ignore_errors=True)
 
 
-def alone_leg(st, alg_bytes_launch):
-    """The same kernel in an extra untimed step on one stream (RDR_NO_OVERLAP=1): informative, not the headline."""
+def alone_leg(st, alg_bytes_step):
+    """The same kernel in an extra untimed step of the short job with ONE sample worker and every stage on one stream: no other
+    kernel beside a closest-hit launch.  Informative, not the headline.  `alg_bytes_step`: algorithmic bytes of that step."""
     ms = st.closest_ms / max(st.closest_launches, 1)
-    achieved = alg_bytes_launch / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    return {'mean_launch_ms': ms, 'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS,
-            'note': 'untimed extra step with every stage on one stream'}
+    achieved = alg_bytes_step / (st.closest_ms * 1e-3) / 1e9 if st.closest_ms > 0 else 0.0
+    return {'mean_launch_ms': ms, 'launches': st.closest_launches, 'achieved': achieved, 'frac': achieved / HBM_PEAK_GBS,
+            'note': 'untimed extra step, one sample worker, every stage on one stream'}
 
 
 # ---- hardware counters, collected from inside the run ------------------------------------------------------------------
@@ -710,7 +711,8 @@ def main():
     # everything below is untimed and works on a short job (the counters do not depend on the sample count)
     # (32 spp: enough samples for the library to form the same sample batches as in the timed job, so that launches of the
     #  counted job and of the timed job cover the same number of rays)
-    short = Prepared(redner, build_scene(a, dev, a.res), min(spp_rank, 32), min(spp_rank, 32), 0, a.max_bounces, dev)
+    short_spp = min(spp_rank, 32)
+    short = Prepared(redner, build_scene(a, dev, a.res), short_spp, short_spp, 0, a.max_bounces, dev)
     scene_build_warm_ms = short.scene_build_s * 1e3      # second Scene of the process: allocator, staging buffer, topology caches warm
     # instrumented traversal variant: node / triangle records per launch
     lib.rdr_trace_stats_enable(0, 1)
@@ -737,21 +739,31 @@ def main():
 
     out = None
     if rank == 0:
+        # Accounting is per SAMPLE, not per launch: the instrumented pass counts the records of the short job exactly; a sample of
+        # the timed job draws the same kind of rays, so the timed region's algorithmic bytes are bytes-per-sample x its samples --
+        # whatever the launch shapes were (forward launches cover 16 samples, gradient launches 8, the single-chain leg 8 and 8).
         rays = cnt.closest_rays
         alg_bytes = rays * (RAY_BYTES + HIT_BYTES) + cnt.closest_nodes * NODE_BYTES + cnt.closest_wide_nodes * WIDE_NODE_BYTES + cnt.closest_tris * TRI_BYTES
-        alg_bytes_launch = alg_bytes / max(cnt.closest_launches, 1)
+        alg_bytes_sample = alg_bytes / float(short_spp)
+        rays_sample = rays / float(short_spp)
+        alg_bytes_timed = alg_bytes_sample * spp_rank * a.steps          # this rank's timed region
+        alg_bytes_launch = alg_bytes_timed / max(st.closest_launches, 1)
         mean_launch_ms = st.closest_ms / max(st.closest_launches, 1)
         # Schedule-invariant form (round 6): the algorithmic bytes of ALL closest-hit launches of the timed region over the time
         # during which at least one of them was in flight (union of their [start, end] event intervals).  With one chain of
         # launches that is bytes over mean launch duration; with two sample workers two launches trace side by side -- each
         # takes longer, the same rays are traced at the same total rate -- and the per-launch quotient would halve for no reason.
         busy_ms = st.closest_union_ms if st.closest_union_ms > 0 else st.closest_ms
-        achieved = alg_bytes_launch * st.closest_launches / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0
-        achieved_per_launch = alg_bytes_launch / (mean_launch_ms * 1e-3) / 1e9 if mean_launch_ms > 0 else 0.0
-        rays_per_launch = rays / max(cnt.closest_launches, 1)
+        achieved = alg_bytes_timed / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0
+        achieved_per_launch = alg_bytes_timed / (st.closest_ms * 1e-3) / 1e9 if st.closest_ms > 0 else 0.0
+        rays_per_launch = rays_sample * spp_rank * a.steps / max(st.closest_launches, 1)
         prof = None
         if world == 1 and not a.no_profile and not under_profiler():
             try:
+                # the passes run in child processes: what this process parks (up to 32 GiB, > 10 % of the device) would make the
+                # library size their batches for a shared device (render.cpp: memory_held_by_others)
+                redner.trim_cache()
+                torch.cuda.empty_cache()
                 prof = profile_kernels(a, timed_batch)
             except Exception as e:      # the counters must never take the throughput number down with them
                 prof = {'error': repr(e)}
@@ -798,13 +810,13 @@ def main():
                                         'note': 'bytes of one launch / its own duration, with whatever shares the GPU beside it'},
                          'mean_launch_ms': mean_launch_ms, 'launches_per_step': st.closest_launches / max(a.steps, 1),
                          'rays_per_launch': rays_per_launch,
-                         'rays_per_s': rays_per_launch * st.closest_launches / (busy_ms * 1e-3) if busy_ms > 0 else None,
+                         'rays_per_s': rays_sample * spp_rank * a.steps / (busy_ms * 1e-3) if busy_ms > 0 else None,
                          'nodes_per_ray': cnt.closest_nodes / max(rays, 1), 'wide_nodes_per_ray': cnt.closest_wide_nodes / max(rays, 1), 'tris_per_ray': cnt.closest_tris / max(rays, 1),
-                         'algorithmic_bytes_per_launch': alg_bytes_launch,
+                         'algorithmic_bytes_per_launch': alg_bytes_launch, 'algorithmic_bytes_per_sample': alg_bytes_sample,
                          'hbm_frac_measured': tc['hbm_frac_of_peak'] if tc else None,
                          'valu_lane_util': tc['valu_lane_util'] if tc else None,
-                         'traversal_share_of_step': (st.closest_union_ms + st.any_union_ms) / (dt * 1e3) if st.closest_union_ms > 0 else (st.closest_ms + st.any_ms) / (dt * 1e3),
-                         'alone': alone_leg(alone, alg_bytes_launch) if alone is not None else None,
+                         'closest_hit_busy_share_of_step': busy_ms / (dt * 1e3), 'any_hit_busy_share_of_step': (st.any_union_ms or st.any_ms) / (dt * 1e3),
+                         'alone': alone_leg(alone, alg_bytes_sample * short_spp) if alone is not None else None,
                          'kernels': prof,
                          'note': 'frac = algorithmic bytes (SURVEY.md 8d) over launch time: the 1 MB hierarchy is L2-resident, '
                                  'so this is an L2-served rate; hbm_frac_measured is what reaches HBM (counters), and the '
@@ -816,6 +828,8 @@ def main():
             try:
                 big = large_hierarchy_leg(LARGE_LEVELS, LARGE_SPP)
                 if not a.no_profile and not under_profiler():
+                    redner.trim_cache()
+                    torch.cuda.empty_cache()
                     big['counters'] = large_hierarchy_counters(a)
                     if big['counters'] and big['counters'].get('launches_counted'):
                         big['traffic'] = big['counters']['hbm_bytes_per_launch']
