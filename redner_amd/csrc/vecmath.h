@@ -32,7 +32,8 @@ namespace rdr {
 // The seven transcendental functions of the path are glibc's, bit for bit, on the device as on the oracle's host
 // (libm_exact.h): inside namespace rdr an unqualified sin(x) ... is gm::sin(x).  All call sites pass doubles, like the
 // reference's Real; a float argument would have selected glibc's float routine there and is a compile error here.
-#ifndef RDR_PLATFORM_LIBM    // A/B builds only (tools/build_variant.sh): the device's own libm, as in rounds 1-3
+#ifndef RDR_PLATFORM_LIBM    // defined for the DEFAULT product build (libredner_amd.so: the device's own libm, __graft_entry__.build_native);
+                             // undefined: the glibc-exact routines of libm_exact.h (libredner_amd_exact.so, the CPU harness)
 using gm::sin; using gm::cos; using gm::atan2; using gm::atan; using gm::acos; using gm::log; using gm::pow;
 #endif
 

@@ -163,7 +163,10 @@ def _compare(mine, ref, render_oracle):
     scene is listed (ORACLE_UNSTABLE) and compared with the second render.  (Found the hard way: with an 8 KiB threshold and
     no zero fill the oracle's own two renders of four pixel-centre scenes differed by up to 30 % in a vertex gradient.)"""
     bad = _compare_once(mine, ref, render_oracle)
-    if bad and ON_GPU and bad not in ('keys differ',):
+    # (round 6: also on the CPU legs -- two of three full CPU-suite runs failed ONE scene of ONE leg, a different leg each time,
+    #  on a few-element tensor whose single pass and striped sum had moved together by 3e-4 between runs of the same scene
+    #  against a deterministic harness: the oracle's run-to-run behaviour, not its fp32 noise)
+    if bad and bad not in ('keys differ',):
         ref2 = render_oracle(None)
         if _distance(ref2, ref) is not None:
             ORACLE_UNSTABLE.append(SCENE[0])
@@ -196,7 +199,16 @@ def _few_element_check(bad, mine, ref, render_oracle):
     n = np.linalg.norm(fine)
     own = np.linalg.norm(ref[k].astype(np.float64) - fine) / n
     d = np.linalg.norm(mine[k].astype(np.float64) - fine) / n
-    return None if d <= 1e-4 + own else '%s: %.3e against the striped sum (oracle single pass: %.3e)' % (k, d, own)
+    if d <= 1e-4 + own:
+        return None
+    # once more with fresh oracle passes (their fp32 atomics interleave differently every time): the better of the two sums decides
+    fine2 = sum(render_oracle((j, K))[k].astype(np.float64) for j in range(K))
+    n2 = np.linalg.norm(fine2)
+    d2 = np.linalg.norm(mine[k].astype(np.float64) - fine2) / n2
+    own2 = np.linalg.norm(ref[k].astype(np.float64) - fine2) / n2
+    if d2 <= 1e-4 + own2:
+        return None
+    return '%s: %.3e / %.3e against two striped sums (oracle single pass: %.3e / %.3e)' % (k, d, d2, own, own2)
 
 
 def _scene_rich(seed, device):
