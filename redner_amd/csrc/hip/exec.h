@@ -439,8 +439,11 @@ __global__ void __launch_bounds__(256) persistent_kernel(W w, int n, const int *
 // longest walk of a chunk, only for the longest walk of the launch.  Items that are neighbours in the list (neighbouring pixels:
 // walks of similar length through the same tree nodes) stay in one wave.  For walks that are long and uneven (the hierarchical
 // edge pick: 20 ... 300 steps).
+#ifndef RDR_CHUNKED_MIN_BLOCKS             // (variant builds: workgroups per CU the chunked walks are compiled for)
+#define RDR_CHUNKED_MIN_BLOCKS 1
+#endif
 template <class W>
-__global__ void __launch_bounds__(256) chunked_kernel(W w, int n, const int *count, int items_per_lane, int idle_min, int steps, int *next_chunk) {
+__global__ void __launch_bounds__(256, RDR_CHUNKED_MIN_BLOCKS) chunked_kernel(W w, int n, const int *count, int items_per_lane, int idle_min, int steps, int *next_chunk) {
     if (count) { const int c = *count; n = c < n ? c : n; }
     const int chunk = 64 * items_per_lane;
     const int lane = threadIdx.x & 63;

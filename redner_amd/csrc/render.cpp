@@ -631,7 +631,11 @@ struct Backward {
         const int dim0 = opt.sample_pixel_center ? 0 : 2;
         const bool pickh_fused = tuning().has(RDR_TUNE_PICKH_FUSED);     // A/B: the one-loop form
         const bool pickh_lazy = tuning().has(RDR_TUNE_PICKH_LAZY);       // A/B: per-field node loads
-        const bool pickh_one_launch = tuning().has(RDR_TUNE_PICKH_ONE_LAUNCH);       // A/B: one slot per lane from root to last leaf
+        // Small frames are chains of short launches (a 256 x 256 x 4 spp iteration: ~330 of them in 11 ms): the two extra launches
+        // of the split pick and the three of every list compaction cost more there than fuller waves give back (+0.3-0.4 ms,
+        // profiles/r6_notes.md).  The large-frame forms from 2^19 lanes per launch set on, or everywhere on request.
+        const bool large_forms = tuning().has(RDR_TUNE_LARGE_FORMS) || P >= (1 << 19);
+        const bool pickh_one_launch = tuning().has(RDR_TUNE_PICKH_ONE_LAUNCH) || !large_forms;       // one slot per lane from root to last leaf
         const int pickh_k = tuning().pickh_k, pickh_idle = tuning().pickh_idle, pickh_steps = tuning().pickh_steps;      // rdr_tuning::pickh_*
         // The two edge picks of a secondary pass: slot setup, the per-mode slot lists, the NEE-mode gather and the hierarchical
         // pick.  `early`: everything off the calling stream (setup + lists + gather on side stream 1, hierarchical pick on side
@@ -762,7 +766,7 @@ struct Backward {
         // lies below a horizon (the forward pass left both in the slice's occlusion byte): it runs over the compacted list of the
         // others -- full waves (lane utilisation 0.61 over the whole list).  Order-preserving: the adds keep their order.
         // (its own scratch: the pick phase's compactions may be in flight on another stream of this thread)
-        static const bool nee_compact = std::getenv("RDR_NO_NEE_COMPACT") == nullptr;
+        const bool nee_compact = !tuning().has(RDR_TUNE_NO_NEE_COMPACT) && large_forms;
         auto adj_nee = [&](const AdjBounceArgs &ba, exec::Count nA, int d) {
             if (!nee_compact || !vs[d].occl) { launch_v(lean, nA, AdjBounceNee{ba}); return; }
             AdjBounceArgs lit = ba;

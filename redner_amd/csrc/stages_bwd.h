@@ -74,7 +74,10 @@ struct AdjBounceScatter {
     AdjBounceArgs a;
     static constexpr int kMidBlocksPerCU = 2;          // 320 -> 256 registers (256 B of scratch), two waves per SIMD
     static constexpr int kMinBlocksPerCU = 2;          // general form
-    static constexpr int kLeanBlocksPerCU = 3;         // 190 -> 168 registers (100 B of scratch), three waves per SIMD: +2 % on the benchmark
+#ifndef RDR_ADJ_SCATTER_LEAN_BLOCKS          // (variant builds: tools/build_render_variant.sh x -DRDR_ADJ_SCATTER_LEAN_BLOCKS=4)
+#define RDR_ADJ_SCATTER_LEAN_BLOCKS 3
+#endif
+    static constexpr int kLeanBlocksPerCU = RDR_ADJ_SCATTER_LEAN_BLOCKS;         // 190 -> 168 registers (100 B of scratch), three waves per SIMD: +2 % on the benchmark
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; a.adj.plain = 1; }
     RDR_FN void make_mid() { mid_scene(a.sc); a.nd = 3; a.radiance_dim = 0; }
     RDR_FN void operator()(int idx) const {
@@ -206,6 +209,9 @@ struct AdjBounceNee {
     // launch on the config-5 stand-in); the same cap costs AdjBounceScatter 650 B of spills and 1.8 -> 3.0 ms, so it keeps one wave
     static constexpr int kMinBlocksPerCU = 2;
     static constexpr int kMidBlocksPerCU = 2;
+#ifdef RDR_ADJ_NEE_LEAN_BLOCKS              // (variant builds only; the lean form runs at 231 registers, two waves per SIMD)
+    static constexpr int kLeanBlocksPerCU = RDR_ADJ_NEE_LEAN_BLOCKS;
+#endif
     AdjBounceArgs a;
     RDR_FN void make_lean() { lean_scene(a.sc); lean_slice(a.v); lean_slice(a.vn); a.nd = 3; a.radiance_dim = 0; a.adj.plain = 1; }
     RDR_FN void make_mid() { mid_scene(a.sc); a.nd = 3; a.radiance_dim = 0; }

@@ -18,6 +18,12 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
 # RDR_TEST_LIBM=exact|default restricts a run to one build.
 GPU_BUILDS = [b for b in ('exact', 'default') if os.environ.get('RDR_TEST_LIBM', b) == b]
 
+# The fixtures are small frames; the benchmark is a large one.  Below 2^19 lanes per launch set the library keeps the one-launch
+# hierarchical pick and un-compacted adjoint lists (fewer launches: render.cpp `large_forms`).  The test session asks for the
+# LARGE-frame forms at every size, so that what the benchmark runs is what the fixtures, the fuzz legs and the harness check;
+# tests/test_tuning.py (`small_frame_forms`, `pickh_one_launch`, `no_nee_compact`) covers the small-frame forms.
+os.environ.setdefault('RDR_LARGE_FRAME_FORMS', '1')
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run by the driver with -m gpu)')

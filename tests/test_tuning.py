@@ -24,6 +24,9 @@ SCHEDULES = {
     'pickh_fused': {'flags': K.TUNE_PICKH_FUSED},
     'pickh_lazy': {'flags': K.TUNE_PICKH_LAZY},
     'pickh_one_launch': {'flags': K.TUNE_PICKH_ONE_LAUNCH},
+    'no_nee_compact': {'flags': K.TUNE_NO_NEE_COMPACT},
+    'small_frame_forms': {'flags': K.TUNE_PICKH_ONE_LAUNCH | K.TUNE_NO_NEE_COMPACT},
+    'large_frame_forms': {'flags': K.TUNE_LARGE_FORMS},
     'pickh_walk_params': {'pickh_slots_per_lane': 4, 'pickh_idle_lanes': 32, 'pickh_steps': 3},
     'pickh_one_launch_lazy': {'flags': K.TUNE_PICKH_ONE_LAUNCH | K.TUNE_PICKH_LAZY},
     'gather_hand_over': {'gather_budget': 2, 'gather_heavy_cap_plus1': 4, 'gather_work_cap_plus1': 6},
