@@ -18,20 +18,27 @@ outside the timed region and reported separately; inputs 
 `--workload living_room_standin` is BASELINE config 5's stand-in (tests/scenes.py): the general kernels
 (mip-mapped textures, two-sided materials, ray differentials), max_bounces 6, camera-pose gradients.
 
-The library runs with its defaults (at most 16 GiB of device memory parked between calls: 7 Sobol' samples of this frame per
-launch); a process that raises the bound (redner.set_pool_cap_mb(65536) / RDR_POOL_CAP_MB) gets 16 samples per launch and
-+1-2 % (profiles/r4_notes.md).  per_rank_ms_per_step / per_rank_render_ms_per_step: every rank's wall time per step and the part
-of it inside render() (the rest: the one collective per step + waiting for the slowest rank).
+The library parks at most 8 GiB of device memory between calls by default; this benchmark owns its GPU and raises the bound to
+32 GiB (`config.pool_cap_mb`; RDR_POOL_CAP_MB overrides): two sample workers x 8 Sobol' samples of the frame per launch set
+(8 GiB: 2 x 2, 69.7 Msamples/s; 16 GiB: 2 x 4, 74.1; 32 GiB: 2 x 8, 74.4-76.1; profiles/r6_notes.md).  `config.samples_per_launch` /
+`config.sample_workers` say how the library scheduled the timed steps.  per_rank_ms_per_step / per_rank_render_ms_per_step: every
+rank's wall time per step and the part of it inside render() (the rest: the one collective per step + waiting for the slowest rank).
 
 Extra objects in the JSON line:
   roofline      -- the closest-hit traversal kernel by SURVEY.md section 8d: algorithmic bytes (40 B per ray +
-                   32 B per node record + 36 B per triangle tested, counted by the instrumented kernel on the
-                   same rays in an untimed pass) / mean launch time from HIP events on the launch stream inside
-                   the timed region, vs 8 TB/s.  Next to it what the hardware counters say (rocprofv3 passes
-                   run from inside this process on a 2-spp job, `profile`): HBM bytes actually moved
-                   (hbm_frac_measured), vector-ALU lane utilisation, rays/s -- and the same for the kernels that
-                   dominate the backward pass (`kernels`: fp64 VALU lane-operations/s against the 39.3 T/s the
-                   chip can issue, HBM bytes/s against 8 TB/s).
+                   32 B per node record + 36 B per triangle tested, counted per SAMPLE by the instrumented kernel in an
+                   untimed pass; the timed region's bytes = bytes per sample x its samples) / the time during which at
+                   least one closest-hit launch was in flight (union of HIP-event intervals on the launch streams inside
+                   the timed region), vs 8 TB/s.  `per_launch`: the same bytes / the sum of the launches' own durations;
+                   `alone`: an extra untimed step with one sample worker and one stream.  Next to it what the hardware
+                   counters say (rocprofv3 passes run from inside this process on a 32-spp job, `kernels`): HBM bytes
+                   actually moved (`traffic`, hbm_frac_measured), vector-ALU lane utilisation -- and the same for the
+                   kernels that dominate the backward pass (fp64 VALU lane-operations/s against the 39.3 T/s the chip can
+                   issue, HBM bytes/s against 8 TB/s).
+  roofline_large-- the same kernel on a hierarchy that does not fit the L2 (bunny tessellated to 3.7 M triangles), forward
+                   render, + three counter passes: what the design does when traversal goes to the MALL / HBM.
+  collective / sharded_check -- when a process group exists: the one all_gather per step (backend, bytes, ms), and the
+                   gathered sum of one sample per rank against the same blocks rendered on rank 0 (bit-identical).
   cpu_baseline  -- the reference's own C++ core (oracle/_ref, Embree stand-in) on this box's host
                    cores, on bounded samples of the same workload (rank 0, N = 1 only); `gpu_vs_reference`: the full frame
                    at 1 spp rendered by both and compared (image + every gradient tensor).
