@@ -731,7 +731,7 @@ def main():
 
     # ONE stream: the traversal kernel's launch duration without a neighbour on the GPU (in the timed region the
     # shadow-ray launch of the same bounce runs beside every closest-hit launch)
-    alone = None
+    alone = one_chain = None
     if not a.no_alone_leg:
         short.u.options.tuning.flags |= _capi.TUNE_NO_OVERLAP          # rdr_tuning: every stage on the calling stream ...
         short.u.options.tuning.workers = 1                              # ... of ONE host thread, the timed job's samples per launch
@@ -741,6 +741,19 @@ def main():
         short.step(a.warmup)
         torch.cuda.synchronize(dev)
         alone = trace_stats()
+        lib.rdr_trace_stats_enable(0, 0)
+        # ... and ONE worker with the stages overlapped as usual (shadow-ray launch beside every closest-hit launch, picks and adjoints
+        # on their side streams): the schedule of round 5, whose bench line reported exactly this quotient (bytes / mean launch
+        # duration = bytes / union when one chain of launches is in flight) -- the like-for-like figure across rounds
+        short.u.options.tuning.flags &= ~_capi.TUNE_NO_OVERLAP
+        short.step(a.warmup)                                            # (the schedule's first step: untimed)
+        torch.cuda.synchronize(dev)
+        lib.rdr_trace_stats_enable(1, 0)
+        trace_stats(reset=True)
+        short.step(a.warmup + 1)
+        short.step(a.warmup + 2)
+        torch.cuda.synchronize(dev)
+        one_chain = trace_stats()
         lib.rdr_trace_stats_enable(0, 0)
     del short
 
@@ -824,6 +837,10 @@ def main():
                          'valu_lane_util': tc['valu_lane_util'] if tc else None,
                          'closest_hit_busy_share_of_step': busy_ms / (dt * 1e3), 'any_hit_busy_share_of_step': (st.any_union_ms or st.any_ms) / (dt * 1e3),
                          'alone': alone_leg(alone, alg_bytes_sample * short_spp) if alone is not None else None,
+                         'one_chain': (dict(alone_leg(one_chain, alg_bytes_sample * short_spp * 2),
+                                            note='two untimed extra steps, ONE sample worker, stages overlapped as in the timed region: the '
+                                                 'schedule and the quotient of the round-5 bench line (0.72 there)')
+                                       if one_chain is not None else None),
                          'kernels': prof,
                          'note': 'frac = algorithmic bytes (SURVEY.md 8d) over launch time: the 1 MB hierarchy is L2-resident, '
                                  'so this is an L2-served rate; hbm_frac_measured is what reaches HBM (counters), and the '
