@@ -646,6 +646,8 @@ def main():
         reduce_all()
     lib.rdr_trace_stats_enable(1, 0)
     trace_stats(reset=True)
+    dbg0 = _capi.DebugCounters()
+    lib.rdr_debug_counters_get(ctypes.byref(dbg0))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -676,6 +678,7 @@ def main():
     dbg = _capi.DebugCounters()
     lib.rdr_debug_counters_get(ctypes.byref(dbg))
     timed_batch, timed_workers = int(dbg.last_batch_samples), int(dbg.last_workers)      # how the library scheduled the timed steps
+    timed_mallocs = int(dbg.device_mallocs) - int(dbg0.device_mallocs)                  # hipMalloc calls inside the timed region (0: everything came from the buffer cache)
 
     # untimed, world > 1 (or the forced one-rank collective): the north star's rule "bit-identical sum at 1 vs N GPUs", checked
     # on the hardware the job ran on -- a short job of one sample per rank, gathered and summed as in the timed steps, against
@@ -803,7 +806,7 @@ def main():
                                       'camera-pose' if a.workload.startswith('living_room_standin') else 'vertex', world, spp_rank),
                        'resolution': [a.res, a.res], 'spp': a.spp, 'spp_per_gpu': spp_rank, 'max_bounces': a.max_bounces,
                        'parallelism': 'sample-sharded x%d' % world, 'world_size': world, 'pool_cap_mb': pool_cap_mb,
-                       'samples_per_launch': timed_batch, 'sample_workers': timed_workers,
+                       'samples_per_launch': timed_batch, 'sample_workers': timed_workers, 'device_mallocs_in_timed_region': timed_mallocs,
                        'schedule': os.environ.get('RDR_BENCH_SCHEDULE_NOTE', 'library default: two sample workers, batches as large as the buffer cache holds')},
             # per rank: wall time per step, and the part of it spent inside render() (the rest: the one collective + waiting
             # for the slowest rank) -- so that a scaling curve explains itself
