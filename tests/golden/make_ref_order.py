@@ -30,6 +30,25 @@ HOSTSIM = os.path.join(ROOT, 'tests', 'hostsim', '_build', 'libredner_hostsim.so
 CAM = ('grad_cam_position', 'grad_cam_look_at', 'grad_cam_up')
 
 
+def inputs_digest(builder, res, spp, mb):
+    """SHA-256 over what a ref-order fixture was rendered from: every tensor the scene builder hands to serialize_scene + the
+    render options.  Stored in the fixture (`inputs_sha256`) and recomputed by tests/test_accumulation_order.py: a fixture whose
+    scene or options have since changed is STALE and must be regenerated, not compared with."""
+    import hashlib
+    import torch
+    import scenes
+    from redner_amd import redner
+    from redner_amd.render_pytorch import RenderFunction
+    sc = getattr(scenes, builder)(torch.device('cpu'), resolution=res if isinstance(res, tuple) else (res, res))
+    args = RenderFunction.serialize_scene(sc, spp, mb, sampler_type=redner.SamplerType.sobol, device=torch.device('cpu'), backend=redner)
+    h = hashlib.sha256(('%s %s %d %d' % (builder, res, spp, mb)).encode())
+    for t in args[1:]:
+        if t is not None:
+            a = t.detach().cpu().contiguous().numpy()
+            h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8).copy()
+
+
 def leg(which, case, out):
     import torch  # noqa: F401
     from golden.make_golden import CASES, CONFIG_CASES, render_case
@@ -69,6 +88,9 @@ def make(case, tmp='/tmp', out_dir=HERE):
         n = np.linalg.norm(h64)
         print('%s %-20s harness floats vs one-thread oracle %.3e | oracle vs fp64 sum %.3e | floats vs fp64 sum %.3e'
               % (case, k, np.linalg.norm(h32 - o) / n, np.linalg.norm(o - h64) / n, np.linalg.norm(h32 - h64) / n), flush=True)
+    from golden.make_golden import CASES, CONFIG_CASES
+    spec = (CASES.get(case) or CONFIG_CASES[case])
+    out['inputs_sha256'] = inputs_digest(*spec[:4])
     np.savez(os.path.join(out_dir, case + '_ref_order.npz'), **out)
     return out
 
@@ -129,6 +151,7 @@ def make_bench_job(tmp='/tmp', out_dir=HERE):
         if n > 0:
             print('bench job %-5s (%2d elements) harness floats vs one-thread oracle %.3e | oracle vs fp64 sum %.3e'
                   % (k, o.size, np.linalg.norm(h32 - o) / n, np.linalg.norm(o - h64) / n), flush=True)
+    out['inputs_sha256'] = inputs_digest(*BENCH_JOB)
     np.savez(os.path.join(out_dir, BENCH_FIXTURE), **out)
     return out
 
@@ -140,6 +163,15 @@ if __name__ == '__main__':
         bench_leg(*sys.argv[2:4])
     elif sys.argv[1] == '--bench-job':
         make_bench_job()
+    elif sys.argv[1] == '--stamp':            # add inputs_sha256 to fixtures made before round 6 (their renders are not repeated)
+        from golden.make_golden import CASES, CONFIG_CASES
+        for c in sys.argv[2:]:
+            path = os.path.join(HERE, BENCH_FIXTURE if c == 'bench-job' else c + '_ref_order.npz')
+            z = np.load(path)
+            out = {k: z[k] for k in z.files}
+            out['inputs_sha256'] = inputs_digest(*(BENCH_JOB if c == 'bench-job' else (CASES.get(c) or CONFIG_CASES[c])[:4]))
+            np.savez(path, **out)
+            print(c, out['inputs_sha256'][:6])
     else:
         for c in sys.argv[1:]:
             make(c)

@@ -40,6 +40,10 @@ def test_committed_ref_order_fixture(name):
     """The committed fixtures of the config-size cases (tests/golden/make_ref_order.py): floats in reference order == one-thread
     oracle, bit for bit, for every camera tensor; what is left between the oracle and the fp64 sum is reported."""
     z = np.load(os.path.join(GOLD, name + '_ref_order.npz'))
+    from golden.make_golden import CASES, CONFIG_CASES
+    spec = (CASES.get(name) or CONFIG_CASES[name])
+    assert np.array_equal(z['inputs_sha256'], make_ref_order.inputs_digest(*spec[:4])), \
+        'stale fixture: the scene / options it was rendered from have changed -- python tests/golden/make_ref_order.py ' + name
     keys = [k[len('oracle1t_'):] for k in z.files if k.startswith('oracle1t_')]
     assert 'grad_cam_position' in keys
     for k in keys:
@@ -73,6 +77,8 @@ def test_committed_bench_job_fixture():
     exactly.  (Material / light tensors are added in another kernel order by the harness: close to the reference, not bit-equal;
     both are within 4e-4 of the fp64 sum.)"""
     z = np.load(os.path.join(GOLD, make_ref_order.BENCH_FIXTURE))
+    assert np.array_equal(z['inputs_sha256'], make_ref_order.inputs_digest(*make_ref_order.BENCH_JOB)), \
+        'stale fixture: python tests/golden/make_ref_order.py --bench-job'
     keys = sorted(k[len('oracle1t_'):] for k in z.files if k.startswith('oracle1t_'))
     assert {'g0', 'g1', 'g2'} <= set(keys)
     worst_oracle_gap = 0.0
