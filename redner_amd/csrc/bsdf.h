@@ -361,7 +361,7 @@ RDR_FN void adj_bsdf_eval(const MaterialD &m, const Surf &sp, V3 wi, V3 wo, doub
             if (rough > min_rough) adj_tex1(m.roughness, sp, rough_bar, gm.roughness, sp_bar);
         }
     }
-    if (has_normal_map(m)) adj_perturbed_normal(m, sp, n_bar, gm, sp_bar);
+    if (!sp.plain && has_normal_map(m)) adj_perturbed_normal(m, sp, n_bar, gm, sp_bar);      // (as shade_ctx decides)
     else sp_bar.frame.n += n_bar;
 }
 

@@ -409,8 +409,8 @@ struct Backward {
         adj.n = P; adj.plain = 0;
         adj.thr = arena.get<double>((size_t)3 * P);
         adj.ray_dir = arena.get<double>((size_t)3 * P);
-        // (the lean stages keep no uv / uv-derivative / colour adjoints: 15 of the 24 components, stages_bwd.h: AdjState::plain)
-        adj_point_doubles = lean == kLean ? 15 : kAdjPointDoubles;
+        // (the lean stages keep position and shading normal: 6 of the 24 components, stages_bwd.h: AdjState)
+        adj_point_doubles = lean == kLean ? kAdjPointDoublesLean : kAdjPointDoubles;
         adj.point = arena.get<double>((size_t)adj_point_doubles * P);
         nee_act = arena.get<int>((size_t)P);
         const bool edges_on = scene.edges && scene.edges->d.num_edges > 0 &&
@@ -829,6 +829,9 @@ struct Backward {
                 exec::launch(nA, SecondaryEdgeDerivatives{sd, grads.g, act, sec_recs, hit_view(seg_of(d), d), edge_contrib, adj});
             }
         }
+        auto launch_adj_primary = [&] {
+            launch_v(lean, P, AdjPrimary{sd, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight, adj, screen_grad, ch});
+        };
         // the camera-vertex adjoint runs beside the primary-edge pass unless both would add to the screen-gradient image
         const bool adj_primary_aside = overlap && screen_grad == nullptr && edges_on && scene.use_primary_edges;
         if (adj_primary_aside) {
@@ -836,12 +839,10 @@ struct Backward {
             depth_begin.after(main_stream);
             exec::StreamScope on(exec::side_stream(side_index(0, P)));
             depth_begin.gate(exec::ctx().stream);
-            launch_v(lean, P, AdjPrimary{sd, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
-                                       adj, screen_grad, ch});
+            launch_adj_primary();
             adjoint_done.after(exec::ctx().stream);
         } else {
-            launch_v(lean, P, AdjPrimary{sd, grads.g, rng, opt.sample_pixel_center, vs[0], d_image, nd, radiance_dim, weight,
-                                       adj, screen_grad, ch});
+            launch_adj_primary();
         }
         if (edges_on && scene.use_primary_edges) {
             // ---- primary (camera-visible silhouette) edges, :766-942 ----

@@ -19,32 +19,39 @@
 namespace rdr {
 
 constexpr int kAdjPointDoubles = 24;   // position 3, frame 9, dpdu 3, uv 2, du_dxy 2, dv_dxy 2, color 3
+constexpr int kAdjPointDoublesLean = 6;
 
+// The lean stages (plain scenes: constant reflectances, no normal map, radiance only) keep SIX components of the shading-point
+// adjoint: position and shading normal.  Nothing writes the others there: the BSDF adjoint of an untextured material without a
+// normal map adds to frame.n only (bsdf.h: adj_bsdf_eval), the edge estimators and the replay add to the position
+// (stages_edge.h), the first-hit channels do not exist -- the tangent, bitangent, dp/du, uv and colour adjoints a record would
+// carry are zeros from the first vertex to the camera, and adding a zero changes no sum.  (Round 6: 15 -> 6 doubles read and
+// written per lane and stage, and the surface adjoint of the lean form loses the terms those zeros fed.)
 struct AdjState {      // SoA, stride n, indexed by lane id
     double *thr;       // 3 x n
     double *ray_dir;   // 3 x n   (adjoint of the incoming ray's direction; the origin's is always 0)
-    double *point;     // 24 x n  (non-zero part of the shading point adjoint)
+    double *point;     // 24 x n  (non-zero part of the shading point adjoint); lean: 6 x n = position, frame.n
     int n;
-    int plain;         // lean stages: uv / uv-derivative / colour adjoints are identically zero and not kept
+    int plain;         // lean stages (see above)
 };
 
 RDR_FN Surf load_adj_point(const AdjState &a, int p) {
     Surf s = surf_zero();
     s.position = ld3(a.point, a.n, p, 0);
+    if (a.plain) { s.frame.n = ld3(a.point, a.n, p, 3); return s; }       // the lean record: position, shading normal (see AdjState)
     s.frame.x = ld3(a.point, a.n, p, 3); s.frame.y = ld3(a.point, a.n, p, 6); s.frame.n = ld3(a.point, a.n, p, 9);
     s.dpdu = ld3(a.point, a.n, p, 12);
-    if (a.plain) return s;
     s.uv = v2(a.point[(size_t)15 * a.n + p], a.point[(size_t)16 * a.n + p]);
     s.du_dxy = v2(a.point[(size_t)17 * a.n + p], a.point[(size_t)18 * a.n + p]);
     s.dv_dxy = v2(a.point[(size_t)19 * a.n + p], a.point[(size_t)20 * a.n + p]);
     s.color = ld3(a.point, a.n, p, 21);
     return s;
 }
-RDR_FN void store_adj_point(const AdjState &a, int p, const Surf &s) {
-    st3(a.point, a.n, p, 0, s.position);
+RDR_FN void store_adj_point(const AdjState &a, int p, const Surf &s, bool with_position = true) {
+    if (with_position) st3(a.point, a.n, p, 0, s.position);
+    if (a.plain) { st3(a.point, a.n, p, 3, s.frame.n); return; }
     st3(a.point, a.n, p, 3, s.frame.x); st3(a.point, a.n, p, 6, s.frame.y); st3(a.point, a.n, p, 9, s.frame.n);
     st3(a.point, a.n, p, 12, s.dpdu);
-    if (a.plain) return;
     a.point[(size_t)15 * a.n + p] = s.uv.x; a.point[(size_t)16 * a.n + p] = s.uv.y;
     a.point[(size_t)17 * a.n + p] = s.du_dxy.x; a.point[(size_t)18 * a.n + p] = s.du_dxy.y;
     a.point[(size_t)19 * a.n + p] = s.dv_dxy.x; a.point[(size_t)20 * a.n + p] = s.dv_dxy.y;
@@ -171,7 +178,7 @@ struct AdjBounceScatter {
         V3 pos_bar = sp_bar.position;
         Surf next_pt_bar = surf_zero();
         if (through_hit) next_pt_bar = load_adj_point(adj, p);
-        store_adj_point(adj, p, sp_bar);                 // the position is stored again below
+        store_adj_point(adj, p, sp_bar, false);          // all but the position: the second half still changes it
         if (through_hit) {
             const ShapeD &bsh = sc.shapes[bshape];
             const int btri = vn.tri[p];
@@ -185,9 +192,9 @@ struct AdjBounceScatter {
             if (c.mrough > 0.01f) {
                 pos_bar -= dir_bar;
                 pos_bar += r_bar.org;
-                st3(adj.point, adj.n, p, 0, pos_bar);
             }
         }
+        st3(adj.point, adj.n, p, 0, pos_bar);
         scatter_trigrad_wave(sc.shapes, g.shapes, tg_shape, tg_tri, tg, sc.plain_materials != 0);   // every lane gets here
     }
 };
@@ -198,9 +205,12 @@ RDR_FN void adj_record_add(const AdjState &adj, int p, V3 thr_bar, V3 in_dir_bar
     st3(adj.ray_dir, adj.n, p, 0, ld3(adj.ray_dir, adj.n, p, 0) + in_dir_bar);
     Surf cur = load_adj_point(adj, p);
     cur.position += sp_bar.position;
-    cur.frame.x += sp_bar.frame.x; cur.frame.y += sp_bar.frame.y; cur.frame.n += sp_bar.frame.n;
-    cur.dpdu += sp_bar.dpdu; cur.uv += sp_bar.uv; cur.du_dxy += sp_bar.du_dxy; cur.dv_dxy += sp_bar.dv_dxy;
-    cur.color += sp_bar.color;
+    cur.frame.n += sp_bar.frame.n;
+    if (!adj.plain) {
+        cur.frame.x += sp_bar.frame.x; cur.frame.y += sp_bar.frame.y;
+        cur.dpdu += sp_bar.dpdu; cur.uv += sp_bar.uv; cur.du_dxy += sp_bar.du_dxy; cur.dv_dxy += sp_bar.dv_dxy;
+        cur.color += sp_bar.color;
+    }
     store_adj_point(adj, p, cur);
 }
 
