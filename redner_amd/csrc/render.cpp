@@ -774,6 +774,27 @@ struct Backward {
             lit.active = nee_act;
             launch_v(lean, nLit, AdjBounceNee{lit});
         };
+        // The continuation half of a bounce adjoint overwrites the lane's record with what flows back through the BSDF-sampled
+        // ray.  Two kinds of lanes have only zeros to write there, and their records ARE zero (cleared above, written by no deeper
+        // vertex: the lane had none):
+        //  * the continuation ray left the scene and there is no environment light: the stage runs over the NEXT depth's live-lane
+        //    list (the lanes of this one whose ray hit something -- it exists already);
+        //  * at the DEEPEST vertex nothing follows, the adjoints taken over are those zeros: all the stage can add comes from
+        //    emission seen through the BSDF (AdjBounceScatter's light branch, or the environment); it runs over the lanes whose
+        //    ray reached an emitter -- an area light is a few per cent of them.
+        // Same sums: what is skipped multiplied by zeros and added zeros.
+        auto adj_scatter = [&](const AdjBounceArgs &ba, exec::Count nA, int d) {
+            if (!nee_compact) { launch_v(lean, nA, AdjBounceScatter{ba}); return; }
+            AdjBounceArgs part = ba;
+            exec::Count n = nA;
+            if (sd.envmap == nullptr) { part.active = active + (size_t)(d + 1) * stride; n = num_active[d + 1]; }
+            if (d == B - 1) {
+                n = exec::compact_dev(part.active, n, nee_act, KeepLitContinuation{vs[d + 1].shape, sd.shapes, sd.envmap != nullptr},
+                                      nullptr, nullptr, 0, nullptr, 1);
+                part.active = nee_act;          // (read by this launch before adj_nee, on the same stream, compacts into it again)
+            }
+            launch_v(lean, n, AdjBounceScatter{part});
+        };
         for (int d = B - 1; d >= 0 && has_lights; --d) {
             const exec::Count nA = num_active[d];
             if (nA.upper <= 0) continue;
@@ -797,11 +818,11 @@ struct Backward {
                 depth_begin.after(main_stream);
                 exec::StreamScope on(exec::side_stream(side_index(0, P)));
                 depth_begin.gate(exec::ctx().stream);
-                launch_v(lean, nA, AdjBounceScatter{ba});
+                adj_scatter(ba, nA, d);
                 adj_nee(ba, nA, d);
                 adjoint_done.after(exec::ctx().stream);
             } else {
-                launch_v(lean, nA, AdjBounceScatter{ba});
+                adj_scatter(ba, nA, d);
                 adj_nee(ba, nA, d);
             }
             if (with_edges) {

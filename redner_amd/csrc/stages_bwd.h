@@ -479,6 +479,11 @@ struct KeepNeeLive {    // lanes whose next-event estimate has something to diff
     RDR_FN bool operator()(int p) const { return occl[p] == 0; }
 };
 
+struct KeepLitContinuation {    // lanes whose continuation ray reached an emitter (or, without a hit, the environment light)
+    const int *next_shape; const ShapeD *shapes; bool envmap;
+    RDR_FN bool operator()(int p) const { const int s = next_shape[p]; return s >= 0 ? shapes[s].light_id >= 0 : envmap; }
+};
+
 struct FlushSegment { size_t begin, count; float *out; };      // elements [begin, begin + count) of the block
 struct FlushGrad {
     const double *block; size_t stride; int replicas;
