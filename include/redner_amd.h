@@ -157,8 +157,9 @@ enum rdr_tune_flags {
     RDR_TUNE_TRACE_NO_LDS_TOP = 1 << 9,   /* hierarchy top not staged in LDS                                  RDR_TRACE_NO_LDS_TOP */
     RDR_TUNE_NO_FUSED_BOUNCE  = 1 << 10,  /* BounceContrib(d) and BounceSample(d+1) as two launches          RDR_NO_FUSED_BOUNCE */
     RDR_TUNE_PICKH_ONE_LAUNCH = 1 << 11,  /* hierarchical edge pick: one slot per lane, one launch (r1-r5)   RDR_PICKH_ONE_LAUNCH */
-    RDR_TUNE_NO_NEE_COMPACT   = 1 << 12,  /* bounce adjoints over the whole live-lane list (no compacted
-                                           * lists: next-event half, deepest continuation half)               RDR_NO_NEE_COMPACT */
+    RDR_TUNE_NO_NEE_COMPACT   = 1 << 12,  /* bounce adjoints without list compactions (next-event half over
+                                           * the whole live-lane list, continuation half over the next
+                                           * depth's list as it is)                                            RDR_NO_NEE_COMPACT */
     RDR_TUNE_LARGE_FORMS      = 1 << 13   /* the stage forms of large frames (split pick, compacted adjoint
                                            * lists) at every size; default: from 2^19 lanes per launch set     RDR_LARGE_FRAME_FORMS */
 };

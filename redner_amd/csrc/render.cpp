@@ -412,6 +412,7 @@ struct Backward {
         // (the lean stages keep position and shading normal: 6 of the 24 components, stages_bwd.h: AdjState)
         adj_point_doubles = lean == kLean ? kAdjPointDoublesLean : kAdjPointDoubles;
         adj.point = arena.get<double>((size_t)adj_point_doubles * P);
+        adj.carries = scene.d.envmap == nullptr ? arena.get<unsigned char>((size_t)P) : nullptr;      // (stages_bwd.h: AdjState)
         nee_act = arena.get<int>((size_t)P);
         const bool edges_on = scene.edges && scene.edges->d.num_edges > 0 &&
                               (scene.use_primary_edges || scene.use_secondary_edges);
@@ -628,6 +629,7 @@ struct Backward {
         exec::zero(adj.thr, sizeof(double) * 3 * stride);
         exec::zero(adj.ray_dir, sizeof(double) * 3 * stride);
         exec::zero(adj.point, sizeof(double) * adj_point_doubles * stride);
+        if (adj.carries) exec::zero(adj.carries, (size_t)stride);
         const int dim0 = opt.sample_pixel_center ? 0 : 2;
         const bool pickh_fused = tuning().has(RDR_TUNE_PICKH_FUSED);     // A/B: the one-loop form
         const bool pickh_lazy = tuning().has(RDR_TUNE_PICKH_LAZY);       // A/B: per-field node loads
@@ -775,23 +777,28 @@ struct Backward {
             launch_v(lean, nLit, AdjBounceNee{lit});
         };
         // The continuation half of a bounce adjoint overwrites the lane's record with what flows back through the BSDF-sampled
-        // ray.  Two kinds of lanes have only zeros to write there, and their records ARE zero (cleared above, written by no deeper
-        // vertex: the lane had none):
-        //  * the continuation ray left the scene and there is no environment light: the stage runs over the NEXT depth's live-lane
-        //    list (the lanes of this one whose ray hit something -- it exists already);
-        //  * at the DEEPEST vertex nothing follows, the adjoints taken over are those zeros: all the stage can add comes from
-        //    emission seen through the BSDF (AdjBounceScatter's light branch, or the environment); it runs over the lanes whose
-        //    ray reached an emitter -- an area light is a few per cent of them.
-        // Same sums: what is skipped multiplied by zeros and added zeros.
+        // ray.  Two kinds of lanes have only zeros to write there, onto records that ARE zero:
+        //  * the continuation ray left the scene and there is no environment light (the record was cleared above and no deeper
+        //    vertex wrote it: the lane had none): the stage takes its lanes from the NEXT depth's live-lane list;
+        //  * the successor's record is all zeros (AdjState::carries: nothing has been written there since the clear -- every lane
+        //    of the deepest vertex, a third of the next one up, a tenth further up) and the ray did not reach an emitter: all the
+        //    stage adds is a product with those zeros.  One compaction per depth takes them out.
+        // (With an environment light a ray that leaves the scene carries radiance: the full list, and at the deepest vertex the
+        // lanes that reached an emitter or the environment.)  Same sums: what is skipped multiplied by zeros and added zeros.
         auto adj_scatter = [&](const AdjBounceArgs &ba, exec::Count nA, int d) {
-            if (!nee_compact) { launch_v(lean, nA, AdjBounceScatter{ba}); return; }
             AdjBounceArgs part = ba;
             exec::Count n = nA;
-            if (sd.envmap == nullptr) { part.active = active + (size_t)(d + 1) * stride; n = num_active[d + 1]; }
-            if (d == B - 1) {
-                n = exec::compact_dev(part.active, n, nee_act, KeepLitContinuation{vs[d + 1].shape, sd.shapes, sd.envmap != nullptr},
-                                      nullptr, nullptr, 0, nullptr, 1);
+            if (!nee_compact) {
+                // small frames / RDR_TUNE_NO_NEE_COMPACT (no extra launches): the next depth's list as it is
+                if (sd.envmap == nullptr) { part.active = active + (size_t)(d + 1) * stride; n = num_active[d + 1]; }
+            } else if (adj.carries) {
+                n = exec::compact_dev(active + (size_t)(d + 1) * stride, num_active[d + 1], nee_act,
+                                      KeepCarryingContinuation{adj.carries, vs[d + 1].shape, sd.shapes}, nullptr, nullptr, 0, nullptr, 1);
                 part.active = nee_act;          // (read by this launch before adj_nee, on the same stream, compacts into it again)
+            } else if (d == B - 1) {
+                n = exec::compact_dev(ba.active, nA, nee_act, KeepLitContinuation{vs[d + 1].shape, sd.shapes, sd.envmap != nullptr},
+                                      nullptr, nullptr, 0, nullptr, 1);
+                part.active = nee_act;
             }
             launch_v(lean, n, AdjBounceScatter{part});
         };

@@ -33,6 +33,10 @@ struct AdjState {      // SoA, stride n, indexed by lane id
     double *point;     // 24 x n  (non-zero part of the shading point adjoint); lean: 6 x n = position, frame.n
     int n;
     int plain;         // lean stages (see above)
+    // per lane, or null (not tracked): 0 = the lane's record is all zeros -- cleared, and none of the stages that write records
+    // (AdjBounceScatter, adj_record_add, SecondaryEdgeDerivatives) has come by since.  The continuation half of the next vertex up
+    // the path skips such a lane unless its ray reached an emitter (render.cpp: adj_scatter).
+    unsigned char *carries;
 };
 
 RDR_FN Surf load_adj_point(const AdjState &a, int p) {
@@ -195,6 +199,7 @@ struct AdjBounceScatter {
             }
         }
         st3(adj.point, adj.n, p, 0, pos_bar);
+        if (adj.carries) adj.carries[p] = 1;
         scatter_trigrad_wave(sc.shapes, g.shapes, tg_shape, tg_tri, tg, sc.plain_materials != 0);   // every lane gets here
     }
 };
@@ -212,6 +217,7 @@ RDR_FN void adj_record_add(const AdjState &adj, int p, V3 thr_bar, V3 in_dir_bar
         cur.color += sp_bar.color;
     }
     store_adj_point(adj, p, cur);
+    if (adj.carries) adj.carries[p] = 1;
 }
 
 struct AdjBounceNee {
@@ -482,6 +488,10 @@ struct KeepNeeLive {    // lanes whose next-event estimate has something to diff
 struct KeepLitContinuation {    // lanes whose continuation ray reached an emitter (or, without a hit, the environment light)
     const int *next_shape; const ShapeD *shapes; bool envmap;
     RDR_FN bool operator()(int p) const { const int s = next_shape[p]; return s >= 0 ? shapes[s].light_id >= 0 : envmap; }
+};
+struct KeepCarryingContinuation {    // lanes (with a continuation hit) whose successor left a non-zero record, or whose ray reached an emitter
+    const unsigned char *carries; const int *next_shape; const ShapeD *shapes;
+    RDR_FN bool operator()(int p) const { return carries[p] != 0 || shapes[next_shape[p]].light_id >= 0; }
 };
 
 struct FlushSegment { size_t begin, count; float *out; };      // elements [begin, begin + count) of the block

@@ -249,6 +249,7 @@ struct PrimaryEdgeDerivatives {
         const PrimaryEdgeRec &rec = recs[slot];
         if (rec.edge.shape_id < 0) return;
         double contrib = edge_contrib[2 * slot] + edge_contrib[2 * slot + 1];
+        if (contrib == 0) return;                  // every term below is a product with it
         V3 a = edge_v0(sc.shapes, rec.edge), b = edge_v1(sc.shapes, rec.edge);
         V2 a_ss, b_ss;
         if (!project_segment(sc.cam, a, b, a_ss, b_ss)) return;
@@ -1528,6 +1529,7 @@ struct SecondaryEdgeDerivatives {
     RDR_FN void operator()(int idx) const {
         const SecondaryEdgeRec &rec = recs[idx];
         if (rec.edge.shape_id < 0) return;
+        if (edge_contrib[2 * idx] == 0 && edge_contrib[2 * idx + 1] == 0) return;      // nothing but zeros to add
         int p = active[idx];
         V3 a = edge_v0(sc.shapes, rec.edge), b = edge_v1(sc.shapes, rec.edge);
         V3 dp = v3(0), da = v3(0), db = v3(0);
@@ -1552,6 +1554,7 @@ struct SecondaryEdgeDerivatives {
         adj.point[(size_t)0 * adj.n + p] += dp.x;
         adj.point[(size_t)1 * adj.n + p] += dp.y;
         adj.point[(size_t)2 * adj.n + p] += dp.z;
+        if (adj.carries) adj.carries[p] = 1;
         double *gv = g.shapes[rec.edge.shape_id].vertices;
         accum3(gv + 3 * rec.edge.v0, da);
         accum3(gv + 3 * rec.edge.v1, db);

@@ -5,6 +5,9 @@
 // without a GPU.  It is compiled only into tests/hostsim/_build/, is never imported by
 // redner_amd, and the product raises if the HIP library or a GPU is missing.
 #pragma once
+#include <typeinfo>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <stdint.h>
 #include <stdio.h>
@@ -108,12 +111,18 @@ struct Count {                 // see hip/exec.h: `dev` is host memory here
 inline int *new_count() { static int ring[8192]; static int at = 0; at = (at + 1) % 8192; return ring + at; }
 inline int read_count(Count c) { return c.value(); }
 inline Count scaled_count(Count c, int k) { if (!c.dev) return Count(k * c.upper); int *d = new_count(); *d = k * c.value(); return Count(d, k * c.upper); }
+// RDR_HOSTSIM_LANES=1: one line per stage launch (stage type, lanes) on stderr -- where the lanes of a frame go
+inline void note_launch(const char *stage, int n) {
+    static const bool on = std::getenv("RDR_HOSTSIM_LANES") != nullptr;
+    if (on) std::fprintf(stderr, "[lanes] %d %s\n", n, stage);
+}
 template <class F>
-inline void launch(Count c, const F &f) { const int n = c.value(); for (int i = 0; i < n; ++i) f(i); }
+inline void launch(Count c, const F &f) { const int n = c.value(); note_launch(typeid(F).name(), n); for (int i = 0; i < n; ++i) f(i); }
 inline int *persistent_counter() { static int ring[64]; static int at = 0; at = (at + 1) % 64; ring[at] = 0; return ring + at; }
 template <class W>
 inline void launch_persistent(Count c, const W &w) {          // see hip/exec.h: begin / step... / finish per item
     const int n = c.value();
+    note_launch(typeid(W).name(), n);
     for (int i = 0; i < n; ++i) {
         typename W::State st;
         if (w.begin(i, st)) { while (!w.step(st)) {} }
