@@ -124,3 +124,18 @@ def test_unknown_tuning_field_is_an_error(hostsim_backend):
                                           backend=hostsim_backend, tuning={'batch_sample': 1})
     with pytest.raises(ValueError, match='batch_sample'):
         RenderFunction.apply(1, *args)
+
+
+@pytest.mark.parametrize('case', [CASE, GLOSSY, 'bunny_box_96x96x8', 'envmap_sphere_48x48x4'])
+def test_adjoint_lists_skip_only_zero_terms_hostsim(hostsim_backend, case):
+    """The continuation half of the bounce adjoint runs over the lanes that have something to take over (render.cpp: adj_scatter:
+    the next depth's list minus the lanes whose successor record is known to be all zeros, AdjState::carries), the next-event half
+    over the lanes whose estimate is not zero for geometric reasons, the edge-derivative stages return on a zero contribution.  What
+    is skipped only multiplied by zeros and added zeros -- so on the sequential harness with one sample worker every gradient tensor
+    must come out BIT FOR BIT the same with the list forms on (the session's default) and off."""
+    b, res, spp, mb = CASES[case][:4]
+    on = render_case(hostsim_backend, b, res, spp, mb, None, {'tuning': {'workers': 1}}, device=torch.device('cpu'))
+    off = render_case(hostsim_backend, b, res, spp, mb, None, {'tuning': {'workers': 1, 'flags': K.TUNE_NO_NEE_COMPACT}}, device=torch.device('cpu'))
+    assert set(on) == set(off)
+    for k in on:
+        assert np.array_equal(np.asarray(on[k]), np.asarray(off[k])), (case, k, float(np.abs(np.asarray(on[k], np.float64) - np.asarray(off[k], np.float64)).max()))
