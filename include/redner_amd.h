@@ -160,8 +160,11 @@ enum rdr_tune_flags {
     RDR_TUNE_NO_NEE_COMPACT   = 1 << 12,  /* bounce adjoints without list compactions (next-event half over
                                            * the whole live-lane list, continuation half over the next
                                            * depth's list as it is)                                            RDR_NO_NEE_COMPACT */
-    RDR_TUNE_LARGE_FORMS      = 1 << 13   /* the stage forms of large frames (split pick, compacted adjoint
+    RDR_TUNE_LARGE_FORMS      = 1 << 13,  /* the stage forms of large frames (split pick, compacted adjoint
                                            * lists) at every size; default: from 2^19 lanes per launch set     RDR_LARGE_FRAME_FORMS */
+    RDR_TUNE_TRACE_EVERY_CONTINUATION = 1 << 14   /* the last bounce's continuation rays are all traced (default in a
+                                           * plain scene with <= 8 emitter triangles: those that meet no
+                                           * emitter triangle are answered "no hit" untraced)                  RDR_TRACE_EVERY_CONTINUATION */
 };
 struct rdr_tuning {
     unsigned flags;                 /* rdr_tune_flags */

@@ -98,7 +98,7 @@ class Tuning(C.Structure):
 # rdr_tune_flags / rdr_build_flags
 TUNE_NO_OVERLAP, TUNE_FORCE_GENERAL, TUNE_PICKN_WALK, TUNE_PICKH_FUSED, TUNE_PICKH_LAZY, TUNE_NO_HOIST, TUNE_REFILL_OFF, \
     TUNE_REFILL_ALL, TUNE_TRACE_BINARY, TUNE_TRACE_NO_LDS_TOP, TUNE_NO_FUSED_BOUNCE, TUNE_PICKH_ONE_LAUNCH, TUNE_NO_NEE_COMPACT, \
-    TUNE_LARGE_FORMS = [1 << k for k in range(14)]
+    TUNE_LARGE_FORMS, TUNE_TRACE_EVERY_CONTINUATION = [1 << k for k in range(15)]
 BUILD_NO_REFIT, BUILD_NO_EDGE_CACHE, BUILD_SYNC_EDGES, BUILD_EDGE_HOST_BUILD = [1 << k for k in range(4)]
 
 

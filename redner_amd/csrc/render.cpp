@@ -158,18 +158,26 @@ inline int side_index(int k, int lanes) { return lanes >= (1 << 19) ? k + 2 : k;
 inline bool fuse_bounces(bool pcg, int kind, int chain_lanes) {
     return !pcg && kind == kLean && chain_lanes <= (1 << 19) && !tuning().has(RDR_TUNE_NO_FUSED_BOUNCE);
 }
+constexpr int kEmitterTestMax = 8;          // most emitter triangles tested per last-bounce ray in BounceSample (beyond: every ray is traced)
 // `chain` / `vnn` (fused form): the chain's state, and the slice that receives the rays of the NEXT bounce (null: this is the
 // chain's last bounce)
 exec::Count run_bounce(const Scene &scene, const SceneD &sd, const SamplerD &rng, int dim, int rng_shift,
                        const int *active, exec::Count num_active, const VSlice &v, const VSlice &vn,
                        const Queues &q, const Sink &sink, int *next_active, int *dyn = nullptr, int dyn_inc = 0,
-                       bool shadow_rays_coherent = false, BounceChain *chain = nullptr, const VSlice *vnn = nullptr) {
+                       bool shadow_rays_coherent = false, BounceChain *chain = nullptr, const VSlice *vnn = nullptr, bool last_bounce = false) {
     const int lean = scene_kind(scene, sink.ch);
     const bool fused = chain && chain->fused;
     const bool drawn = fused && chain->have_rays;                      // this bounce's rays exist already
     const exec::Count queue_n = drawn ? chain->queue_n : num_active;
     const int *qpos = drawn ? chain->qpos : nullptr;
-    if (!drawn) launch_v(lean, num_active, BounceSample{sd, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf});
+    if (!drawn) {
+        BounceSample bs{sd, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf};
+        // the last bounce of a plain scene lit by a few triangles: continuation rays that meet no emitter triangle are not traced
+        // (stages_fwd.h: BounceSample::last_bounce_emitters)
+        bs.last_bounce_emitters = last_bounce && lean == kLean && scene.emitter_triangles > 0 && scene.emitter_triangles <= kEmitterTestMax &&
+                                  !tuning().has(RDR_TUNE_TRACE_EVERY_CONTINUATION);
+        launch_v(lean, num_active, bs);
+    }
     // the shadow-ray and the continuation-ray queue are traced side by side: both kernels wait on dependent loads
     // with a fraction of their lanes active (profiles/r1_notes.md), so they fill each other's gaps
     const bool side = overlap_on();
@@ -595,7 +603,7 @@ struct Backward {
             const VSlice &nx = (k % 2 == 0) ? eb : ea;
             int nxt = (cur == 1) ? 2 : 1;
             exec::Count next = run_bounce(scene, sd, edge_rng_at(rng_edge, edim, dyn, seg), edim, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt],
-                                          batch.on ? nullptr : dyn, 7, false, &chain, depth + 1 < B ? &m : nullptr);
+                                          batch.on ? nullptr : dyn, 7, false, &chain, depth + 1 < B ? &m : nullptr, depth == B - 1);
             // a batch: the counter of every sample that had lanes in this bounce (the list is ascending in the lane id)
             if (batch.on) exec::launch(cur_S, BumpDynList{dyn, elist[cur], n_act.dev, n_act.upper, seg, 2 * batch.P0, 7});
             edge_rng_consumed(n_slots, 7, n_act.dev);
@@ -1227,7 +1235,7 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
                 num_active[d + 1] = run_bounce(scene, sd, rng, dim, 0, active + (size_t)d * PL, num_active[d],
                                                vs[d], vs[d + 1], q, sink_of(d + 1), active + (size_t)(d + 1) * PL, w.main_dyn, 7,
                                                d == 0,         // shadow rays of the camera vertices: neighbouring origins
-                                               &chain, d + 1 < B ? &vs[d + 2] : nullptr);
+                                               &chain, d + 1 < B ? &vs[d + 2] : nullptr, d == B - 1);
                 if (num_active[d + 1].dev && d_image) segments(d + 1);
                 dim += 7;
             }

@@ -312,6 +312,7 @@ Scene *create_scene(const rdr_camera_desc *cam, const rdr_shape_desc *shapes, in
         int total_tris = 0;
         for (int l = 0; l < num_area_lights; ++l) { s.area_cdf_offset[l] = total_tris; total_tris += s.shapes[s.lights[l].shape_id].num_triangles; }
         s.area_cdf_pool.assign(total_tris, 0);
+        s.emitter_triangles = total_tris;
         double total_importance = 0;
         for (int l = 0; l < num_area_lights; ++l) {
             int sid = s.lights[l].shape_id;

@@ -49,6 +49,7 @@ struct Scene {
     bool has_textures = false;     // some reflectance / roughness is an image, or a normal map is present
     bool has_vertex_colors = false;
     bool has_mipmaps = false;
+    int emitter_triangles = 0;     // triangles of all area-light shapes together (render.cpp: last-bounce emitter test)
     bool diffuse_only = false;     // every material: constant specular reflectance (0, 0, 0) -- see render.cpp: run_sample
     EnvmapD h_envmap;              // valid when d.envmap != nullptr      // some texture has > 1 level, i.e. ray differentials influence results
 

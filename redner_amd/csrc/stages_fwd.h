@@ -84,13 +84,14 @@ RDR_FN RayDiff ld_rdiff(const double *b, int n, int i) {
 }
 RDR_FN void store_rdiff(const VSlice &v, int i, const RayDiff &r) { if (v.rdiff) st_rdiff(v.rdiff, v.n, i, r); }
 
-RDR_FN void put_ray(rt::RayRec *q, int slot, const Ray &r, bool dead) {
+RDR_FN rt::RayRec ray_rec(const Ray &r, bool dead) {
     rt::RayRec rec;
     rec.ox = (float)r.org.x; rec.oy = (float)r.org.y; rec.oz = (float)r.org.z; rec.tmin = (float)r.tmin;
     rec.dx = (float)r.dir.x; rec.dy = (float)r.dir.y; rec.dz = (float)r.dir.z;
     rec.tmax = dead ? -1.f : (float)r.tmax;
-    q[slot] = rec;
+    return rec;
 }
+RDR_FN void put_ray(rt::RayRec *q, int slot, const Ray &r, bool dead) { q[slot] = ray_rec(r, dead); }
 
 // Where a stage deposits radiance: the image (camera paths) and/or a per-lane scalar (edge paths).
 constexpr int kMaxChannels = 16;
@@ -340,6 +341,29 @@ RDR_FN VertexCtx load_vertex(const SceneD &sc, const VSlice &v, int p) {
     return c;
 }
 
+// Does the ray, by the traversal kernels' own triangle rule (raytri.h; same fp32 ray record, same fp32 corners), meet ANY triangle
+// of an area light within (tmin, tmax)?  A superset of "its closest hit lies on an emitter": the closest-hit query reports an
+// emitter triangle only if this test passes for that triangle.  For scenes with a handful of emitter triangles (render.cpp decides).
+RDR_FN bool ray_meets_emitter_triangle(const SceneD &sc, const rt::RayRec &r) {
+    const float o[3] = {r.ox, r.oy, r.oz}, d[3] = {r.dx, r.dy, r.dz};
+    for (int l = 0; l < sc.num_area_lights; ++l) {
+        const ShapeD &sh = sc.shapes[sc.lights[l].shape_id];
+        for (int t = 0; t < sh.num_triangles; ++t) {
+            float a[3], b[3], c[3];
+            if (sh.geom) {
+                const TriGeomD g = load_dev(sh.geom + t);
+                for (int k = 0; k < 3; ++k) { a[k] = g.p[k]; b[k] = g.p[3 + k]; c[k] = g.p[6 + k]; }
+            } else {
+                const int i0 = sh.indices[3 * t], i1 = sh.indices[3 * t + 1], i2 = sh.indices[3 * t + 2];
+                for (int k = 0; k < 3; ++k) { a[k] = sh.vertices[3 * i0 + k]; b[k] = sh.vertices[3 * i1 + k]; c[k] = sh.vertices[3 * i2 + k]; }
+            }
+            float tt;
+            if (rt::ray_triangle(o, d, r.tmin, r.tmax, a, b, c, &tt)) return true;
+        }
+    }
+    return false;
+}
+
 // ---- stage: draw the NEE point and the BSDF direction, emit both rays ---------------------------
 struct BounceSample {
     static constexpr int kMidBlocksPerCU = 3;
@@ -349,6 +373,11 @@ struct BounceSample {
     RDR_FN void make_mid() { mid_scene(sc); }
     const int *active; VSlice v, vn;
     rt::RayRec *q_nee, *q_bsdf;
+    // The path's LAST bounce (set by the host, plain scenes with a handful of emitter triangles): the vertex the continuation ray
+    // reaches is never shaded -- it matters only as an emitter seen through the BSDF (eval_bounce's light branch and its adjoint).
+    // A ray that meets no emitter triangle at all is queued dead: the query answers "no hit" without a traversal, which is what
+    // every consumer makes of a hit on a non-emitter there.  The others are traced as ever (an occluder may still come first).
+    int last_bounce_emitters = 0;
     RDR_FN void operator()(int idx) const {
         int p = active[idx];
         VertexCtx c = load_vertex(sc, v, p);
@@ -404,7 +433,9 @@ struct BounceSample {
         if (vn.erd) st_erd(vn, p, wo_rd);
         vn.mrough[p] = next_mr;
         Ray nr = make_ray(c.sp.position, dir);
-        put_ray(q_bsdf, idx, nr, len_sq(dir) <= 1e-3f);
+        bool dead = len_sq(dir) <= 1e-3f;
+        if (last_bounce_emitters && !dead) dead = !ray_meets_emitter_triangle(sc, ray_rec(nr, false));
+        put_ray(q_bsdf, idx, nr, dead);
     }
 };
 

@@ -52,6 +52,7 @@ struct EnvDefaults {
         if (env_set("RDR_PICKH_ONE_LAUNCH")) flags |= RDR_TUNE_PICKH_ONE_LAUNCH;
         if (env_set("RDR_NO_NEE_COMPACT")) flags |= RDR_TUNE_NO_NEE_COMPACT;
         if (env_set("RDR_LARGE_FRAME_FORMS")) flags |= RDR_TUNE_LARGE_FORMS;
+        if (env_set("RDR_TRACE_EVERY_CONTINUATION")) flags |= RDR_TUNE_TRACE_EVERY_CONTINUATION;
         if (const char *e = env("RDR_TRACE_REFILL")) {
             int k = 0, idle = 0, steps = 0;
             const int got = std::sscanf(e, "%d,%d,%d", &k, &idle, &steps);

@@ -33,6 +33,7 @@ SCHEDULES = {
     'gather_no_lists': {'gather_budget': 1, 'gather_heavy_cap_plus1': 1, 'gather_work_cap_plus1': 1},
     'little_memory': {'mem_available_mb': 8},
     'unfused_bounce': {'flags': K.TUNE_NO_FUSED_BOUNCE},
+    'trace_every_continuation': {'flags': K.TUNE_TRACE_EVERY_CONTINUATION},
 }
 GPU_ONLY = {
     'refill_everywhere': {'flags': K.TUNE_REFILL_ALL},
@@ -139,3 +140,15 @@ def test_adjoint_lists_skip_only_zero_terms_hostsim(hostsim_backend, case):
     assert set(on) == set(off)
     for k in on:
         assert np.array_equal(np.asarray(on[k]), np.asarray(off[k])), (case, k, float(np.abs(np.asarray(on[k], np.float64) - np.asarray(off[k], np.float64)).max()))
+
+
+@pytest.mark.parametrize('case', [CASE, GLOSSY, 'bunny_box_96x96x8'])
+def test_last_bounce_emitter_test_changes_nothing_hostsim(hostsim_backend, case):
+    """The last bounce's continuation rays that meet no emitter triangle are answered "no hit" without a traversal (stages_fwd.h:
+    BounceSample::last_bounce_emitters): the vertex they would reach is never shaded, it matters only as an emitter.  Image and
+    every gradient tensor bit for bit as with every ray traced (sequential harness, one sample worker)."""
+    b, res, spp, mb = CASES[case][:4]
+    on = render_case(hostsim_backend, b, res, spp, mb, None, {'tuning': {'workers': 1}}, device=torch.device('cpu'))
+    off = render_case(hostsim_backend, b, res, spp, mb, None, {'tuning': {'workers': 1, 'flags': K.TUNE_TRACE_EVERY_CONTINUATION}}, device=torch.device('cpu'))
+    for k in on:
+        assert np.array_equal(np.asarray(on[k]), np.asarray(off[k])), (case, k)
