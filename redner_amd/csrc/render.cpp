@@ -1177,7 +1177,8 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
     };
     auto make_worker = [&](Worker &w) {
         w.vs.resize(B + 1);
-        for (int d = 0; d <= B; ++d) w.vs[d] = make_slice(w.arena, PL, d < B, lean != kLean);
+        // (the occlusion byte is what the next-event adjoint compacts by: a forward render keeps none and BounceContrib skips the test)
+        for (int d = 0; d <= B; ++d) w.vs[d] = make_slice(w.arena, PL, d < B && d_image_lanes != nullptr, lean != kLean);
         w.active = w.arena.get<int>((size_t)(B + 1) * PL);
         w.q.nee = w.arena.get<rt::RayRec>((size_t)2 * PL); w.q.bsdf = w.arena.get<rt::RayRec>((size_t)2 * PL);
         w.q.h_nee = w.arena.get<rt::HitRec>((size_t)2 * PL); w.q.h_bsdf = w.arena.get<rt::HitRec>((size_t)2 * PL);

@@ -588,7 +588,10 @@ struct BounceContrib {
             next.wi = -next.ray.dir;
             next.mrough = vn.mrough[p];
         }
-        BounceEval e = eval_bounce(sc, c, thr, !blocked, pk, lp, ld.uv, hb.shape, bp, load_ray(vn, p).dir);
+        // (the camera paths of a gradient render feed no image and no edge estimate: their next-event term is consumed by nobody
+        //  -- the adjoint stages re-evaluate it -- and is not evaluated; throughput and occlusion byte are what they leave behind)
+        const bool consumed = sink.image != nullptr || sink.edge_contrib != nullptr;
+        BounceEval e = eval_bounce(sc, c, thr, !blocked && consumed, pk, lp, ld.uv, hb.shape, bp, load_ray(vn, p).dir);
         if (e.next_thr_valid) st3(vn.thr, vn.n, p, 0, e.next_thr);
         V3 pc = thr * (e.nee + e.scatter);
         if (sink.image) {
