@@ -164,18 +164,20 @@ constexpr int kEmitterTestMax = 8;          // most emitter triangles tested per
 exec::Count run_bounce(const Scene &scene, const SceneD &sd, const SamplerD &rng, int dim, int rng_shift,
                        const int *active, exec::Count num_active, const VSlice &v, const VSlice &vn,
                        const Queues &q, const Sink &sink, int *next_active, int *dyn = nullptr, int dyn_inc = 0,
-                       bool shadow_rays_coherent = false, BounceChain *chain = nullptr, const VSlice *vnn = nullptr, bool last_bounce = false) {
+                       bool shadow_rays_coherent = false, BounceChain *chain = nullptr, const VSlice *vnn = nullptr, bool last_bounce = false,
+                       bool next_is_last = false) {
     const int lean = scene_kind(scene, sink.ch);
     const bool fused = chain && chain->fused;
     const bool drawn = fused && chain->have_rays;                      // this bounce's rays exist already
     const exec::Count queue_n = drawn ? chain->queue_n : num_active;
     const int *qpos = drawn ? chain->qpos : nullptr;
+    // the last bounce of a plain scene lit by a few triangles: continuation rays that meet no emitter triangle are not traced
+    // (stages_fwd.h: BounceSample::last_bounce_emitters)
+    const bool emitter_test = lean == kLean && scene.emitter_triangles > 0 && scene.emitter_triangles <= kEmitterTestMax &&
+                              !tuning().has(RDR_TUNE_TRACE_EVERY_CONTINUATION);
     if (!drawn) {
         BounceSample bs{sd, rng, dim, rng_shift, active, v, vn, q.nee, q.bsdf};
-        // the last bounce of a plain scene lit by a few triangles: continuation rays that meet no emitter triangle are not traced
-        // (stages_fwd.h: BounceSample::last_bounce_emitters)
-        bs.last_bounce_emitters = last_bounce && lean == kLean && scene.emitter_triangles > 0 && scene.emitter_triangles <= kEmitterTestMax &&
-                                  !tuning().has(RDR_TUNE_TRACE_EVERY_CONTINUATION);
+        bs.last_bounce_emitters = last_bounce && emitter_test;
         launch_v(lean, num_active, bs);
     }
     // the shadow-ray and the continuation-ray queue are traced side by side: both kernels wait on dependent loads
@@ -207,7 +209,9 @@ exec::Count run_bounce(const Scene &scene, const SceneD &sd, const SamplerD &rng
     }
     if (vnn) {
         // ... and the rays of the next bounce: the next list's lanes are drawn HERE, at this list's positions
-        launch_v(lean, num_active, BounceContribSample{contrib, BounceSample{sd, rng, dim + 7, rng_shift, active, vn, *vnn, q.nee, q.bsdf}, qpos});
+        BounceSample next{sd, rng, dim + 7, rng_shift, active, vn, *vnn, q.nee, q.bsdf};
+        next.last_bounce_emitters = next_is_last && emitter_test;
+        launch_v(lean, num_active, BounceContribSample{contrib, next, qpos});
     } else if (qpos) {
         launch_v(lean, num_active, BounceContribSample{contrib, BounceSample{sd, rng, dim + 7, rng_shift, active, vn, vn, nullptr, nullptr}, qpos, 1});
     } else {
@@ -603,7 +607,7 @@ struct Backward {
             const VSlice &nx = (k % 2 == 0) ? eb : ea;
             int nxt = (cur == 1) ? 2 : 1;
             exec::Count next = run_bounce(scene, sd, edge_rng_at(rng_edge, edim, dyn, seg), edim, 1, elist[cur], n_act, m, nx, q, sink, elist[nxt],
-                                          batch.on ? nullptr : dyn, 7, false, &chain, depth + 1 < B ? &m : nullptr, depth == B - 1);
+                                          batch.on ? nullptr : dyn, 7, false, &chain, depth + 1 < B ? &m : nullptr, depth == B - 1, depth + 2 == B);
             // a batch: the counter of every sample that had lanes in this bounce (the list is ascending in the lane id)
             if (batch.on) exec::launch(cur_S, BumpDynList{dyn, elist[cur], n_act.dev, n_act.upper, seg, 2 * batch.P0, 7});
             edge_rng_consumed(n_slots, 7, n_act.dev);
@@ -1236,7 +1240,7 @@ void render_once(const Scene &scene, const rdr_render_options &opt, float *image
                 num_active[d + 1] = run_bounce(scene, sd, rng, dim, 0, active + (size_t)d * PL, num_active[d],
                                                vs[d], vs[d + 1], q, sink_of(d + 1), active + (size_t)(d + 1) * PL, w.main_dyn, 7,
                                                d == 0,         // shadow rays of the camera vertices: neighbouring origins
-                                               &chain, d + 1 < B ? &vs[d + 2] : nullptr, d == B - 1);
+                                               &chain, d + 1 < B ? &vs[d + 2] : nullptr, d == B - 1, d + 2 == B);
                 if (num_active[d + 1].dev && d_image) segments(d + 1);
                 dim += 7;
             }

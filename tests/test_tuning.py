@@ -148,7 +148,9 @@ def test_last_bounce_emitter_test_changes_nothing_hostsim(hostsim_backend, case)
     BounceSample::last_bounce_emitters): the vertex they would reach is never shaded, it matters only as an emitter.  Image and
     every gradient tensor bit for bit as with every ray traced (sequential harness, one sample worker)."""
     b, res, spp, mb = CASES[case][:4]
-    on = render_case(hostsim_backend, b, res, spp, mb, None, {'tuning': {'workers': 1}}, device=torch.device('cpu'))
-    off = render_case(hostsim_backend, b, res, spp, mb, None, {'tuning': {'workers': 1, 'flags': K.TUNE_TRACE_EVERY_CONTINUATION}}, device=torch.device('cpu'))
-    for k in on:
-        assert np.array_equal(np.asarray(on[k]), np.asarray(off[k])), (case, k)
+    for form in (0, K.TUNE_NO_FUSED_BOUNCE):          # the fused bounce stage (small frames) and the two-stage form (large ones)
+        on = render_case(hostsim_backend, b, res, spp, mb, None, {'tuning': {'workers': 1, 'flags': form}}, device=torch.device('cpu'))
+        off = render_case(hostsim_backend, b, res, spp, mb, None, {'tuning': {'workers': 1, 'flags': form | K.TUNE_TRACE_EVERY_CONTINUATION}},
+                          device=torch.device('cpu'))
+        for k in on:
+            assert np.array_equal(np.asarray(on[k]), np.asarray(off[k])), (case, form, k)
