@@ -455,13 +455,18 @@ struct Backward {
             nee_slots = arena.get<int>(P);
             gather_cands = arena.get<GatherCand>((size_t)kGatherCands * P);
             gshared.book = arena.get<GatherBook>(1);
-            gshared.heavy_slot = arena.get<int>(kGatherHeavyCap);
-            gshared.work = arena.get<GatherWork>(kGatherWorkCap);
-            gshared.cands_big = arena.get<GatherCand>((size_t)kGatherCandsBig * kGatherHeavyCap);
-            gshared.heavy_cap = kGatherHeavyCap; gshared.work_cap = kGatherWorkCap;
+            // The lists of the next-event-mode pick's heavy slots (more than kGatherCands candidates or kGatherBudget pops: ~0.3 % of
+            // the slots of the Cornell-box benchmark) grow with the launch set: 8 192 heavy slots / 131 072 work items were sized for
+            // one-sample launches of a 1024 x 1024 frame -- an 8-sample set has ~11 k heavy slots, and every slot past the cap fell
+            // back to the reference-order walk (a few thousand sequential walks: 4.5 ms per launch set, profiles/r6_notes.md 8b).
+            gshared.heavy_cap = (int)std::min<long long>(std::max<long long>((long long)P / 256, kGatherHeavyCap), kGatherHeavyMax);
+            gshared.work_cap = (int)std::min<long long>(std::max<long long>((long long)P / 32, kGatherWorkCap), kGatherWorkMax);
+            gshared.heavy_slot = arena.get<int>(gshared.heavy_cap);
+            gshared.work = arena.get<GatherWork>(gshared.work_cap);
+            gshared.cands_big = arena.get<GatherCand>((size_t)kGatherCandsBig * gshared.heavy_cap);
             // tests: small lists, so that the overflow paths run (rdr_tuning::gather_*_cap_plus1)
-            if (tuning().gather_heavy_cap >= 0) gshared.heavy_cap = std::min(tuning().gather_heavy_cap, kGatherHeavyCap);
-            if (tuning().gather_work_cap >= 0) gshared.work_cap = std::min(tuning().gather_work_cap, kGatherWorkCap);
+            if (tuning().gather_heavy_cap >= 0) gshared.heavy_cap = std::min(tuning().gather_heavy_cap, gshared.heavy_cap);
+            if (tuning().gather_work_cap >= 0) gshared.work_cap = std::min(tuning().gather_work_cap, gshared.work_cap);
             h_leaves = arena.get<HLeaf>((size_t)kHSamples * P);
             h_spill = arena.get<HLeaf>((size_t)(kHSamples - kHStackLds) * P);
             h_descent = arena.get<HDescent>((size_t)P);
@@ -565,8 +570,8 @@ struct Backward {
                 constexpr int NS = decltype(tag)::value;
                 const int budget = tuning().gather_budget;
                 launch_v(LEAN, nN, SecEdgeGatherN<NS>{sa, nee_slots, sec_picks, gather_cands, gshared, budget});
-                launch_v(LEAN, kGatherWorkCap, SecEdgeGatherSub<NS>{sa, nee_slots, gshared});
-                launch_v(LEAN, kGatherHeavyCap, SecEdgeGatherReplay{sa, nee_slots, sec_picks, gshared});
+                launch_v(LEAN, gshared.work_cap, SecEdgeGatherSub<NS>{sa, nee_slots, gshared});
+                launch_v(LEAN, gshared.heavy_cap, SecEdgeGatherReplay{sa, nee_slots, sec_picks, gshared});
             };
             if (gneed <= 24) passes(std::integral_constant<int, 24>{});
             else if (gneed <= 40) passes(std::integral_constant<int, 40>{});

@@ -1151,11 +1151,12 @@ RDR_FN int gather_entry(const GatherQuad &lo, const GatherQuad &hi) {      // st
 // A slot whose lists overflow (kGatherCandsBig candidates, kGatherHeavyCap slots, kGatherWorkCap items) keeps the
 // kPickOverflow mark and is walked by SecEdgePickNWalk.
 constexpr int kGatherBudget = 256, kGatherCandsBig = 256, kGatherHeavyCap = 8192, kGatherWorkCap = 131072, kGatherPoison = 1 << 20;
+constexpr int kGatherHeavyMax = 65536, kGatherWorkMax = 1 << 20;      // (kGatherHeavyCap / kGatherWorkCap: the smallest lists; render.cpp sizes them by the launch set)
 struct GatherWork { int heavy, entry; };
 struct GatherBook {                 // zeroed before every SecEdgeGatherN launch
     int heavy_count, work_count;
     int walk_needed;                // some slot keeps its kPickOverflow mark: SecEdgePickNWalk has work (else it returns at once)
-    int cand_count[kGatherHeavyCap];
+    int cand_count[kGatherHeavyMax];
 };
 // heavy_cap / work_cap: how much of the (kGatherHeavyCap / kGatherWorkCap sized) lists may be used -- the full size, or less
 // when RDR_GATHER_CAPS=h,w asks for it, which is how the tests reach the overflow paths.
