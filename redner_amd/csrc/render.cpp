@@ -560,7 +560,7 @@ struct Backward {
 
     template <int LEAN> void launch_pick_n(int need, exec::Count nN, const SecEdgeArgs &sa) {
         // order-free gather over the billboard hierarchy (SecEdgeGatherN), then the reference-order walk for the slots it
-        // marked kPickOverflow (none in practice); RDR_PICKN_WALK=1 walks every slot instead (A/B measurements)
+        // marked kPickOverflow (none once the big lists hold every heavy slot); RDR_PICKN_WALK=1 walks every slot (A/B measurements)
         const bool walk_all = tuning().has(RDR_TUNE_PICKN_WALK);
         const bool gather = !walk_all && sa.es.gather.num_nodes > 0;
         if (gather) {
