@@ -20,7 +20,7 @@ outside the timed region and reported separately; inputs 
 
 The library parks at most 8 GiB of device memory between calls by default; this benchmark owns its GPU and raises the bound to
 32 GiB (`config.pool_cap_mb`; RDR_POOL_CAP_MB overrides): two sample workers x 8 Sobol' samples of the frame per launch set
-(8 GiB: 2 x 2, 69.7 Msamples/s; 16 GiB: 2 x 4, 74.1; 32 GiB: 2 x 8, 74.4-76.1; profiles/r6_notes.md).  `config.samples_per_launch` /
+(8 GiB: 2 x 2, 77.7 Msamples/s; 16 GiB: 2 x 4, 84.3; 32 GiB: 2 x 8, 86.0 at the end of round 6; profiles/r6_notes.md).  `config.samples_per_launch` /
 `config.sample_workers` say how the library scheduled the timed steps.  per_rank_ms_per_step / per_rank_render_ms_per_step: every
 rank's wall time per step and the part of it inside render() (the rest: the one collective per step + waiting for the slowest rank).
 
@@ -607,7 +607,7 @@ def main():
     # The library parks at most 8 GiB of buffers between calls by default (it may share the device with torch's allocator).  This
     # process owns its GPU: it raises the bound -- stated in the line (`config.pool_cap_mb`) -- so that two sample workers keep
     # 8-sample batches of the 1024 x 1024 frame resident (32 GiB of the 288; RDR_POOL_CAP_MB overrides.  Measured on the final
-    # tree, profiles/r6_notes.md: 8 GiB 72.4, 16 GiB 74.1, 32 GiB 75.5, 64 GiB 75.7 Msamples/s).
+    # tree, profiles/r6_notes.md: 8 GiB 72.4, 16 GiB 74.1, 32 GiB 75.5, 64 GiB 75.7 Msamples/s when it was measured; 77.7 / 84.3 / 86.0 at the end of round 6).
     if 'RDR_POOL_CAP_MB' not in os.environ:
         redner.set_pool_cap_mb(BENCH_POOL_CAP_MB)
     pool_cap_mb = redner.get_pool_cap_mb()
